@@ -1,0 +1,114 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or called from the product
+ * (whisper_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * rv_oracle: a scalar CPU restatement, in plain C, of the reference ISS hot path
+ * (tenstorrent/whisper Hart<URV>::untilAddress / singleStep, /root/reference/Hart.cpp:6003,7417)
+ * for one hart with a private RAM arena.  Each function cites the reference lines it follows.
+ *
+ * Pinning (see DESIGN.md "Oracle"): Hart.cpp itself cannot be compiled in this image (it needs
+ * Boost headers the image lacks), so the restatement is pinned by
+ *   - the captured reference commit logs in SURVEY.md Appendix D (tests/golden/appendix_d_*.json),
+ *   - the reference's own Decoder/Disassembler and vendored SoftFloat compiled from
+ *     /root/reference into oracle/_ref (this file *calls* that SoftFloat for all F/D arithmetic).
+ */
+#ifndef RV_ORACLE_H
+#define RV_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ISA option bits (letters of the --isa string that matter to the hot path). */
+enum {
+  RVO_ISA_M = 1 << 0, RVO_ISA_A = 1 << 1, RVO_ISA_F = 1 << 2, RVO_ISA_D = 1 << 3,
+  RVO_ISA_C = 1 << 4, RVO_ISA_S = 1 << 5, RVO_ISA_U = 1 << 6, RVO_ISA_V = 1 << 7,
+  RVO_ISA_ZICNTR = 1 << 8
+};
+
+/* Stop reasons (mirror include/whisper_amd.h WSP_ST_*). */
+enum {
+  RVO_RUNNING = 0,
+  RVO_STOP_TOHOST = 1,     /* store to tohost with bit0 set; value = HTIF word (Hart.cpp:2665)      */
+  RVO_STOP_ILLEGAL = 2,    /* >16 consecutive no-di exceptions (Hart.cpp:3329-3340); value = 3      */
+  RVO_STOP_LIMIT = 3,      /* execCount reached the instruction limit (Hart.cpp:6025)               */
+  RVO_STOP_UNSUPPORTED = 4 /* outside the modelled subset; value = reason code                      */
+};
+
+/* Kinds of change in a commit record (printTrace.cpp:388-493 order r,f,v,m,c). */
+enum { RVO_CH_R = 1, RVO_CH_F = 2, RVO_CH_V = 3, RVO_CH_M = 4, RVO_CH_C = 5 };
+
+typedef struct {
+  uint32_t kind;
+  uint32_t pad;
+  uint64_t key;   /* register number / address / CSR number */
+  uint64_t val;
+} rvo_change;
+
+#define RVO_MAX_CHANGES 12
+typedef struct {
+  uint64_t tag;        /* execCount_ */
+  uint64_t pc;         /* currPc_ */
+  uint32_t inst;       /* raw bits (16-bit masked when compressed; 0 on fetch fault) */
+  uint8_t  size;       /* 2 or 4 */
+  uint8_t  priv;       /* privilege the instruction executed in: 0 U, 1 S, 3 M */
+  uint8_t  trap;       /* 1 exception, 2 interrupt */
+  uint8_t  nchanges;
+  rvo_change ch[RVO_MAX_CHANGES];
+} rvo_commit;
+
+typedef struct {
+  uint32_t xlen;        /* 64 (32 reserved) */
+  uint32_t isa;         /* RVO_ISA_* */
+  uint64_t mem_base;    /* arena = [mem_base, mem_base+mem_size): RWX, everything else faults */
+  uint64_t mem_size;
+  uint64_t tohost;      /* valid iff tohost_valid */
+  uint32_t tohost_valid;
+  uint32_t hart_id;
+  uint64_t reset_pc;
+} rvo_config;
+
+typedef struct rvo_hart rvo_hart;
+
+rvo_hart* rvo_create(const rvo_config* cfg);
+void      rvo_destroy(rvo_hart* h);
+/* Point the oracle at the reference SoftFloat (oracle/_ref/libsoftfloat_ref.so). Returns 0 on
+ * success. Must be called before any F/D instruction executes. */
+int       rvo_bind_softfloat(const char* path);
+
+int       rvo_write_mem(rvo_hart* h, uint64_t addr, const void* src, size_t n);
+int       rvo_read_mem(const rvo_hart* h, uint64_t addr, void* dst, size_t n);
+void      rvo_set_pc(rvo_hart* h, uint64_t pc);
+uint64_t  rvo_get_pc(const rvo_hart* h);
+void      rvo_set_x(rvo_hart* h, unsigned i, uint64_t v);
+uint64_t  rvo_get_x(const rvo_hart* h, unsigned i);
+void      rvo_set_f(rvo_hart* h, unsigned i, uint64_t v);
+uint64_t  rvo_get_f(const rvo_hart* h, unsigned i);
+/* peek/poke of the modelled CSRs by number; returns 0 when the CSR is modelled. */
+int       rvo_peek_csr(const rvo_hart* h, unsigned num, uint64_t* v);
+int       rvo_poke_csr(rvo_hart* h, unsigned num, uint64_t v);
+unsigned  rvo_priv(const rvo_hart* h);
+
+/* Run until a stop condition or until `max_exec` instructions have been executed in total
+ * (Hart::setInstructionCountLimit semantics: counts trapped instructions too).  If `log` is
+ * non-NULL up to `log_cap` commit records are stored and *log_n updated. Returns status. */
+int       rvo_run(rvo_hart* h, uint64_t max_exec, rvo_commit* log, size_t log_cap, size_t* log_n);
+
+int       rvo_status(const rvo_hart* h);
+uint64_t  rvo_stop_value(const rvo_hart* h);
+uint64_t  rvo_exec_count(const rvo_hart* h);
+uint64_t  rvo_retired_count(const rvo_hart* h);
+uint64_t  rvo_trace_hash(const rvo_hart* h);
+uint64_t  rvo_state_hash(const rvo_hart* h);
+uint64_t  rvo_mem_hash(const rvo_hart* h);
+
+/* The hash primitives the device kernels must reproduce bit-for-bit. */
+uint64_t  rvo_fold(uint64_t h, uint64_t w);
+uint64_t  rvo_mix(uint64_t x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,413 @@
+// Bit-exact IEEE-754 binary32/binary64 arithmetic in integer registers, for one hart per lane.
+//
+// Stands in for the reference's vendored Berkeley SoftFloat 3e as configured for RISC-V
+// (/root/reference/third_party/softfloat/source/RISCV/specialize.h: canonical NaN on every NaN
+// result, invalid on signaling NaNs, tininess detected AFTER rounding, RISC-V integer saturation
+// values), which the reference reaches through float-util.hpp:230-930.  Written from the IEEE
+// behaviour, not from the library's code: every operation funnels an exact (sign, exponent,
+// 128-bit significand + sticky) value through one rounding routine.  tests/test_softfloat.py
+// compares each entry point against the real library (oracle/_ref) on directed + random operands.
+//
+// All functions are WSP_HD so the same source is compiled into the HIP kernels and into the
+// host-side unit-test shim; there is no separate CPU implementation.
+#pragma once
+#include <stdint.h>
+
+#ifndef WSP_HD
+#  if defined(__HIPCC__) || defined(__CUDACC__)
+#    define WSP_HD __host__ __device__ __forceinline__
+#  else
+#    define WSP_HD inline
+#  endif
+#endif
+
+namespace wsf {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int64_t  i64;
+typedef int32_t  i32;
+
+enum { FL_NX = 1, FL_UF = 2, FL_OF = 4, FL_DZ = 8, FL_NV = 16 };
+enum { RM_RNE = 0, RM_RTZ = 1, RM_RDN = 2, RM_RUP = 3, RM_RMM = 4 };
+
+struct U128 { u64 hi, lo; };
+
+WSP_HD int clz64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return x ? __clzll((long long)x) : 64;
+#else
+  return x ? __builtin_clzll(x) : 64;
+#endif
+}
+
+WSP_HD U128 mul64x64(u64 a, u64 b)
+{
+  U128 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  r.hi = __umul64hi(a, b);
+  r.lo = a * b;
+#else
+  unsigned __int128 p = (unsigned __int128)a * b;
+  r.hi = (u64)(p >> 64);
+  r.lo = (u64)p;
+#endif
+  return r;
+}
+
+WSP_HD U128 shl128(U128 a, unsigned n)   // n in [0,127]
+{
+  U128 r;
+  if (n == 0) return a;
+  if (n >= 64) { r.hi = a.lo << (n - 64); r.lo = 0; }
+  else { r.hi = (a.hi << n) | (a.lo >> (64 - n)); r.lo = a.lo << n; }
+  return r;
+}
+
+WSP_HD U128 shr128_jam(U128 a, unsigned n)   // any n; bits shifted out are OR-ed into bit 0
+{
+  U128 r;
+  if (n == 0) return a;
+  if (n >= 128) { r.hi = 0; r.lo = (a.hi | a.lo) != 0; return r; }
+  if (n >= 64) {
+    unsigned m = n - 64;
+    u64 lost = a.lo | (m ? (a.hi << (64 - m)) : 0);
+    r.hi = 0; r.lo = (m ? (a.hi >> m) : a.hi) | (lost != 0);
+    return r;
+  }
+  u64 lost = a.lo << (64 - n);
+  r.hi = a.hi >> n;
+  r.lo = (a.hi << (64 - n)) | (a.lo >> n) | (lost != 0);
+  return r;
+}
+
+WSP_HD U128 add128(U128 a, U128 b) { U128 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi + (r.lo < a.lo); return r; }
+WSP_HD U128 sub128(U128 a, U128 b) { U128 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi - (a.lo < b.lo); return r; }
+WSP_HD bool lt128(U128 a, U128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+WSP_HD bool eq128(U128 a, U128 b) { return a.hi == b.hi && a.lo == b.lo; }
+
+// floor((hi:lo) / d) for hi < d and d normalised (bit 63 set); remainder in *rem.
+WSP_HD u64 div128by64(u64 hi, u64 lo, u64 d, u64* rem)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+  unsigned __int128 n = ((unsigned __int128)hi << 64) | lo;
+  *rem = (u64)(n % d);
+  return (u64)(n / d);
+#else
+  // schoolbook base-2^32 long division with two quotient digits (d has its top bit set)
+  const u64 b = 1ULL << 32;
+  u64 dh = d >> 32, dl = d & 0xffffffffULL;
+  u64 l1 = lo >> 32, l0 = lo & 0xffffffffULL;
+  u64 q1 = hi / dh, r = hi - q1 * dh;
+  while (q1 >= b || q1 * dl > ((r << 32) | l1)) { --q1; r += dh; if (r >= b) break; }
+  u64 un = ((hi << 32) | l1) - q1 * d;
+  u64 q0 = un / dh; r = un - q0 * dh;
+  while (q0 >= b || q0 * dl > ((r << 32) | l0)) { --q0; r += dh; if (r >= b) break; }
+  *rem = ((un << 32) | l0) - q0 * d;
+  return (q1 << 32) | q0;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+template <int EB_, int MB_> struct Fmt {
+  static constexpr int EB = EB_, MB = MB_;
+  static constexpr int BIAS = (1 << (EB_ - 1)) - 1;
+  static constexpr int EMAX = (1 << EB_) - 1;             // all-ones exponent field
+  static constexpr u64 MANT = (1ULL << MB_) - 1;
+  static constexpr u64 SIGN = 1ULL << (EB_ + MB_);
+  static constexpr u64 QNAN = ((u64)EMAX << MB_) | (1ULL << (MB_ - 1));   // canonical quiet NaN
+  static constexpr u64 INF = (u64)EMAX << MB_;
+};
+typedef Fmt<8, 23> F32;
+typedef Fmt<11, 52> F64;
+
+enum { K_ZERO = 0, K_FIN = 1, K_INF = 2, K_QNAN = 3, K_SNAN = 4 };
+struct Unp { int kind; bool sign; int exp; u64 sig; };   // finite: value = sig * 2^(exp-63), sig bit 63 set
+
+template <class F> WSP_HD Unp unpack(u64 a)
+{
+  Unp u;
+  u.sign = (a & F::SIGN) != 0;
+  int e = (int)((a >> F::MB) & (u64)F::EMAX);
+  u64 m = a & F::MANT;
+  u.exp = 0; u.sig = 0;
+  if (e == F::EMAX) { u.kind = m ? ((m >> (F::MB - 1)) ? K_QNAN : K_SNAN) : K_INF; return u; }
+  if (e == 0) {
+    if (!m) { u.kind = K_ZERO; return u; }
+    int lz = clz64(m);
+    u.kind = K_FIN; u.sig = m << lz;
+    u.exp = 1 - F::BIAS - F::MB + (63 - lz);     // subnormal: value = m * 2^(1-bias-MB)
+    return u;
+  }
+  u.kind = K_FIN; u.sig = ((1ULL << F::MB) | m) << (63 - F::MB); u.exp = e - F::BIAS;
+  return u;
+}
+
+// Round the exact value (-1)^sign * (sig.hi:sig.lo) * 2^(exp-127) (sig != 0) to format F.
+template <class F> WSP_HD u64 round_pack(bool sign, int exp, U128 sig, int rm, unsigned& fl)
+{
+  // normalise so the leading one sits at bit 126 (bit 62 of the high word)
+  int lz = sig.hi ? clz64(sig.hi) : 64 + clz64(sig.lo);
+  if (lz == 0) { sig = shr128_jam(sig, 1); exp += 1; }
+  else if (lz > 1) { sig = shl128(sig, (unsigned)(lz - 1)); exp -= lz - 1; }
+  exp -= 1;                                 // value = 1.f * 2^exp with the one at bit 126
+  u64 s = sig.hi | (sig.lo != 0);           // 63-bit significand with sticky in bit 0
+  const int RB = 62 - F::MB;                // number of bits to round away
+  const u64 rmask = (1ULL << RB) - 1, half = 1ULL << (RB - 1);
+  u64 inc = (rm == RM_RNE || rm == RM_RMM) ? half
+          : (rm == RM_RTZ) ? 0
+          : ((rm == RM_RDN) == sign) ? rmask : 0;   // RDN rounds negative magnitudes up, RUP positive
+  i64 e = (i64)exp + F::BIAS;               // biased exponent of the unrounded value
+  if (e <= 0) {
+    // tininess after rounding: tiny unless rounding at full precision reaches the smallest normal
+    bool tiny = e < 0 || (s + inc) < 0x8000000000000000ULL;
+    u64 sh = (u64)(1 - e);
+    s = sh >= 63 ? (u64)(s != 0) : ((s >> sh) | ((s << (64 - sh)) != 0));
+    if (tiny && (s & rmask)) fl |= FL_UF;
+    e = 0;
+  } else if (e >= F::EMAX || (e == F::EMAX - 1 && (s + inc) >= 0x8000000000000000ULL)) {
+    fl |= FL_OF | FL_NX;
+    bool to_inf = inc == half || inc == rmask;
+    u64 mag = to_inf ? F::INF : (F::INF - 1);
+    return (sign ? F::SIGN : 0) | mag;
+  }
+  u64 rb = s & rmask;
+  if (rb) fl |= FL_NX;
+  u64 r = (s + inc) >> RB;
+  if (rm == RM_RNE && rb == half) r &= ~1ULL;
+  // r holds the hidden bit at position MB for normals; adding it to the exponent field below
+  // accounts for it (and for a carry out of the significand).
+  u64 ef = e > 0 ? (u64)(e - 1) : 0;
+  if (e == 0) return (sign ? F::SIGN : 0) | r;
+  return (sign ? F::SIGN : 0) | ((ef << F::MB) + r);
+}
+
+template <class F> WSP_HD u64 nan_result(const Unp& a, const Unp& b, unsigned& fl)
+{ if (a.kind == K_SNAN || b.kind == K_SNAN) fl |= FL_NV; return F::QNAN; }
+
+// exact sum of two finite non-zero magnitudes with signs; result rounded to F.
+template <class F> WSP_HD u64 add_fin(bool sa, int ea, U128 xa, bool sb, int eb, U128 xb, int rm, unsigned& fl)
+{
+  // operands have their leading one at bit 126 of the 128-bit frame
+  if (ea < eb || (ea == eb && lt128(xa, xb))) { bool ts = sa; sa = sb; sb = ts; int te = ea; ea = eb; eb = te; U128 tx = xa; xa = xb; xb = tx; }
+  xb = shr128_jam(xb, (unsigned)(ea - eb > 200 ? 200 : ea - eb));
+  U128 r;
+  if (sa == sb) r = add128(xa, xb);
+  else {
+    r = sub128(xa, xb);
+    if (!(r.hi | r.lo)) return rm == RM_RDN ? F::SIGN : 0;     // exact cancellation
+  }
+  return round_pack<F>(sa, ea + 1, r, rm, fl);
+}
+
+WSP_HD U128 frame(u64 sig) { U128 r; r.hi = sig >> 1; r.lo = sig << 63; return r; }
+
+template <class F> WSP_HD u64 f_add(u64 a, u64 b, int rm, unsigned& fl, bool negate_b = false)
+{
+  Unp x = unpack<F>(a), y = unpack<F>(b);
+  if (x.kind >= K_QNAN || y.kind >= K_QNAN) return nan_result<F>(x, y, fl);
+  if (negate_b) { y.sign = !y.sign; b ^= F::SIGN; }
+  if (x.kind == K_INF || y.kind == K_INF) {
+    if (x.kind == K_INF && y.kind == K_INF && x.sign != y.sign) { fl |= FL_NV; return F::QNAN; }
+    return x.kind == K_INF ? a : b;
+  }
+  if (x.kind == K_ZERO && y.kind == K_ZERO) return (x.sign == y.sign) ? a : (rm == RM_RDN ? F::SIGN : 0);
+  if (x.kind == K_ZERO) return b;
+  if (y.kind == K_ZERO) return a;
+  return add_fin<F>(x.sign, x.exp, frame(x.sig), y.sign, y.exp, frame(y.sig), rm, fl);
+}
+
+template <class F> WSP_HD u64 f_sub(u64 a, u64 b, int rm, unsigned& fl) { return f_add<F>(a, b, rm, fl, true); }
+
+template <class F> WSP_HD u64 f_mul(u64 a, u64 b, int rm, unsigned& fl)
+{
+  Unp x = unpack<F>(a), y = unpack<F>(b);
+  if (x.kind >= K_QNAN || y.kind >= K_QNAN) return nan_result<F>(x, y, fl);
+  bool s = x.sign != y.sign;
+  if (x.kind == K_INF || y.kind == K_INF) {
+    if (x.kind == K_ZERO || y.kind == K_ZERO) { fl |= FL_NV; return F::QNAN; }
+    return (s ? F::SIGN : 0) | F::INF;
+  }
+  if (x.kind == K_ZERO || y.kind == K_ZERO) return s ? F::SIGN : 0;
+  return round_pack<F>(s, x.exp + y.exp + 1, mul64x64(x.sig, y.sig), rm, fl);
+}
+
+// a*b + c with a single rounding
+template <class F> WSP_HD u64 f_fma(u64 a, u64 b, u64 c, int rm, unsigned& fl)
+{
+  Unp x = unpack<F>(a), y = unpack<F>(b), z = unpack<F>(c);
+  bool sp = x.sign != y.sign;
+  if (x.kind >= K_QNAN || y.kind >= K_QNAN || z.kind >= K_QNAN) {
+    if (x.kind == K_SNAN || y.kind == K_SNAN || z.kind == K_SNAN) fl |= FL_NV;
+    // inf * 0 is invalid even when the addend is a quiet NaN
+    if ((x.kind == K_INF && y.kind == K_ZERO) || (x.kind == K_ZERO && y.kind == K_INF)) fl |= FL_NV;
+    return F::QNAN;
+  }
+  if (x.kind == K_INF || y.kind == K_INF) {
+    if (x.kind == K_ZERO || y.kind == K_ZERO) { fl |= FL_NV; return F::QNAN; }
+    if (z.kind == K_INF && z.sign != sp) { fl |= FL_NV; return F::QNAN; }
+    return (sp ? F::SIGN : 0) | F::INF;
+  }
+  if (z.kind == K_INF) return c;
+  if (x.kind == K_ZERO || y.kind == K_ZERO) {
+    if (z.kind == K_ZERO) return (sp == z.sign) ? c : (rm == RM_RDN ? F::SIGN : 0);
+    return c;
+  }
+  U128 p = mul64x64(x.sig, y.sig);          // leading one at bit 127 or 126
+  int ep = x.exp + y.exp;
+  if (p.hi >> 63) { p = shr128_jam(p, 1); ep += 1; }   // exact: at most 106 significant bits... low bit is 0
+  if (z.kind == K_ZERO) return round_pack<F>(sp, ep + 1, p, rm, fl);
+  return add_fin<F>(sp, ep, p, z.sign, z.exp, frame(z.sig), rm, fl);
+}
+
+template <class F> WSP_HD u64 f_div(u64 a, u64 b, int rm, unsigned& fl)
+{
+  Unp x = unpack<F>(a), y = unpack<F>(b);
+  if (x.kind >= K_QNAN || y.kind >= K_QNAN) return nan_result<F>(x, y, fl);
+  bool s = x.sign != y.sign;
+  if (x.kind == K_INF) { if (y.kind == K_INF) { fl |= FL_NV; return F::QNAN; } return (s ? F::SIGN : 0) | F::INF; }
+  if (y.kind == K_INF) return s ? F::SIGN : 0;
+  if (y.kind == K_ZERO) {
+    if (x.kind == K_ZERO) { fl |= FL_NV; return F::QNAN; }
+    fl |= FL_DZ; return (s ? F::SIGN : 0) | F::INF;
+  }
+  if (x.kind == K_ZERO) return s ? F::SIGN : 0;
+  u64 rem, q; int e = x.exp - y.exp;
+  if (x.sig < y.sig) { q = div128by64(x.sig, 0, y.sig, &rem); e -= 1; }
+  else q = div128by64(x.sig >> 1, x.sig << 63, y.sig, &rem);
+  U128 sg; sg.hi = q; sg.lo = rem != 0;     // value = q * 2^(e-63) = (q*2^64) * 2^(e-127)
+  return round_pack<F>(s, e, sg, rm, fl);
+}
+
+// floor(sqrt(n)) for a 128-bit n >= 2^126, with *inexact set when n is not a perfect square
+WSP_HD u64 isqrt128(U128 n, bool* inexact)
+{
+  U128 rem = n, res = { 0, 0 };
+  U128 bit = { 1ULL << 62, 0 };             // highest power of four <= 2^126
+  for (int i = 0; i < 64; ++i) {
+    U128 t = add128(res, bit);
+    res = shr128_jam(res, 1);                // low bit of res is always 0 here: no jamming occurs
+    if (!lt128(rem, t)) { rem = sub128(rem, t); res = add128(res, bit); }
+    bit.lo = (bit.lo >> 2) | (bit.hi << 62); bit.hi >>= 2;
+  }
+  *inexact = (rem.hi | rem.lo) != 0;
+  return res.lo;
+}
+
+template <class F> WSP_HD u64 f_sqrt(u64 a, int rm, unsigned& fl)
+{
+  Unp x = unpack<F>(a);
+  if (x.kind >= K_QNAN) { if (x.kind == K_SNAN) fl |= FL_NV; return F::QNAN; }
+  if (x.kind == K_ZERO) return a;
+  if (x.sign) { fl |= FL_NV; return F::QNAN; }
+  if (x.kind == K_INF) return a;
+  U128 n; int e;
+  if (x.exp & 1) { n.hi = x.sig; n.lo = 0; e = (x.exp - 1) / 2; }           // sig*2^64, in [2^127,2^128)
+  else { n.hi = x.sig >> 1; n.lo = x.sig << 63; e = x.exp / 2; }            // sig*2^63, in [2^126,2^127)
+  bool inex; u64 r = isqrt128(n, &inex);                                     // r in [2^63, 2^64)
+  U128 sg; sg.hi = r; sg.lo = inex;
+  return round_pack<F>(false, e, sg, rm, fl);
+}
+
+// ---- conversions -------------------------------------------------------------------------
+// Round |value| to an integer: returns magnitude in *mag, false if it does not fit 64 bits.
+WSP_HD bool round_to_mag(const Unp& x, int rm, u64* mag, bool* inexact)
+{
+  if (x.exp > 63) return false;
+  int sh = 63 - x.exp;                      // >= 0
+  u64 ip, frac_hi; bool frac_nz, ge_half, gt_half;
+  if (sh == 0) { ip = x.sig; frac_nz = ge_half = gt_half = false; }
+  else if (sh < 64) {
+    ip = x.sig >> sh; u64 rem = x.sig << (64 - sh);     // fraction left-aligned
+    frac_nz = rem != 0; ge_half = (rem >> 63) != 0; gt_half = ge_half && (rem << 1) != 0;
+  } else if (sh == 64) { ip = 0; frac_nz = true; ge_half = true; gt_half = (x.sig << 1) != 0; }
+  else { ip = 0; frac_nz = true; ge_half = gt_half = false; }
+  (void)frac_hi;
+  bool up = rm == RM_RNE ? (gt_half || (ge_half && (ip & 1)))
+          : rm == RM_RMM ? ge_half
+          : rm == RM_RTZ ? false
+          : rm == RM_RDN ? (x.sign && frac_nz) : (!x.sign && frac_nz);
+  if (up) { ip += 1; if (ip == 0) return false; }
+  *mag = ip; *inexact = frac_nz;
+  return true;
+}
+
+template <class F> WSP_HD u64 f_to_int(u64 a, int rm, bool is_signed, bool is64, unsigned& fl)
+{
+  Unp x = unpack<F>(a);
+  const u64 pos_max = is_signed ? (is64 ? 0x7fffffffffffffffULL : 0x7fffffffULL) : (is64 ? ~0ULL : 0xffffffffULL);
+  const u64 neg_ovf = is_signed ? (is64 ? 0x8000000000000000ULL : 0xffffffff80000000ULL) : 0;
+  if (x.kind >= K_QNAN) { fl |= FL_NV; return pos_max; }
+  if (x.kind == K_INF) { fl |= FL_NV; return x.sign ? neg_ovf : pos_max; }
+  if (x.kind == K_ZERO) return 0;
+  u64 mag; bool inex;
+  if (!round_to_mag(x, rm, &mag, &inex)) { fl |= FL_NV; return x.sign ? neg_ovf : pos_max; }
+  if (x.sign) {
+    if (is_signed) {
+      u64 lim = is64 ? 0x8000000000000000ULL : 0x80000000ULL;
+      if (mag > lim) { fl |= FL_NV; return neg_ovf; }
+      if (inex) fl |= FL_NX;
+      return (u64)(-(i64)mag);
+    }
+    if (mag != 0) { fl |= FL_NV; return neg_ovf; }
+    if (inex) fl |= FL_NX;
+    return 0;
+  }
+  if (mag > pos_max) { fl |= FL_NV; return pos_max; }
+  if (inex) fl |= FL_NX;
+  return mag;
+}
+
+template <class F> WSP_HD u64 int_to_f(u64 v, bool is_signed, bool is64, int rm, unsigned& fl)
+{
+  bool sign = false; u64 mag;
+  if (is64) { if (is_signed && (i64)v < 0) { sign = true; mag = (u64)(-(i64)v); } else mag = v; }
+  else { if (is_signed && (i32)v < 0) { sign = true; mag = (u64)(-(i64)(i32)v); } else mag = (u32)v; }
+  if (!mag) return 0;
+  U128 sg; sg.hi = mag; sg.lo = 0;          // mag * 2^64 * 2^(63-127)
+  return round_pack<F>(sign, 63, sg, rm, fl);
+}
+
+WSP_HD u64 f32_to_f64(u64 a, unsigned& fl)
+{
+  Unp x = unpack<F32>(a);
+  if (x.kind >= K_QNAN) { if (x.kind == K_SNAN) fl |= FL_NV; return F64::QNAN; }
+  u64 s = x.sign ? F64::SIGN : 0;
+  if (x.kind == K_INF) return s | F64::INF;
+  if (x.kind == K_ZERO) return s;
+  return s | ((u64)(x.exp + F64::BIAS) << 52) | ((x.sig << 1) >> 12);
+}
+
+WSP_HD u64 f64_to_f32(u64 a, int rm, unsigned& fl)
+{
+  Unp x = unpack<F64>(a);
+  if (x.kind >= K_QNAN) { if (x.kind == K_SNAN) fl |= FL_NV; return F32::QNAN; }
+  u64 s = x.sign ? F32::SIGN : 0;
+  if (x.kind == K_INF) return s | F32::INF;
+  if (x.kind == K_ZERO) return s;
+  U128 sg; sg.hi = x.sig; sg.lo = 0;
+  return round_pack<F32>(x.sign, x.exp, sg, rm, fl);
+}
+
+// ---- non-arithmetic helpers (the reference uses host float ops here: float.cpp:499-829) ----
+template <class F> WSP_HD bool is_nan(u64 a) { return (a & F::INF) == F::INF && (a & F::MANT); }
+template <class F> WSP_HD bool is_snan(u64 a) { return is_nan<F>(a) && !((a >> (F::MB - 1)) & 1); }
+template <class F> WSP_HD bool lt_ord(u64 a, u64 b)   // a < b for non-NaN operands
+{
+  const u64 mag = F::SIGN - 1;
+  bool sa = (a & F::SIGN) != 0, sb = (b & F::SIGN) != 0;
+  if (!((a | b) & mag)) return false;
+  if (sa != sb) return sa;
+  return sa ? ((a & mag) > (b & mag)) : ((a & mag) < (b & mag));
+}
+template <class F> WSP_HD bool eq_ord(u64 a, u64 b) { const u64 mag = F::SIGN - 1; return a == b || !((a | b) & mag); }
+template <class F> WSP_HD unsigned fclass(u64 a)
+{
+  bool s = (a & F::SIGN) != 0; int e = (int)((a >> F::MB) & (u64)F::EMAX); u64 m = a & F::MANT;
+  if (e == F::EMAX) return m ? (((m >> (F::MB - 1)) & 1) ? 0x200u : 0x100u) : (s ? 1u : 0x80u);
+  if (e == 0) return m ? (s ? 4u : 0x20u) : (s ? 8u : 0x10u);
+  return s ? 2u : 0x40u;
+}
+
+}  // namespace wsf
