@@ -1,0 +1,129 @@
+/*
+ * whisper_amd C ABI: batched RISC-V hart execution on MI355X (gfx950).
+ *
+ * The reference (tenstorrent/whisper) has no FFI for its execution path: every front end drives
+ * the C++ classes System<URV>/Hart<URV> directly.  Each entry point below
+ * names the reference call(s) it stands in for; file:line are into /root/reference.  A batch is
+ * N independent single-hart systems, each with a private RAM arena [mem_base, mem_base+mem_size);
+ * all run in lock step on one HIP device.  Plain C types only, caller-owned buffers, 0 or a
+ * negative WSP_E* code returned, message via wsp_last_error() (mirrors the reference's
+ * bool + "Error:" line on stderr).  No exceptions cross the ABI.
+ *
+ * The run entry points are HIP-only.  There is no CPU fallback: with no usable device
+ * wsp_batch_create fails with WSP_ENODEV.
+ */
+#ifndef WHISPER_AMD_H
+#define WHISPER_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wsp_batch wsp_batch;
+
+enum { WSP_OK = 0, WSP_EINVAL = -1, WSP_ENODEV = -2, WSP_ENOMEM = -3, WSP_EIO = -4, WSP_EFORMAT = -5,
+       WSP_ERANGE = -6, WSP_EUNSUPPORTED = -7, WSP_EHIP = -8 };
+
+/* Hart stop states (wsp_result.status). */
+enum { WSP_ST_RUNNING = 0,
+       WSP_ST_STOP_TOHOST = 1,      /* store to tohost, bit 0 set (Hart.cpp:2665); success iff (value>>1)==0 (printTrace.cpp:943) */
+       WSP_ST_STOP_ILLEGAL = 2,     /* >16 consecutive illegal/no-di exceptions (Hart.cpp:3329-3340), value 3 */
+       WSP_ST_STOP_LIMIT = 3,       /* instruction-count limit reached (Hart.cpp:6025, setInstructionCountLimit) */
+       WSP_ST_STOP_UNSUPPORTED = 4  /* left the modelled subset; stop_value holds the reason */ };
+
+/* Resources for peek/poke (Hart::peekIntReg/pokeIntReg ... Hart.hpp:219-325, Hart.cpp:1345-1560). */
+enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4 };
+
+/* wsp_batch_run flags */
+enum { WSP_RUN_TRACE_HASH = 1 /* fold every commit record (printTrace.cpp:302-517) into trace_hash */ };
+/* wsp_batch_load_image flags */
+enum { WSP_LOAD_EXEC = 1 /* bytes are code: pre-decode them */ };
+
+typedef struct {
+  uint32_t xlen;            /* 64 (32 is reserved)                                        */
+  uint32_t n_harts;         /* number of independent single-hart systems                                   */
+  const char* isa;          /* e.g. "rv64imafdc_zicsr" (Hart::configIsa, Hart.cpp:5122; Isa.cpp:561)       */
+  uint64_t mem_base;        /* arena base; accesses outside the arena take access faults (PMA no-access)   */
+  uint64_t mem_size;        /* bytes per hart, multiple of 4096 (System ctor memSize, System.cpp:50)       */
+  uint32_t lanes_per_wave;  /* 0 = auto; else 8/16/32/64 harts per 64-lane wavefront                      */
+  int32_t  device;          /* HIP device ordinal, -1 = current                                            */
+  uint32_t hart_id_base;    /* mhartid of hart 0 (core_hart_id_offset)                                     */
+  uint32_t reserved;
+} wsp_batch_desc;
+
+typedef struct {
+  uint32_t status;          /* WSP_ST_*                                                                    */
+  uint32_t priv;            /* final privilege mode (0 U, 1 S, 3 M)                                        */
+  uint64_t stop_value;      /* tohost value / 3 / unsupported reason                                       */
+  uint64_t pc;
+  uint64_t exec_count;      /* Hart::getInstructionCount (execCount_: traps included)                      */
+  uint64_t retired_count;   /* Hart::getRetiredInstructionCount                                            */
+  uint64_t state_hash;      /* digest of pc, x1..x31, f0..f31, privilege and the modelled CSRs             */
+  uint64_t mem_hash;        /* digest of the hart's whole RAM arena                                        */
+  uint64_t trace_hash;      /* digest of all commit records (0 unless WSP_RUN_TRACE_HASH)                  */
+} wsp_result;
+
+/* One pre-decoded instruction as produced by the device decoder (test/diagnostic surface). */
+typedef struct { uint32_t w0; int32_t imm; uint32_t raw; uint32_t pad; } wsp_decoded;
+
+/* System ctor + HartConfig::configHarts/configMemory + Hart::configIsa + Hart::reset
+ * (System.cpp:50, HartConfig.cpp:3282/3414, Hart.cpp:5122, 942). */
+int  wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out);
+void wsp_batch_destroy(wsp_batch* b);
+
+/* System::loadElfFiles (System.cpp:288) for harts [hart_lo, hart_hi): PT_LOAD by physical address,
+ * p_filesz bytes (Memory.cpp:450-489); pc=entry, gp=__global_pointer$, tp=.tdata (System.cpp:334-354);
+ * tohost symbol -> stop address (System.cpp:323). */
+int  wsp_batch_load_elf(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, const char* path);
+/* Same from an in-memory ELF image. */
+int  wsp_batch_load_elf_mem(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, const void* elf, size_t n);
+/* System::loadHexFiles/loadBinaryFiles / Hart::pokeMemory (System.cpp:363,434; Hart.cpp:1345). */
+int  wsp_batch_load_image(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t addr, const void* bytes, size_t n, uint32_t flags);
+/* Address of an ELF symbol of the last ELF loaded into `hart` (Memory::findElfSymbol). */
+int  wsp_batch_symbol(wsp_batch* b, uint32_t hart, const char* name, uint64_t* addr);
+
+/* Hart::poke* / peek* for one hart. idx = register number, CSR number or byte address; size in
+ * bytes (8 for PC/X/F/CSR, 1..n for MEM). */
+int  wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_t idx, const void* val, size_t size);
+int  wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_t idx, void* val, size_t size);
+/* Poke a different 64-bit value into the same X register / memory dword of every hart in
+ * [hart_lo, hart_hi) (per-instance seeds); vals has hart_hi-hart_lo entries. */
+int  wsp_batch_poke_each(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint32_t res, uint64_t idx, const uint64_t* vals);
+
+/* Hart::setToHostAddress (Hart.cpp:1626) + setInstructionCountLimit (Hart.hpp:1385).
+ * tohost = UINT64_MAX leaves/clears it; max_inst = UINT64_MAX means no limit. */
+int  wsp_batch_set_stop(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t tohost, uint64_t max_inst);
+
+/* System::batchRun / Hart::run (System.cpp:1654, Hart.cpp:6963): step every running hart until it
+ * stops or has executed max_steps more instructions. Returns the number of harts still running
+ * (>= 0) or a negative error. */
+int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flags);
+/* Seconds the device spent inside the step kernel during the last wsp_batch_run (HIP events on
+ * the batch's stream) and the number of kernel launches it took. */
+int  wsp_batch_last_run_stats(wsp_batch* b, double* kernel_seconds, uint32_t* launches);
+
+/* Fill out[0 .. n_harts) (computes the state and memory digests on the device). */
+int  wsp_batch_results(wsp_batch* b, wsp_result* out);
+/* Seconds spent in the memory-digest kernel during the last wsp_batch_results and its HBM bytes. */
+int  wsp_batch_last_hash_stats(wsp_batch* b, double* kernel_seconds, uint64_t* bytes);
+
+/* System::produceTestSignatureFile (System.cpp:1586-1633): 32-bit words from begin_signature to
+ * end_signature of `hart`; writes up to cap words, returns the word count or a negative error. */
+int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap);
+
+/* Run the device decoder (the one the step kernel uses) over n instruction words. */
+int  wsp_decode_words(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out);
+/* The same decoder compiled for the host (no device needed; used by CPU-only tests). */
+int  wsp_decode_words_host(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out);
+/* Parse an ISA string into the internal option bit set (tests). */
+uint32_t wsp_isa_flags(const char* isa);
+
+const char* wsp_last_error(void);
+const char* wsp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -603,7 +603,7 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   int cls = csr_class(h, num);
   int do_read = (op != 1) || rd != 0;
   int do_write = (op == 1) || src_field_nz;
-  if (cls < 0) { stop(h, RVO_STOP_UNSUPPORTED, num); return; }
+  if (cls < 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x10000 | num); return; }
   if (cls == 0) { illegal(h, inst); return; }
   if ((num == C_FFLAGS || num == C_FRM || num == C_FCSR) && !fp_legal(h)) { illegal(h, inst); return; }
   if (!csr_readable(h, num) || (do_write && !csr_writeable(h, num))) { illegal(h, inst); return; }
@@ -618,7 +618,7 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   if (num == C_SATP) {
     unsigned mode = (unsigned)(next >> 60);
     if (mode != 0 && mode != 8 && mode != 9 && mode != 10) goto done;  /* unsupported MODE: dropped (13284-13294) */
-    if (mode != 0) { stop(h, RVO_STOP_UNSUPPORTED, num); return; }
+    if (mode != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return; }
   }
   csr_store(h, num, next, 1);
   if ((num == C_FFLAGS || num == C_FRM || num == C_FCSR)) mark_fs_dirty(h);  /* postCsrUpdate: FS dirty on fp csr write */

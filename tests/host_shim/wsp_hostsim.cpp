@@ -1,0 +1,114 @@
+// TEST TOOL (never loaded by the whisper_amd package): compiles the device semantics header
+// whisper_amd/csrc/wsp_core.h for the host and steps ONE hart serially, so that the decoder,
+// softfloat and per-lane step logic that the HIP kernel runs can be diffed against the oracle
+// on the CPU-only build machine.  The product path is the HIP kernel in wsp_lib.hip; GPU parity
+// tests (pytest -m gpu) go through the C ABI, not through this file.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../whisper_amd/csrc/wsp_core.h"
+using namespace wsp;
+
+struct HostMem {
+  u64 x[32], f[32], cold_[CI_COUNT];
+  u8* ram;
+  u64 rx(u32 r) const { return x[r]; }
+  void wx(u32 r, u64 v) { x[r] = v; }
+  u64 rf(u32 r) const { return f[r]; }
+  void wf(u32 r, u64 v) { f[r] = v; }
+  u64& cold(u32 i) { return cold_[i]; }
+  u8 ld8(u64 o) const { return ram[o]; }
+  u16 ld16(u64 o) const { u16 v; memcpy(&v, ram + o, 2); return v; }
+  u32 ld32(u64 o) const { u32 v; memcpy(&v, ram + o, 4); return v; }
+  u64 ld64(u64 o) const { u64 v; memcpy(&v, ram + o, 8); return v; }
+  void st8(u64 o, u8 v) { ram[o] = v; }
+  void st16(u64 o, u16 v) { memcpy(ram + o, &v, 2); }
+  void st32(u64 o, u32 v) { memcpy(ram + o, &v, 4); }
+  void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
+};
+
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<Rec> recs; u64 max_exec; };
+
+extern "C" {
+Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id)
+{
+  Sim* s = new Sim();
+  s->ram.assign(mem_size, 0);
+  memset(&s->L, 0, sizeof s->L);
+  s->L.m.ram = s->ram.data();
+  s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
+  s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
+  s->max_exec = ~0ULL;
+  return s;
+}
+void hs_destroy(Sim* s) { delete s; }
+int hs_write_mem(Sim* s, u64 addr, const void* src, u64 n)
+{ if (!s->L.in_mem(addr, n)) return -1; memcpy(s->ram.data() + (addr - s->L.mem_base), src, n); return 0; }
+int hs_read_mem(Sim* s, u64 addr, void* dst, u64 n)
+{ if (!s->L.in_mem(addr, n)) return -1; memcpy(dst, s->ram.data() + (addr - s->L.mem_base), n); return 0; }
+// pre-decode [addr, addr+n) exactly as wsp_predecode_kernel does
+void hs_predecode(Sim* s, u64 addr, u64 n)
+{
+  n &= ~1ULL;
+  const u8* img = s->ram.data() + (addr - s->L.mem_base);
+  s->recs.assign(n / 2, Rec());
+  for (u64 off = 0; off + 2 <= n; off += 2) {
+    u32 lo = img[off] | ((u32)img[off + 1] << 8); Rec r;
+    if ((lo & 3) != 3) r = decode16(lo, s->L.isa);
+    else if (off + 4 <= n) r = decode32(lo | ((u32)img[off + 2] << 16) | ((u32)img[off + 3] << 24), s->L.isa);
+    else { r = mk(OP_SLOWFETCH, 0, 0, 0, 0); r.raw = lo; }
+    s->recs[off / 2] = r;
+  }
+  s->L.text_lo = addr; s->L.text_hi = addr + n;
+}
+void hs_set_pc(Sim* s, u64 pc) { s->L.h.pc = pc & ~1ULL; }
+void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = v; }
+u64 hs_get_x(Sim* s, u32 i) { return s->L.m.x[i & 31]; }
+u64 hs_get_f(Sim* s, u32 i) { return s->L.m.f[i & 31]; }
+void hs_set_f(Sim* s, u32 i, u64 v) { s->L.m.f[i & 31] = v; }
+u64 hs_get_pc(Sim* s) { return s->L.h.pc; }
+u64 hs_csr(Sim* s, u32 num) { return s->L.csr_peek(num); }
+void hs_poke_csr(Sim* s, u32 num, u64 v) { s->L.csr_store(num, v); s->L.s.chg = 0; }
+int hs_run(Sim* s, u64 max_exec, int trace)
+{
+  Lane<HostMem>& L = s->L;
+  while (L.h.status == ST_RUNNING) {
+    if (L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; break; }
+    Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+    u64 a = 0, b = 0, cur_pc = 0; u32 priv0 = 0;
+    bool todo = trace ? L.step_begin<true>(s->recs.data(), rec, a, b, cur_pc, priv0) : L.step_begin<false>(s->recs.data(), rec, a, b, cur_pc, priv0);
+    if (!todo) continue;
+    L.exec(rec.w0 & 0xff, rec, a, b, cur_pc);
+    if (trace) L.step_end<true>(rec, cur_pc, priv0); else L.step_end<false>(rec, cur_pc, priv0);
+  }
+  return (int)L.h.status;
+}
+u64 hs_stop_value(Sim* s) { return s->L.h.stop_value; }
+u64 hs_exec(Sim* s) { return s->L.h.exec; }
+u64 hs_retired(Sim* s) { return s->L.h.retired; }
+u64 hs_thash(Sim* s) { return s->L.h.thash; }
+u32 hs_priv(Sim* s) { return s->L.h.priv; }
+u64 hs_state_hash(Sim* s)
+{
+  Lane<HostMem>& L = s->L; u64 h = 0;
+  h = fold(h, L.h.pc);
+  for (int i = 1; i < 32; ++i) h = fold(h, L.m.x[i]);
+  for (int i = 0; i < 32; ++i) h = fold(h, L.m.f[i]);
+  h = fold(h, L.h.priv); h = fold(h, L.h.fcsr);
+  const int c1[] = { CI_STVEC, CI_SCOUNTEREN, CI_SENVCFG, CI_SSCRATCH, CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP };
+  for (int c : c1) h = fold(h, L.m.cold_[c]);
+  h = fold(h, L.h.mstatus);
+  const int c2[] = { CI_MEDELEG, CI_MIDELEG, CI_MIE, CI_MTVEC, CI_MCOUNTEREN, CI_MENVCFG, CI_MCOUNTINHIBIT, CI_MSCRATCH, CI_MEPC, CI_MCAUSE, CI_MTVAL, CI_MIP };
+  for (int c : c2) h = fold(h, L.m.cold_[c]);
+  h = fold(h, L.h.cycle); h = fold(h, L.h.instret); h = fold(h, L.h.exec);
+  return h;
+}
+u64 hs_mem_hash(Sim* s)
+{
+  u64 sum = 0, nw = s->L.mem_size / 8;
+  for (u64 i = 0; i < nw; ++i) { u64 w; memcpy(&w, s->ram.data() + i * 8, 8); sum += mix(w ^ (GOLDEN * (i + 1))); }
+  return sum;
+}
+void hs_decode(u32 isa, const u32* words, u64 n, Rec* out) { for (u64 i = 0; i < n; ++i) out[i] = decode(words[i], isa); }
+}

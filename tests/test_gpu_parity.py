@@ -1,0 +1,142 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact on
+status, stop value, pc, executed/retired counts, state digest, memory digest and commit-trace
+digest for every hart."""
+import pytest
+
+import simutil as S
+import whisper_amd as W
+from whisper_amd import workloads as WL
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_batch(progs, seeds=None, lanes=0, trace=True, same_elf=False, max_steps=W.NO_LIMIT):
+    n = len(progs)
+    p0 = progs[0]
+    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes)
+    try:
+        if same_elf:
+            b.load_elf_bytes(p0.elf)
+            b.set_stop(max_inst=p0.max_inst)
+        else:
+            for i, p in enumerate(progs):
+                b.load_elf_bytes(p.elf, i, i + 1)
+                b.set_stop(max_inst=p.max_inst, lo=i, hi=i + 1)
+        if seeds is not None:
+            b.poke_each(W.RES_X, 10, [s[0] for s in seeds])
+            b.poke_each(W.RES_MEM, p0.symbols["seed"], [s[1] for s in seeds])
+        left = b.run(max_steps, trace_hash=trace)
+        res = [r.as_dict() for r in b.results()]
+        return b, left, res
+    except Exception:
+        b.close()
+        raise
+
+
+def _check(progs, res, seeds=None, trace=True):
+    bad = []
+    for i, p in enumerate(progs):
+        ro, h, _ = S.run_oracle(p, seed_a0=seeds[i][0] if seeds else None, seed_mem=seeds[i][1] if seeds else None)
+        rd = dict(res[i])
+        if not trace:
+            ro = dict(ro); ro["trace_hash"] = 0
+        if ro != rd:
+            bad.append((i, p.name, ro, rd))
+    assert not bad, f"{len(bad)} of {len(progs)} harts differ; first: {bad[0]}"
+
+
+def test_readme_single_and_replicated():
+    p = WL.readme_program()
+    for n, lanes in ((1, 0), (130, 64), (100, 16)):
+        b, left, res = _run_batch([p] * n, lanes=lanes, same_elf=True)
+        b.close()
+        assert left == 0
+        _check([p] * n, res)
+        assert res[0]["status"] == W.ST_STOP_TOHOST and res[0]["value"] == 1
+
+
+def test_archtest_suite_signatures():
+    progs = WL.archtest_suite()
+    b, left, res = _run_batch(progs)
+    try:
+        assert left == 0
+        _check(progs, res)
+        for i, p in enumerate(progs):
+            assert res[i]["status"] == W.ST_STOP_TOHOST and res[i]["value"] == 1, p.name
+            ro, h, _ = S.run_oracle(p)
+            lo, hi = p.symbols["begin_signature"], p.symbols["end_signature"]
+            want = h.read_mem(lo, hi - lo)
+            got = b.signature(i)
+            assert len(got) == (hi - lo) // 4
+            assert b"".join(int(w).to_bytes(4, "little") for w in got) == want, p.name
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("lanes", [0, 64, 8])
+def test_compute_kernel_seeds(lanes):
+    p = WL.compute_kernel(iters=1)
+    n = 96
+    seeds = [(WL.compute_seed(i), i) for i in range(n)]
+    b, left, res = _run_batch([p] * n, seeds=seeds, lanes=lanes, same_elf=True)
+    b.close()
+    assert left == 0
+    _check([p] * n, res, seeds=seeds)
+
+
+def test_compute_kernel_no_trace_and_slices():
+    p = WL.compute_kernel(iters=1)
+    n = 40
+    seeds = [(WL.compute_seed(i), i) for i in range(n)]
+    b = W.Batch(n, isa=p.isa, mem_base=p.mem_base, mem_size=p.mem_size)
+    try:
+        b.load_elf_bytes(p.elf)
+        b.poke_each(W.RES_X, 10, [s[0] for s in seeds])
+        b.poke_each(W.RES_MEM, p.symbols["seed"], [s[1] for s in seeds])
+        # run in several bounded slices: state must survive kernel boundaries
+        left = n
+        while left:
+            left = b.run(7001, trace_hash=False)
+        res = [r.as_dict() for r in b.results()]
+    finally:
+        b.close()
+    _check([p] * n, res, seeds=seeds, trace=False)
+
+
+def test_fuzz_programs():
+    progs = [WL.fuzz_program(s, n=300) for s in range(200)]
+    b, left, res = _run_batch(progs)
+    b.close()
+    assert left == 0
+    _check(progs, res)
+
+
+def test_instruction_limit_and_peek_poke():
+    p = WL.compute_kernel(iters=1)
+    b = W.Batch(3, isa=p.isa, mem_base=p.mem_base, mem_size=p.mem_size)
+    try:
+        b.load_elf_bytes(p.elf)
+        b.set_stop(max_inst=1000)
+        b.poke(1, W.RES_X, 10, 0x1234)
+        assert b.peek(1, W.RES_X, 10) == 0x1234
+        assert b.peek(0, W.RES_PC, 0) == p.entry
+        assert b.peek(2, W.RES_MEM, p.segments[0][0], 16) == p.segments[0][1][:16]
+        assert b.run() == 0
+        res = [r.as_dict() for r in b.results()]
+        assert all(r["status"] == W.ST_STOP_LIMIT and r["exec"] == 1000 for r in res)
+        pq = WL.compute_kernel(iters=1); pq.max_inst = 1000
+        ro, _, _ = S.run_oracle(pq, seed_a0=0x1234)
+        ro = dict(ro); ro["trace_hash"] = 0
+        assert res[1] == ro
+    finally:
+        b.close()
+
+
+def test_device_decoder_matches_host_build():
+    import random
+    rng = random.Random(7)
+    words = [rng.getrandbits(32) for _ in range(20000)] + [rng.getrandbits(16) for _ in range(20000)]
+    d = W.decode_words("rv64imafdc_zicsr", words)
+    h = W.decode_words("rv64imafdc_zicsr", words, host=True)
+    for i in range(len(words)):
+        assert (d[i].w0, d[i].imm, d[i].raw) == (h[i].w0, h[i].imm, h[i].raw), hex(words[i])

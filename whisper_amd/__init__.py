@@ -1,0 +1,204 @@
+"""whisper_amd: MI355X-native batched RISC-V hart execution (the Hart::run hot path of
+tenstorrent/whisper for many independent harts).  This module is a thin ctypes mirror of the C ABI
+in include/whisper_amd.h; the simulator itself is HIP (whisper_amd/csrc).  There is no CPU
+execution path: creating a Batch without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "lib", "libwhisper_amd.so")
+SRC = os.path.join(HERE, "csrc", "wsp_lib.hip")
+
+ST_RUNNING, ST_STOP_TOHOST, ST_STOP_ILLEGAL, ST_STOP_LIMIT, ST_STOP_UNSUPPORTED = range(5)
+RES_PC, RES_X, RES_F, RES_CSR, RES_MEM = range(5)
+RUN_TRACE_HASH = 1
+LOAD_EXEC = 1
+NO_LIMIT = 2**64 - 1
+
+
+class WspError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"whisper_amd error {code}: {msg}")
+        self.code = code
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("xlen", C.c_uint32), ("n_harts", C.c_uint32), ("isa", C.c_char_p), ("mem_base", C.c_uint64),
+                ("mem_size", C.c_uint64), ("lanes_per_wave", C.c_uint32), ("device", C.c_int32), ("hart_id_base", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("priv", C.c_uint32), ("stop_value", C.c_uint64), ("pc", C.c_uint64),
+                ("exec_count", C.c_uint64), ("retired_count", C.c_uint64), ("state_hash", C.c_uint64), ("mem_hash", C.c_uint64),
+                ("trace_hash", C.c_uint64)]
+
+    def as_dict(self):
+        return dict(status=self.status, value=self.stop_value, pc=self.pc, exec=self.exec_count, retired=self.retired_count,
+                    state_hash=self.state_hash, mem_hash=self.mem_hash, trace_hash=self.trace_hash)
+
+
+class Decoded(C.Structure):
+    _fields_ = [("w0", C.c_uint32), ("imm", C.c_int32), ("raw", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_softfloat.h"),
+            os.path.join(ROOT, "include", "whisper_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                           "-o", LIB_PATH, SRC])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; fails loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.wsp_batch_create.argtypes = [C.POINTER(BatchDesc), C.POINTER(vp)]
+        L.wsp_batch_destroy.argtypes = [vp]
+        L.wsp_batch_load_elf.argtypes = [vp, u32, u32, C.c_char_p]
+        L.wsp_batch_load_elf_mem.argtypes = [vp, u32, u32, C.c_char_p, C.c_size_t]
+        L.wsp_batch_load_image.argtypes = [vp, u32, u32, u64, C.c_char_p, C.c_size_t, u32]
+        L.wsp_batch_symbol.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
+        L.wsp_batch_poke.argtypes = [vp, u32, u32, u64, C.c_void_p, C.c_size_t]
+        L.wsp_batch_peek.argtypes = [vp, u32, u32, u64, C.c_void_p, C.c_size_t]
+        L.wsp_batch_poke_each.argtypes = [vp, u32, u32, u32, u64, C.POINTER(u64)]
+        L.wsp_batch_set_stop.argtypes = [vp, u32, u32, u64, u64]
+        L.wsp_batch_run.restype = C.c_int64
+        L.wsp_batch_run.argtypes = [vp, u64, u32]
+        L.wsp_batch_last_run_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
+        L.wsp_batch_results.argtypes = [vp, C.POINTER(Result)]
+        L.wsp_batch_last_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
+        L.wsp_batch_signature.restype = C.c_int64
+        L.wsp_batch_signature.argtypes = [vp, u32, C.POINTER(u32), C.c_size_t]
+        L.wsp_decode_words.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
+        L.wsp_decode_words_host.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
+        L.wsp_isa_flags.restype = u32
+        L.wsp_isa_flags.argtypes = [C.c_char_p]
+        L.wsp_last_error.restype = C.c_char_p
+        L.wsp_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise WspError(rc, lib().wsp_last_error().decode())
+    return rc
+
+
+class Batch:
+    """N independent single-hart systems on one MI355X (mirrors the shape of pywhisper's
+    System64/Hart64, py-bindings.cpp:330-469, for a batch)."""
+
+    def __init__(self, n_harts, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, lanes_per_wave=0, device=-1,
+                 hart_id_base=0):
+        self.L = lib()
+        self._isa = isa.encode()
+        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, 0)
+        h = C.c_void_p()
+        _check(self.L.wsp_batch_create(C.byref(desc), C.byref(h)))
+        self.h = h
+        self.n = n_harts
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.wsp_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _rng(self, lo, hi):
+        return (0 if lo is None else lo, self.n if hi is None else hi)
+
+    def load_elf(self, path, lo=None, hi=None):
+        lo, hi = self._rng(lo, hi)
+        _check(self.L.wsp_batch_load_elf(self.h, lo, hi, os.fsencode(path)))
+
+    def load_elf_bytes(self, elf: bytes, lo=None, hi=None):
+        lo, hi = self._rng(lo, hi)
+        _check(self.L.wsp_batch_load_elf_mem(self.h, lo, hi, elf, len(elf)))
+
+    def load_image(self, addr, data: bytes, lo=None, hi=None, executable=False):
+        lo, hi = self._rng(lo, hi)
+        _check(self.L.wsp_batch_load_image(self.h, lo, hi, addr, data, len(data), LOAD_EXEC if executable else 0))
+
+    def symbol(self, hart, name):
+        v = C.c_uint64()
+        _check(self.L.wsp_batch_symbol(self.h, hart, name.encode(), C.byref(v)))
+        return v.value
+
+    def poke(self, hart, res, idx, value):
+        if res == RES_MEM:
+            buf = bytes(value)
+            _check(self.L.wsp_batch_poke(self.h, hart, res, idx, buf, len(buf)))
+        else:
+            v = C.c_uint64(value & NO_LIMIT)
+            _check(self.L.wsp_batch_poke(self.h, hart, res, idx, C.byref(v), 8))
+
+    def peek(self, hart, res, idx, size=8):
+        if res == RES_MEM:
+            buf = C.create_string_buffer(size)
+            _check(self.L.wsp_batch_peek(self.h, hart, res, idx, buf, size))
+            return buf.raw
+        v = C.c_uint64()
+        _check(self.L.wsp_batch_peek(self.h, hart, res, idx, C.byref(v), 8))
+        return v.value
+
+    def poke_each(self, res, idx, values, lo=None, hi=None):
+        lo, hi = self._rng(lo, hi)
+        arr = (C.c_uint64 * (hi - lo))(*[v & NO_LIMIT for v in values])
+        _check(self.L.wsp_batch_poke_each(self.h, lo, hi, res, idx, arr))
+
+    def set_stop(self, tohost=None, max_inst=NO_LIMIT, lo=None, hi=None):
+        lo, hi = self._rng(lo, hi)
+        _check(self.L.wsp_batch_set_stop(self.h, lo, hi, NO_LIMIT if tohost is None else tohost, max_inst))
+
+    def run(self, max_steps=NO_LIMIT, trace_hash=False):
+        return _check(self.L.wsp_batch_run(self.h, max_steps, RUN_TRACE_HASH if trace_hash else 0))
+
+    def run_stats(self):
+        s = C.c_double(); n = C.c_uint32()
+        _check(self.L.wsp_batch_last_run_stats(self.h, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def results(self):
+        arr = (Result * self.n)()
+        _check(self.L.wsp_batch_results(self.h, arr))
+        return arr
+
+    def hash_stats(self):
+        s = C.c_double(); n = C.c_uint64()
+        _check(self.L.wsp_batch_last_hash_stats(self.h, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def signature(self, hart, cap=1 << 16):
+        arr = (C.c_uint32 * cap)()
+        n = _check(self.L.wsp_batch_signature(self.h, hart, arr, cap))
+        return list(arr[:n])
+
+
+def decode_words(isa, words, host=False):
+    L = lib()
+    n = len(words)
+    arr = (C.c_uint32 * n)(*words)
+    out = (Decoded * n)()
+    fn = L.wsp_decode_words_host if host else L.wsp_decode_words
+    _check(fn(isa.encode(), arr, n, out))
+    return out

@@ -1,0 +1,956 @@
+// Per-hart step semantics of the batched RISC-V simulator (one hart per GPU lane).
+//
+// This header is the product's restatement of the reference hot path
+//   Hart<URV>::untilAddress / singleStep   /root/reference/Hart.cpp:6003-6204, 7417-7529
+//   execute() switch and exec* bodies       Hart.cpp:7544-11480, float.cpp, amo.cpp
+//   traps / xRET / CSR instructions         Hart.cpp:3324-3929, 12247-12560, 12723-13748
+// re-designed for lock-step SIMT execution: instructions are pre-decoded once per program into
+// 16-byte records (replacing Decoder::decode + the per-hart 128Ki-entry decode cache,
+// Hart.cpp:6113-6117), integer/FP registers live in LDS as [reg][lane], cold CSRs and the RAM
+// arena live in HBM, and everything a hart touches every step sits in registers (struct Hot).
+//
+// Everything is WSP_HD so tests can also compile the decoder and softfloat for the host
+// (tests never run a CPU build of the step loop as the product: the C-ABI run entry point is
+// HIP-only and fails loudly without a device).
+#pragma once
+#include <stdint.h>
+#include "wsp_softfloat.h"
+
+namespace wsp {
+
+typedef uint64_t u64;
+typedef int64_t  i64;
+typedef uint32_t u32;
+typedef int32_t  i32;
+typedef uint16_t u16;
+typedef uint8_t  u8;
+
+// ---------------------------------------------------------------------------------- constants
+enum { ISA_M = 1, ISA_A = 2, ISA_F = 4, ISA_D = 8, ISA_C = 16, ISA_S = 32, ISA_U = 64, ISA_V = 128, ISA_ZICNTR = 256 };
+enum { ST_RUNNING = 0, ST_STOP_TOHOST = 1, ST_STOP_ILLEGAL = 2, ST_STOP_LIMIT = 3, ST_STOP_UNSUPPORTED = 4 };
+enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
+
+// Unsupported-reason codes reported in wsp_result.stop_value when status == ST_STOP_UNSUPPORTED
+enum { UNS_PAGING = 0x180, UNS_CSR_BASE = 0x10000, UNS_VECTOR = 0x20000 };
+
+enum Op : u32 {
+  OP_ILLEGAL = 0,
+  // ALU: second operand = imm when F_IMM is set, else x[rs2]
+  OP_ADD, OP_SUB, OP_SLL, OP_SLT, OP_SLTU, OP_XOR, OP_SRL, OP_SRA, OP_OR, OP_AND,
+  OP_ADDW, OP_SUBW, OP_SLLW, OP_SRLW, OP_SRAW,
+  OP_MUL, OP_MULH, OP_MULHSU, OP_MULHU, OP_DIV, OP_DIVU, OP_REM, OP_REMU,
+  OP_MULW, OP_DIVW, OP_DIVUW, OP_REMW, OP_REMUW,
+  OP_AUIPC, OP_JAL, OP_JALR, OP_BEQ, OP_BNE, OP_BLT, OP_BGE, OP_BLTU, OP_BGEU,
+  OP_LB, OP_LH, OP_LW, OP_LD, OP_LBU, OP_LHU, OP_LWU, OP_SB, OP_SH, OP_SW, OP_SD,
+  OP_NOP, OP_ECALL, OP_EBREAK, OP_MRET, OP_SRET, OP_WFI, OP_SFENCE_VMA,
+  OP_CSRRW, OP_CSRRS, OP_CSRRC,
+  OP_LR, OP_SC, OP_AMO,                 // F_DBL = 64-bit form; AMO function (funct5) in imm
+  OP_FLW, OP_FLD, OP_FSW, OP_FSD,
+  // F/D: F_DBL selects double precision; rounding mode field in imm[2:0]
+  OP_FADD, OP_FSUB, OP_FMUL, OP_FDIV, OP_FSQRT, OP_FMA /* imm[4:3]: 0 madd 1 msub 2 nmsub 3 nmadd */,
+  OP_FSGNJ /* imm: 0 j 1 jn 2 jx */, OP_FMINMAX /* imm: 0 min 1 max */, OP_FCMP /* imm: 0 le 1 lt 2 eq */,
+  OP_FCVT_F2I /* rs2: 0 w 1 wu 2 l 3 lu */, OP_FCVT_I2F, OP_FCVT_FF /* to F_DBL ? d.s : s.d */,
+  OP_FMV_F2X, OP_FCLASS, OP_FMV_X2F,
+  OP_SLOWFETCH,                         // predecoded slot cannot be trusted: fetch + decode from RAM
+  OP_COUNT
+};
+
+// Pre-decoded instruction record (replaces DecodedInst, DecodedInst.hpp:640-657).
+struct Rec {
+  u32 w0;     // op[7:0] rd[12:8] rs1[17:13] rs2[22:18] rs3[27:23] F_SIZE4[28] F_IMM[29] F_DBL[30]
+  i32 imm;
+  u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval
+  u32 pad;
+};
+enum : u32 { F_SIZE4 = 1u << 28, F_IMM = 1u << 29, F_DBL = 1u << 30 };
+WSP_HD u32 rec_op(const Rec& r) { return r.w0 & 0xff; }
+WSP_HD u32 rec_rd(const Rec& r) { return (r.w0 >> 8) & 31; }
+WSP_HD u32 rec_rs1(const Rec& r) { return (r.w0 >> 13) & 31; }
+WSP_HD u32 rec_rs2(const Rec& r) { return (r.w0 >> 18) & 31; }
+WSP_HD u32 rec_rs3(const Rec& r) { return (r.w0 >> 23) & 31; }
+WSP_HD Rec mk(u32 op, u32 rd, u32 rs1, u32 rs2, i32 imm, u32 flags = 0, u32 rs3 = 0)
+{ Rec r; r.w0 = op | (rd << 8) | (rs1 << 13) | (rs2 << 18) | (rs3 << 23) | flags; r.imm = imm; r.raw = 0; r.pad = 0; return r; }
+
+// ---------------------------------------------------------------------------------- hashing
+// The commit-trace / state / memory digests; oracle/rv_oracle.c computes the same folds.
+WSP_HD u64 rotl64(u64 x, unsigned r) { return (x << r) | (x >> (64 - r)); }
+WSP_HD u64 fold(u64 h, u64 w) { h ^= w; h = rotl64(h, 27); return h * 5 + 0x52dce729u; }
+WSP_HD u64 mix(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; return x; }
+static constexpr u64 GOLDEN = 0x9E3779B97F4A7C15ULL;
+
+// ---------------------------------------------------------------------------------- decode
+WSP_HD i32 sx(u32 v, unsigned bits) { return (i32)(v << (32 - bits)) >> (32 - bits); }
+
+// 32-bit encodings (Decoder.cpp:2232). Extension gating that the reference performs at execute
+// time against the (read-only) misa/--isa configuration is folded in here because the ISA is
+// fixed for the lifetime of a batch; mstatus.FS-dependent legality stays in exec.
+WSP_HD Rec decode32(u32 inst, u32 isa)
+{
+  u32 op = inst & 0x7f, rd = (inst >> 7) & 31, f3 = (inst >> 12) & 7, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31;
+  u32 f7 = inst >> 25;
+  i32 immi = (i32)inst >> 20;
+  Rec ill = mk(OP_ILLEGAL, 0, 0, 0, 0, F_SIZE4);
+  Rec r = ill;
+  switch (op) {
+    case 0x37: r = mk(OP_ADD, rd, 0, 0, (i32)(inst & 0xfffff000u), F_IMM); break;
+    case 0x17: r = mk(OP_AUIPC, rd, 0, 0, (i32)(inst & 0xfffff000u)); break;
+    case 0x6f: {
+      i32 off = ((i32)(inst & 0x80000000u) >> 11) | (i32)(inst & 0xff000) | (i32)((inst >> 9) & 0x800) | (i32)((inst >> 20) & 0x7fe);
+      r = mk(OP_JAL, rd, 0, 0, off); break; }
+    case 0x67: if (f3 == 0) r = mk(OP_JALR, rd, rs1, 0, immi); break;
+    case 0x63: {
+      i32 off = ((i32)(inst & 0x80000000u) >> 19) | (i32)((inst & 0x80) << 4) | (i32)((inst >> 20) & 0x7e0) | (i32)((inst >> 7) & 0x1e);
+      u32 o = f3 == 0 ? OP_BEQ : f3 == 1 ? OP_BNE : f3 == 4 ? OP_BLT : f3 == 5 ? OP_BGE : f3 == 6 ? OP_BLTU : f3 == 7 ? OP_BGEU : (u32)OP_ILLEGAL;
+      if (o != OP_ILLEGAL) r = mk(o, 0, rs1, rs2, off);
+      break; }
+    case 0x03: if (f3 != 7) r = mk(OP_LB + f3, rd, rs1, 0, immi); break;
+    case 0x23: if (f3 <= 3) r = mk(OP_SB + f3, 0, rs1, rs2, ((i32)(inst & 0xfe000000u) >> 20) | (i32)((inst >> 7) & 31)); break;
+    case 0x13: {
+      u32 sh = (inst >> 20) & 63, top6 = inst >> 26;
+      switch (f3) {
+        case 0: r = mk(OP_ADD, rd, rs1, 0, immi, F_IMM); break;
+        case 1: if (top6 == 0) r = mk(OP_SLL, rd, rs1, 0, (i32)sh, F_IMM); break;
+        case 2: r = mk(OP_SLT, rd, rs1, 0, immi, F_IMM); break;
+        case 3: r = mk(OP_SLTU, rd, rs1, 0, immi, F_IMM); break;
+        case 4: r = mk(OP_XOR, rd, rs1, 0, immi, F_IMM); break;
+        case 5: if (top6 == 0) r = mk(OP_SRL, rd, rs1, 0, (i32)sh, F_IMM); else if (top6 == 0x10) r = mk(OP_SRA, rd, rs1, 0, (i32)sh, F_IMM); break;
+        case 6: r = mk(OP_OR, rd, rs1, 0, immi, F_IMM); break;
+        default: r = mk(OP_AND, rd, rs1, 0, immi, F_IMM); break;
+      }
+      break; }
+    case 0x1b:
+      if (f3 == 0) r = mk(OP_ADDW, rd, rs1, 0, immi, F_IMM);
+      else if (f3 == 1 && f7 == 0) r = mk(OP_SLLW, rd, rs1, 0, (i32)rs2, F_IMM);
+      else if (f3 == 5 && f7 == 0) r = mk(OP_SRLW, rd, rs1, 0, (i32)rs2, F_IMM);
+      else if (f3 == 5 && f7 == 0x20) r = mk(OP_SRAW, rd, rs1, 0, (i32)rs2, F_IMM);
+      break;
+    case 0x33:
+      if (f7 == 1) { if (isa & ISA_M) r = mk(OP_MUL + f3, rd, rs1, rs2, 0); }
+      else if (f7 == 0) { const u32 t[8] = { OP_ADD, OP_SLL, OP_SLT, OP_SLTU, OP_XOR, OP_SRL, OP_OR, OP_AND }; r = mk(t[f3], rd, rs1, rs2, 0); }
+      else if (f7 == 0x20) { if (f3 == 0) r = mk(OP_SUB, rd, rs1, rs2, 0); else if (f3 == 5) r = mk(OP_SRA, rd, rs1, rs2, 0); }
+      break;
+    case 0x3b:
+      if (f7 == 1) {
+        if (isa & ISA_M) { u32 o = f3 == 0 ? OP_MULW : f3 == 4 ? OP_DIVW : f3 == 5 ? OP_DIVUW : f3 == 6 ? OP_REMW : f3 == 7 ? OP_REMUW : (u32)OP_ILLEGAL; if (o) r = mk(o, rd, rs1, rs2, 0); }
+      } else if (f7 == 0) { if (f3 == 0) r = mk(OP_ADDW, rd, rs1, rs2, 0); else if (f3 == 1) r = mk(OP_SLLW, rd, rs1, rs2, 0); else if (f3 == 5) r = mk(OP_SRLW, rd, rs1, rs2, 0); }
+      else if (f7 == 0x20) { if (f3 == 0) r = mk(OP_SUBW, rd, rs1, rs2, 0); else if (f3 == 5) r = mk(OP_SRAW, rd, rs1, rs2, 0); }
+      break;
+    case 0x0f: if (f3 == 0 || f3 == 1) r = mk(OP_NOP, 0, 0, 0, 0); break;
+    case 0x73:
+      if (f3 == 0) {
+        if (rd != 0) break;
+        if (inst == 0x00000073) r = mk(OP_ECALL, 0, 0, 0, 0);
+        else if (inst == 0x00100073) r = mk(OP_EBREAK, 0, 0, 0, 0);
+        else if (inst == 0x30200073) r = mk(OP_MRET, 0, 0, 0, 0);
+        else if (inst == 0x10200073) { if (isa & ISA_S) r = mk(OP_SRET, 0, 0, 0, 0); }
+        else if (inst == 0x10500073) r = mk(OP_WFI, 0, 0, 0, 0);
+        else if (f7 == 0x09) { if (isa & ISA_S) r = mk(OP_SFENCE_VMA, 0, rs1, rs2, 0); }
+      } else if (f3 != 4) {
+        // csr number in imm; for the immediate forms the 5-bit uimm travels in the rs1 field
+        r = mk(OP_CSRRW + ((f3 & 3) - 1), rd, rs1, 0, (i32)(inst >> 20), (f3 & 4) ? F_IMM : 0);
+      }
+      break;
+    case 0x2f: {
+      u32 f5 = inst >> 27;
+      if (!(isa & ISA_A) || (f3 != 2 && f3 != 3)) break;
+      u32 fl = f3 == 3 ? F_DBL : 0;
+      if (f5 == 2) { if (rs2 == 0) r = mk(OP_LR, rd, rs1, 0, 0, fl); }
+      else if (f5 == 3) r = mk(OP_SC, rd, rs1, rs2, 0, fl);
+      else if (f5 == 0 || f5 == 1 || f5 == 4 || f5 == 8 || f5 == 12 || f5 == 16 || f5 == 20 || f5 == 24 || f5 == 28) r = mk(OP_AMO, rd, rs1, rs2, (i32)f5, fl);
+      break; }
+    case 0x07:
+      if (f3 == 2 && (isa & ISA_F)) r = mk(OP_FLW, rd, rs1, 0, immi);
+      else if (f3 == 3 && (isa & ISA_D)) r = mk(OP_FLD, rd, rs1, 0, immi);
+      break;
+    case 0x27: {
+      i32 imms = ((i32)(inst & 0xfe000000u) >> 20) | (i32)((inst >> 7) & 31);
+      if (f3 == 2 && (isa & ISA_F)) r = mk(OP_FSW, 0, rs1, rs2, imms);
+      else if (f3 == 3 && (isa & ISA_D)) r = mk(OP_FSD, 0, rs1, rs2, imms);
+      break; }
+    case 0x43: case 0x47: case 0x4b: case 0x4f: {
+      u32 fmt = (inst >> 25) & 3, k = (op - 0x43) >> 2;
+      if (fmt == 0 && (isa & ISA_F)) r = mk(OP_FMA, rd, rs1, rs2, (i32)(f3 | (k << 3)), 0, inst >> 27);
+      else if (fmt == 1 && (isa & ISA_D)) r = mk(OP_FMA, rd, rs1, rs2, (i32)(f3 | (k << 3)), F_DBL, inst >> 27);
+      break; }
+    case 0x53: {
+      if (f7 & 2) break;
+      u32 dbl = (f7 & 1) ? (u32)F_DBL : 0;
+      if (dbl ? !(isa & ISA_D) : !(isa & ISA_F)) break;
+      switch (f7 >> 2) {
+        case 0: r = mk(OP_FADD, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 1: r = mk(OP_FSUB, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 2: r = mk(OP_FMUL, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 3: r = mk(OP_FDIV, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 0x0b: if (rs2 == 0) r = mk(OP_FSQRT, rd, rs1, 0, (i32)f3, dbl); break;
+        case 4: if (f3 <= 2) r = mk(OP_FSGNJ, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 5: if (f3 <= 1) r = mk(OP_FMINMAX, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 8:
+          if (!(isa & ISA_D)) break;
+          if (!dbl && rs2 == 1) r = mk(OP_FCVT_FF, rd, rs1, 0, (i32)f3, 0);          // fcvt.s.d
+          else if (dbl && rs2 == 0) r = mk(OP_FCVT_FF, rd, rs1, 0, (i32)f3, F_DBL);   // fcvt.d.s
+          break;
+        case 0x14: if (f3 <= 2) r = mk(OP_FCMP, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 0x18: if (rs2 <= 3) r = mk(OP_FCVT_F2I, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 0x1a: if (rs2 <= 3) r = mk(OP_FCVT_I2F, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 0x1c: if (rs2 == 0) { if (f3 == 0) r = mk(OP_FMV_F2X, rd, rs1, 0, 0, dbl); else if (f3 == 1) r = mk(OP_FCLASS, rd, rs1, 0, 0, dbl); } break;
+        case 0x1e: if (rs2 == 0 && f3 == 0) r = mk(OP_FMV_X2F, rd, rs1, 0, 0, dbl); break;
+        default: break;
+      }
+      break; }
+    default: break;
+  }
+  r.w0 |= F_SIZE4;
+  r.raw = inst;
+  return r;
+}
+
+// 16-bit encodings (Decoder.cpp:1455-1819), RV64: produces the record of the equivalent base
+// instruction (the reference executes c.* through the same exec bodies, Hart.cpp:8471-8515).
+WSP_HD Rec decode16(u32 c, u32 isa)
+{
+  c &= 0xffff;
+  u32 q = c & 3, f3 = (c >> 13) & 7;
+  u32 rdp = 8 + ((c >> 2) & 7), rs1p = 8 + ((c >> 7) & 7);
+  u32 rd = (c >> 7) & 31, rs2 = (c >> 2) & 31, b12 = (c >> 12) & 1;
+  i32 imm6 = sx((b12 << 5) | ((c >> 2) & 31), 6);
+  Rec r = mk(OP_ILLEGAL, 0, 0, 0, 0);
+  bool fd = (isa & ISA_D) != 0;                 // Zcd = C + D (Hart.cpp:800-802)
+  if (!(isa & ISA_C)) { r.raw = c; return r; }
+  if (q == 0) {
+    u32 ud = (((c >> 10) & 7) << 3) | (((c >> 5) & 3) << 6);
+    u32 uw = (((c >> 10) & 7) << 3) | (((c >> 6) & 1) << 2) | (((c >> 5) & 1) << 6);
+    switch (f3) {
+      case 0: {
+        u32 imm = (((c >> 11) & 3) << 4) | (((c >> 7) & 0xf) << 6) | (((c >> 6) & 1) << 2) | (((c >> 5) & 1) << 3);
+        if (c != 0 && imm != 0) r = mk(OP_ADD, rdp, 2, 0, (i32)imm, F_IMM);
+        break; }
+      case 1: if (fd) r = mk(OP_FLD, rdp, rs1p, 0, (i32)ud); break;
+      case 2: r = mk(OP_LW, rdp, rs1p, 0, (i32)uw); break;
+      case 3: r = mk(OP_LD, rdp, rs1p, 0, (i32)ud); break;
+      case 5: if (fd) r = mk(OP_FSD, 0, rs1p, rdp, (i32)ud); break;
+      case 6: r = mk(OP_SW, 0, rs1p, rdp, (i32)uw); break;
+      case 7: r = mk(OP_SD, 0, rs1p, rdp, (i32)ud); break;
+      default: break;
+    }
+  } else if (q == 1) {
+    switch (f3) {
+      case 0: r = mk(OP_ADD, rd, rd, 0, imm6, F_IMM); break;
+      case 1: if (rd != 0) r = mk(OP_ADDW, rd, rd, 0, imm6, F_IMM); break;
+      case 2: r = mk(OP_ADD, rd, 0, 0, imm6, F_IMM); break;
+      case 3:
+        if (imm6 == 0) break;
+        if (rd == 2) {
+          i32 imm = sx((b12 << 9) | (((c >> 6) & 1) << 4) | (((c >> 5) & 1) << 6) | (((c >> 3) & 3) << 7) | (((c >> 2) & 1) << 5), 10);
+          r = mk(OP_ADD, 2, 2, 0, imm, F_IMM);
+        } else r = mk(OP_ADD, rd, 0, 0, (i32)((u32)imm6 << 12), F_IMM);
+        break;
+      case 4: {
+        u32 f2 = (c >> 10) & 3, sh = (b12 << 5) | ((c >> 2) & 31), k = (c >> 5) & 3;
+        if (f2 == 0) r = mk(OP_SRL, rs1p, rs1p, 0, (i32)sh, F_IMM);
+        else if (f2 == 1) r = mk(OP_SRA, rs1p, rs1p, 0, (i32)sh, F_IMM);
+        else if (f2 == 2) r = mk(OP_AND, rs1p, rs1p, 0, imm6, F_IMM);
+        else if (!b12) { const u32 t[4] = { OP_SUB, OP_XOR, OP_OR, OP_AND }; r = mk(t[k], rs1p, rs1p, rdp, 0); }
+        else if (k == 0) r = mk(OP_SUBW, rs1p, rs1p, rdp, 0);
+        else if (k == 1) r = mk(OP_ADDW, rs1p, rs1p, rdp, 0);
+        break; }
+      case 5: {
+        i32 off = sx((b12 << 11) | (((c >> 11) & 1) << 4) | (((c >> 9) & 3) << 8) | (((c >> 8) & 1) << 10) |
+                     (((c >> 7) & 1) << 6) | (((c >> 6) & 1) << 7) | (((c >> 3) & 7) << 1) | (((c >> 2) & 1) << 5), 12);
+        r = mk(OP_JAL, 0, 0, 0, off); break; }
+      default: {
+        i32 off = sx((b12 << 8) | (((c >> 10) & 3) << 3) | (((c >> 5) & 3) << 6) | (((c >> 3) & 3) << 1) | (((c >> 2) & 1) << 5), 9);
+        r = mk(f3 == 6 ? OP_BEQ : OP_BNE, 0, rs1p, 0, off); break; }
+    }
+  } else if (q == 2) {
+    switch (f3) {
+      case 0: r = mk(OP_SLL, rd, rd, 0, (i32)((b12 << 5) | rs2), F_IMM); break;
+      case 1: if (fd) r = mk(OP_FLD, rd, 2, 0, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6))); break;
+      case 2: if (rd != 0) r = mk(OP_LW, rd, 2, 0, (i32)((b12 << 5) | (((c >> 4) & 7) << 2) | (((c >> 2) & 3) << 6))); break;
+      case 3: if (rd != 0) r = mk(OP_LD, rd, 2, 0, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6))); break;
+      case 4:
+        if (!b12) { if (rs2 == 0) { if (rd != 0) r = mk(OP_JALR, 0, rd, 0, 0); } else r = mk(OP_ADD, rd, 0, rs2, 0); }
+        else if (rs2 == 0) { if (rd == 0) r = mk(OP_EBREAK, 0, 0, 0, 0); else r = mk(OP_JALR, 1, rd, 0, 0); }
+        else r = mk(OP_ADD, rd, rd, rs2, 0);
+        break;
+      case 5: if (fd) r = mk(OP_FSD, 0, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6))); break;
+      case 6: r = mk(OP_SW, 0, 2, rs2, (i32)((((c >> 9) & 0xf) << 2) | (((c >> 7) & 3) << 6))); break;
+      default: r = mk(OP_SD, 0, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6))); break;
+    }
+  }
+  r.raw = c;
+  return r;
+}
+
+WSP_HD Rec decode(u32 inst, u32 isa) { return (inst & 3) == 3 ? decode32(inst, isa) : decode16(inst, isa); }
+
+// ---------------------------------------------------------------------------------- state
+// Cold CSR slots (SoA rows in HBM: cold[slot * stride + hart_slot]).
+enum ColdIx {
+  CI_MEDELEG, CI_MIDELEG, CI_MIE, CI_MIP, CI_MTVEC, CI_MCOUNTEREN, CI_MENVCFG, CI_MCOUNTINHIBIT,
+  CI_MSCRATCH, CI_MEPC, CI_MCAUSE, CI_MTVAL, CI_STVEC, CI_SCOUNTEREN, CI_SENVCFG, CI_SSCRATCH,
+  CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP, CI_COUNT
+};
+
+enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8 };
+
+// Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
+struct Hot {
+  u64 pc, mstatus, cycle, instret, exec, retired, thash;
+  u64 lr_addr, exec_last_ill, stop_value;
+  u32 fcsr, priv, status, consec_ill, htif_dev, flags;
+};
+
+// CSR numbers
+enum {
+  C_FFLAGS = 0x001, C_FRM = 0x002, C_FCSR = 0x003,
+  C_SSTATUS = 0x100, C_SIE = 0x104, C_STVEC = 0x105, C_SCOUNTEREN = 0x106, C_SENVCFG = 0x10A,
+  C_SSCRATCH = 0x140, C_SEPC = 0x141, C_SCAUSE = 0x142, C_STVAL = 0x143, C_SIP = 0x144, C_SATP = 0x180,
+  C_MSTATUS = 0x300, C_MISA = 0x301, C_MEDELEG = 0x302, C_MIDELEG = 0x303, C_MIE = 0x304, C_MTVEC = 0x305,
+  C_MCOUNTEREN = 0x306, C_MENVCFG = 0x30A, C_MCOUNTINHIBIT = 0x320,
+  C_MSCRATCH = 0x340, C_MEPC = 0x341, C_MCAUSE = 0x342, C_MTVAL = 0x343, C_MIP = 0x344,
+  C_MCYCLE = 0xB00, C_MINSTRET = 0xB02, C_CYCLE = 0xC00, C_TIME = 0xC01, C_INSTRET = 0xC02,
+  C_MVENDORID = 0xF11, C_MARCHID = 0xF12, C_MIMPID = 0xF13, C_MHARTID = 0xF14, C_MCONFIGPTR = 0xF15
+};
+
+static constexpr u64 MST_SIE = 1ULL << 1, MST_MIE = 1ULL << 3, MST_SPIE = 1ULL << 5, MST_MPIE = 1ULL << 7, MST_SPP = 1ULL << 8;
+static constexpr u64 MST_MPRV = 1ULL << 17, MST_TVM = 1ULL << 20, MST_TW = 1ULL << 21, MST_TSR = 1ULL << 22, MST_SD = 1ULL << 63;
+static constexpr int MST_VS_SH = 9, MST_MPP_SH = 11, MST_FS_SH = 13, MST_XS_SH = 15;
+static constexpr u64 MSTATUS_WMASK = 0x7FFFAAULL;             // CsRegs.cpp:4704
+static constexpr u64 SSTATUS_WMASK = 0x000DE722ULL;           // CsRegs.cpp:4979
+static constexpr u64 SSTATUS_RMASK = 0x80000003000DE762ULL;   // CsRegs.cpp:4990
+static constexpr u64 MISA_RESET = 0x800000000034112dULL;      // CsRegs.cpp:4721-4724 (read-only)
+static constexpr u64 MSTATUS_RESET = (3ULL << MST_MPP_SH) | (0xAULL << 32);   // CsRegs.cpp:4705-4710
+
+// Per-step commit bookkeeping (what printDecodedInstTrace would print, printTrace.cpp:388-493).
+enum : u32 {
+  CH_IREG = 1, CH_FREG = 2, CH_MEM = 4, CH_GEN = 8, CH_SSTATUS = 16, CH_SEPC = 32, CH_SCAUSE = 64, CH_STVAL = 128,
+  CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096
+};
+struct Step {
+  u32 chg, ireg, freg, gen_csr;
+  u64 ival, fval, maddr, mval;
+};
+
+// ---------------------------------------------------------------------------------- lane context
+// MEM policy supplies: rx/wx/rf/wf (register files), cold(i) (CSR rows), ld8..ld64/st8..st64 at
+// a byte offset into this hart's RAM arena.
+template <class MEM> struct Lane {
+  Hot h;
+  Step s;
+  MEM m;
+  u64 mem_base, mem_size, tohost, text_lo, text_hi;   // tohost == ~0: none
+  u32 isa, hart_id;
+
+  WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
+  WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
+
+  // ---- integer / fp register writes with trace capture
+  WSP_HD void wx(u32 rd, u64 v) { if (rd) m.wx(rd, v); s.chg |= CH_IREG; s.ireg = rd; s.ival = v; }
+  WSP_HD void wf(u32 rd, u64 v) { m.wf(rd, v); s.chg |= CH_FREG; s.freg = rd; s.fval = v; }
+  WSP_HD void wf_s(u32 rd, u32 v) { wf(rd, ext(ISA_D) ? (0xffffffff00000000ULL | v) : (u64)v); }          // FpRegs.hpp:248-269
+  WSP_HD u32 rf_s(u32 r) { u64 v = m.rf(r); return (ext(ISA_D) && (v >> 32) != 0xffffffffu) ? 0x7fc00000u : (u32)v; }  // FpRegs.hpp:285-295
+
+  // ---- mstatus helpers
+  WSP_HD u64 legalize_mstatus(u64 v) const                                                                  // CsRegs.cpp:2617-2648
+  {
+    u32 fs = (v >> MST_FS_SH) & 3, xs = (v >> MST_XS_SH) & 3, vs = (v >> MST_VS_SH) & 3;
+    v = (fs == 3 || xs == 3 || vs == 3) ? (v | MST_SD) : (v & ~MST_SD);
+    u32 mpp = (v >> MST_MPP_SH) & 3, spp = (v >> 8) & 1;
+    if (!ext(ISA_S)) spp = 0;
+    if (mpp == PRV_S && !ext(ISA_S)) mpp = PRV_U;
+    if (mpp == 2) mpp = PRV_U;
+    if (mpp == PRV_U && !ext(ISA_U)) mpp = PRV_M;
+    v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)mpp << MST_MPP_SH);
+    return (v & ~MST_SPP) | ((u64)spp << 8);
+  }
+  WSP_HD bool fp_on() const { return ((h.mstatus >> MST_FS_SH) & 3) != 0; }                                  // isFpLegal (F folded into decode)
+  WSP_HD void mark_fs_dirty()                                                                               // float.cpp:165-191
+  { if (((h.mstatus >> MST_FS_SH) & 3) != 3) { h.mstatus |= (3ULL << MST_FS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
+  WSP_HD void or_fflags(u32 f)                                                                              // float.cpp:140-162, Hart.hpp:3821
+  {
+    u32 prev = h.fcsr & 0x1f, val = prev | (f & 0x1f);
+    if (val != prev) { h.fcsr = (h.fcsr & ~0x1fu) | val; s.chg |= CH_GEN; s.gen_csr = C_FCSR; }
+    if (f) mark_fs_dirty();
+  }
+
+  WSP_HD void stop(u32 st, u64 v) { h.status = st; h.stop_value = v; }
+
+  // ---- traps: initiateException + initiateTrap (Hart.cpp:3324-3397, 3565-3929)
+  WSP_HD void take_exception(u32 cause, u64 epc, u64 tval, bool counts)
+  {
+    if (counts) {   // di == nullptr or illegal: the consecutive-illegal stop heuristic (3329-3340)
+      if (h.exec == h.exec_last_ill + 1) h.consec_ill++; else h.consec_ill = 0;
+      if (h.consec_ill > 16) { stop(ST_STOP_ILLEGAL, 3); return; }
+      h.exec_last_ill = h.exec;
+    }
+    s.chg |= CH_EXC;
+    u32 next = PRV_M;
+    if (ext(ISA_S) && h.priv != PRV_M && ((m.cold(CI_MEDELEG) >> cause) & 1)) next = PRV_S;
+    u32 orig = h.priv;
+    h.priv = next;
+    u64 tvec, v = h.mstatus;
+    if (next == PRV_M) {
+      m.cold(CI_MEPC) = epc & ~1ULL; m.cold(CI_MCAUSE) = cause; m.cold(CI_MTVAL) = tval;
+      v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)orig << MST_MPP_SH);
+      v = (v & ~MST_MPIE) | ((v & MST_MIE) ? MST_MPIE : 0);
+      v &= ~MST_MIE;
+      s.chg |= CH_MSTATUS | CH_MEPC | CH_MCAUSE | CH_MTVAL;
+      tvec = m.cold(CI_MTVEC);
+    } else {
+      m.cold(CI_SEPC) = epc & ~1ULL; m.cold(CI_SCAUSE) = cause; m.cold(CI_STVAL) = tval;
+      v = (v & ~MST_SPP) | ((u64)(orig & 1) << 8);
+      v = (v & ~MST_SPIE) | ((v & MST_SIE) ? MST_SPIE : 0);
+      v &= ~MST_SIE;
+      s.chg |= CH_SSTATUS | CH_SEPC | CH_SCAUSE | CH_STVAL;
+      tvec = m.cold(CI_STVEC);
+    }
+    h.mstatus = v;
+    h.pc = tvec & ~3ULL;
+  }
+  WSP_HD void illegal(const Rec& r, u64 cur_pc) { take_exception(2, cur_pc, r.raw, true); }
+
+  // ---- data access checks (determineLoad/StoreException, Hart.cpp:1988-2154, 13786-13935)
+  WSP_HD u32 eff_priv() const { return ((h.mstatus & MST_MPRV) && h.priv == PRV_M) ? (u32)((h.mstatus >> MST_MPP_SH) & 3) : h.priv; }   // Hart.hpp:3444
+  // PMP with no programmed entry: M allowed, S/U denied (PmpManager.hpp:155-177)
+  WSP_HD bool check_access(u64 va, u32 size, u64& tval) const
+  {
+    bool pmp_ok = eff_priv() == PRV_M;
+    u64 mask = size - 1;
+    if (!(va & mask)) { if (!pmp_ok || !in_mem(va, size)) { tval = va; return false; } return true; }
+    u64 va2 = (va + size - 1) & ~mask;
+    if (!pmp_ok || !in_mem(va, va2 - va)) { tval = va; return false; }
+    if (!in_mem(va2, size)) { tval = va2; return false; }
+    return true;
+  }
+  WSP_HD bool paging_unsupported()
+  {
+    if (ext(ISA_S) && eff_priv() != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
+    return false;
+  }
+
+  WSP_HD u64 mem_read(u64 off, u32 size)
+  {
+    if (!(off & (size - 1))) {
+      switch (size) { case 1: return m.ld8(off); case 2: return m.ld16(off); case 4: return m.ld32(off); default: return m.ld64(off); }
+    }
+    u64 v = 0;
+    for (u32 i = 0; i < size; ++i) v |= (u64)m.ld8(off + i) << (8 * i);
+    return v;
+  }
+  WSP_HD void mem_write(u64 off, u32 size, u64 v)
+  {
+    if (!(off & (size - 1))) {
+      switch (size) { case 1: m.st8(off, (u8)v); break; case 2: m.st16(off, (u16)v); break; case 4: m.st32(off, (u32)v); break; default: m.st64(off, v); break; }
+      return;
+    }
+    for (u32 i = 0; i < size; ++i) m.st8(off + i, (u8)(v >> (8 * i)));
+  }
+
+  // Hart::load + readForLoad (Hart.cpp:2302, 2477)
+  WSP_HD bool do_load(u64 va, u32 size, u64 cur_pc, u64& out)
+  {
+    u64 tval;
+    if (paging_unsupported()) return false;
+    if (!check_access(va, size, tval)) { take_exception(5, cur_pc, tval, false); return false; }
+    if (va == tohost) { out = 0; return true; }                           // Hart.cpp:2509-2513
+    out = mem_read(va - mem_base, size);
+    return true;
+  }
+  // Hart::store + writeForStore + handleStoreToHost (Hart.cpp:2674, 2727, 2615)
+  WSP_HD bool do_store(u64 va, u32 size, u64 val, u64 cur_pc)
+  {
+    u64 tval;
+    if (paging_unsupported()) return false;
+    if (!check_access(va, size, tval)) { take_exception(7, cur_pc, tval, false); return false; }
+    u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
+    s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
+    mem_write(va - mem_base, size, sv);
+    if (va + size > text_lo && va < text_hi) h.flags |= HF_CODE_DIRTY;    // invalidateDecodeCache (Hart.cpp:7375)
+    if (tohost != ~0ULL && (va == tohost || va == tohost + 4)) {
+      u64 v = sv;
+      if (size == 4) { if (va == tohost + 4) { h.htif_dev = (u32)sv; return true; } v |= (u64)h.htif_dev << 32; }
+      else if (size == 8) h.htif_dev = 0;
+      u32 cmd = (v >> 48) & 0xff, dev = (v >> 56) & 0xff;
+      if (dev == 0 && cmd == 0 && (sv & 1)) stop(ST_STOP_TOHOST, v);
+    }
+    return true;
+  }
+
+  // ---- CSR file (subset). class: 1 modelled, 0 not implemented, -1 unsupported.
+  WSP_HD int csr_class(u32 num) const
+  {
+    bool sup = ext(ISA_S);
+    switch (num) {
+      case C_FFLAGS: case C_FRM: case C_FCSR: return ext(ISA_F) ? 1 : 0;
+      case C_SSTATUS: case C_SIE: case C_STVEC: case C_SCOUNTEREN: case C_SENVCFG: case C_SSCRATCH: case C_SEPC:
+      case C_SCAUSE: case C_STVAL: case C_SIP: case C_SATP: case C_MEDELEG: case C_MIDELEG: return sup ? 1 : 0;
+      case C_MSTATUS: case C_MISA: case C_MIE: case C_MTVEC: case C_MCOUNTEREN: case C_MENVCFG: case C_MCOUNTINHIBIT:
+      case C_MSCRATCH: case C_MEPC: case C_MCAUSE: case C_MTVAL: case C_MIP: case C_MCYCLE: case C_MINSTRET:
+      case C_MVENDORID: case C_MARCHID: case C_MIMPID: case C_MHARTID: case C_MCONFIGPTR: return 1;
+      case C_CYCLE: case C_TIME: case C_INSTRET: return ext(ISA_ZICNTR) ? 1 : 0;
+      default: break;
+    }
+    if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : -1;
+    if (num >= 0xB03 && num <= 0xB1F) return -1;
+    if (num >= 0x323 && num <= 0x33F) return -1;
+    if (num == 0x747 || (num >= 0x7B0 && num <= 0x7B3)) return -1;
+    return 0;
+  }
+  WSP_HD u64 csr_peek(u32 num)
+  {
+    switch (num) {
+      case C_FFLAGS: return h.fcsr & 0x1f;
+      case C_FRM: return (h.fcsr >> 5) & 7;
+      case C_FCSR: return h.fcsr;
+      case C_SSTATUS: return h.mstatus & SSTATUS_RMASK;
+      case C_SIE: return m.cold(CI_MIE) & m.cold(CI_MIDELEG) & 0x2222;
+      case C_SIP: return m.cold(CI_MIP) & m.cold(CI_MIDELEG) & 0x2222;
+      case C_STVEC: return m.cold(CI_STVEC); case C_SCOUNTEREN: return m.cold(CI_SCOUNTEREN); case C_SENVCFG: return m.cold(CI_SENVCFG);
+      case C_SSCRATCH: return m.cold(CI_SSCRATCH); case C_SEPC: return m.cold(CI_SEPC); case C_SCAUSE: return m.cold(CI_SCAUSE);
+      case C_STVAL: return m.cold(CI_STVAL); case C_SATP: return m.cold(CI_SATP);
+      case C_MSTATUS: return (ext(ISA_F) || ext(ISA_S)) ? h.mstatus : (h.mstatus & ~(3ULL << MST_FS_SH));   // CsRegs.cpp:1977-1987
+      case C_MISA: return MISA_RESET;
+      case C_MEDELEG: return m.cold(CI_MEDELEG); case C_MIDELEG: return m.cold(CI_MIDELEG); case C_MIE: return m.cold(CI_MIE);
+      case C_MTVEC: return m.cold(CI_MTVEC); case C_MCOUNTEREN: return m.cold(CI_MCOUNTEREN); case C_MENVCFG: return m.cold(CI_MENVCFG);
+      case C_MCOUNTINHIBIT: return m.cold(CI_MCOUNTINHIBIT);
+      case C_MSCRATCH: return m.cold(CI_MSCRATCH); case C_MEPC: return m.cold(CI_MEPC); case C_MCAUSE: return m.cold(CI_MCAUSE);
+      case C_MTVAL: return m.cold(CI_MTVAL); case C_MIP: return m.cold(CI_MIP);
+      case C_MCYCLE: case C_CYCLE: return h.cycle;
+      case C_MINSTRET: case C_INSTRET: return h.instret;
+      case C_TIME: return h.exec;               // time_ ticks once per loop iteration (Hart.hpp:3101, 1 hart, downsample 0)
+      case C_MHARTID: return hart_id;
+      default: return 0;
+    }
+  }
+  // value update of CsRegs::write (CsRegs.cpp:3908-4165) for the modelled subset
+  WSP_HD void csr_store(u32 num, u64 v)
+  {
+    bool sup = ext(ISA_S);
+    switch (num) {
+      case C_FFLAGS: h.fcsr = (h.fcsr & ~0x1fu) | (u32)(v & 0x1f); break;
+      case C_FRM: h.fcsr = (h.fcsr & ~0xe0u) | (u32)((v & 7) << 5); break;
+      case C_FCSR: h.fcsr = (u32)(v & 0xff); break;
+      case C_MSTATUS: h.mstatus = legalize_mstatus((h.mstatus & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK)); break;
+      case C_SSTATUS: h.mstatus = legalize_mstatus((h.mstatus & ~SSTATUS_WMASK) | (v & SSTATUS_WMASK)); break;
+      case C_MEDELEG: m.cold(CI_MEDELEG) = v & ~((1ULL << 11) | (1ULL << 16) | (1ULL << 14)); break;
+      case C_MIDELEG: m.cold(CI_MIDELEG) = v & 0x222; break;
+      case C_MIE: { u64 k = 0x888 | (sup ? 0x222 : 0); m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
+      case C_MIP: { u64 k = sup ? 0x222 : 0; m.cold(CI_MIP) = (m.cold(CI_MIP) & ~k) | (v & k); break; }
+      case C_SIE: { u64 k = m.cold(CI_MIDELEG) & 0x222; m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
+      case C_SIP: { u64 k = m.cold(CI_MIDELEG) & 0x002; m.cold(CI_MIP) = (m.cold(CI_MIP) & ~k) | (v & k); break; }
+      case C_MTVEC: m.cold(CI_MTVEC) = v & ~2ULL; break;
+      case C_STVEC: m.cold(CI_STVEC) = v & ~2ULL; break;
+      case C_MCOUNTEREN: m.cold(CI_MCOUNTEREN) = v & 0xffffffffULL; break;
+      case C_SCOUNTEREN: m.cold(CI_SCOUNTEREN) = v; break;
+      case C_MENVCFG: m.cold(CI_MENVCFG) = v & 0xe0000003000000f5ULL; break;
+      case C_SENVCFG: m.cold(CI_SENVCFG) = v & 0x00000003000000f5ULL; break;
+      case C_MCOUNTINHIBIT: {
+        u64 nv = v & 0xfffffffdULL; m.cold(CI_MCOUNTINHIBIT) = nv;
+        h.flags = (h.flags & ~(HF_INH_CY | HF_INH_IR)) | ((nv & 1) ? (u32)HF_INH_CY : 0) | ((nv & 4) ? (u32)HF_INH_IR : 0);
+        break; }
+      case C_MSCRATCH: m.cold(CI_MSCRATCH) = v; break;
+      case C_SSCRATCH: m.cold(CI_SSCRATCH) = v; break;
+      case C_MEPC: m.cold(CI_MEPC) = v & ~1ULL; break;
+      case C_SEPC: m.cold(CI_SEPC) = v & ~1ULL; break;
+      case C_MCAUSE: m.cold(CI_MCAUSE) = v; break;
+      case C_SCAUSE: m.cold(CI_SCAUSE) = v; break;
+      case C_MTVAL: m.cold(CI_MTVAL) = v; break;
+      case C_STVAL: m.cold(CI_STVAL) = v; break;
+      case C_SATP: m.cold(CI_SATP) = v; break;
+      case C_MCYCLE: h.cycle = v; break;
+      case C_MINSTRET: h.instret = v; break;
+      default: break;
+    }
+  }
+  WSP_HD bool csr_readable(u32 num)
+  {
+    u32 need = (num >> 8) & 3; if (need == 2) need = 3;
+    if (h.priv < need) return false;
+    if (num == C_CYCLE || num == C_TIME || num == C_INSTRET) {
+      u32 bit = num - C_CYCLE;
+      if (h.priv < PRV_M && !((m.cold(CI_MCOUNTEREN) >> bit) & 1)) return false;
+      if (h.priv == PRV_U && ext(ISA_S) && !((m.cold(CI_SCOUNTEREN) >> bit) & 1)) return false;
+    }
+    return true;
+  }
+  // execCsrr* -> doCsrRead / doCsrWrite (Hart.cpp:13401-13748, 12987, 13244)
+  WSP_HD void exec_csr(const Rec& r, u32 op /*0 rw 1 rs 2 rc*/, u64 src, u64 cur_pc)
+  {
+    u32 num = (u32)r.imm & 0xfff, rd = rec_rd(r);
+    bool src_nz = rec_rs1(r) != 0;
+    int cls = csr_class(num);
+    bool do_read = op != 0 || rd != 0, do_write = op == 0 || src_nz;
+    if (cls < 0) { stop(ST_STOP_UNSUPPORTED, UNS_CSR_BASE | num); return; }
+    if (cls == 0) { illegal(r, cur_pc); return; }
+    if (num <= C_FCSR && !fp_on()) { illegal(r, cur_pc); return; }                       // Hart.cpp:12945-12950
+    if (!csr_readable(num) || (do_write && ((num >> 10) & 3) == 3)) { illegal(r, cur_pc); return; }
+    if (num == C_SATP && h.priv == PRV_S && (h.mstatus & MST_TVM)) { illegal(r, cur_pc); return; }
+    u64 prev = do_read ? csr_peek(num) : 0;
+    if (!do_write) { wx(rd, prev); return; }
+    u64 next = op == 0 ? src : op == 1 ? (prev | src) : (prev & ~src);
+    // the reference pre-increments then post-decrements the counter being written so that the run
+    // loop's own increment is cancelled (Hart.cpp:13251-13255, 13354-13360)
+    bool w_ir = num == C_MINSTRET && !(h.flags & HF_INH_IR), w_cy = num == C_MCYCLE;
+    wx(rd, prev);
+    if (num == C_SATP) {
+      u32 mode = (u32)(next >> 60);
+      if (mode != 0 && mode != 8 && mode != 9 && mode != 10) return;                      // unsupported MODE: write dropped (13284-13294)
+      if (mode != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return; }
+    }
+    csr_store(num, next);
+    if (num == C_MSTATUS) s.chg |= CH_MSTATUS; else if (num == C_SSTATUS) s.chg |= CH_SSTATUS;
+    else { s.chg |= CH_GEN; s.gen_csr = num; }
+    if (num <= C_FCSR) mark_fs_dirty();
+    if (w_ir) h.instret--;
+    if (w_cy) h.cycle--;
+  }
+
+  // ---- floating point (float.cpp). Returns false when the instruction is illegal.
+  WSP_HD bool fp_rm(u32 rmf, int& rm) const { u32 k = rmf == 7 ? ((h.fcsr >> 5) & 7) : rmf; rm = (int)k; return k < 5; }   // float.cpp:200-216
+
+  template <class F> WSP_HD u64 fneg(u64 a, unsigned& fl)                                 // doNegate (float-util.hpp:743-758)
+  { if (!(a & (F::SIGN - 1))) return a ^ F::SIGN; return wsf::f_sub<F>(0, a, 0 /*exact unless NaN*/, fl); }
+
+  WSP_HD void exec_fp(const Rec& r, u64 a /*x[rs1]*/, u64 cur_pc)
+  {
+    using namespace wsf;
+    u32 op = rec_op(r), rd = rec_rd(r), rs1 = rec_rs1(r), rs2 = rec_rs2(r);
+    bool dbl = (r.w0 & F_DBL) != 0;
+    if (!fp_on()) { illegal(r, cur_pc); return; }
+    unsigned fl = 0; int rm = 0;
+    switch (op) {
+      case OP_FADD: case OP_FSUB: case OP_FMUL: case OP_FDIV: case OP_FSQRT: {
+        if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
+        if (dbl) {
+          u64 x = m.rf(rs1), y = m.rf(rs2);
+          u64 z = op == OP_FADD ? f_add<F64>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F64>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F64>(x, y, rm, fl)
+                : op == OP_FDIV ? f_div<F64>(x, y, rm, fl) : f_sqrt<F64>(x, rm, fl);
+          wf(rd, z);
+        } else {
+          u64 x = rf_s(rs1), y = rf_s(rs2);
+          u64 z = op == OP_FADD ? f_add<F32>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F32>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F32>(x, y, rm, fl)
+                : op == OP_FDIV ? f_div<F32>(x, y, rm, fl) : f_sqrt<F32>(x, rm, fl);
+          wf_s(rd, (u32)z);
+        }
+        or_fflags(fl); mark_fs_dirty(); return; }
+      case OP_FMA: {
+        if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
+        u32 k = ((u32)r.imm >> 3) & 3, rs3 = rec_rs3(r);
+        if (dbl) {
+          u64 x = m.rf(rs1), y = m.rf(rs2), z = m.rf(rs3);
+          if (k == 1 || k == 3) z = fneg<F64>(z, fl);
+          if (k == 2 || k == 3) x = fneg<F64>(x, fl);
+          wf(rd, f_fma<F64>(x, y, z, rm, fl));
+        } else {
+          u64 x = rf_s(rs1), y = rf_s(rs2), z = rf_s(rs3);
+          if (k == 1 || k == 3) z = fneg<F32>(z, fl);
+          if (k == 2 || k == 3) x = fneg<F32>(x, fl);
+          wf_s(rd, (u32)f_fma<F32>(x, y, z, rm, fl));
+        }
+        or_fflags(fl); mark_fs_dirty(); return; }
+      case OP_FSGNJ: {                                                                     // float.cpp:499-564
+        u32 k = (u32)r.imm;
+        if (dbl) { u64 x = m.rf(rs1), y = m.rf(rs2), sb = F64::SIGN; u64 sg = k == 0 ? (y & sb) : k == 1 ? (~y & sb) : ((x ^ y) & sb); wf(rd, (x & ~sb) | sg); }
+        else { u32 x = rf_s(rs1), y = rf_s(rs2), sb = 0x80000000u; u32 sg = k == 0 ? (y & sb) : k == 1 ? (~y & sb) : ((x ^ y) & sb); wf_s(rd, (x & ~sb) | sg); }
+        mark_fs_dirty(); return; }
+      case OP_FMINMAX: {                                                                   // float.cpp:569-634
+        bool mx = r.imm != 0;
+        if (dbl) {
+          u64 x = m.rf(rs1), y = m.rf(rs2), z; bool n1 = is_nan<F64>(x), n2 = is_nan<F64>(y);
+          if (n1 && n2) z = F64::QNAN; else if (n1) z = y; else if (n2) z = x;
+          else if (!mx) z = (lt_ord<F64>(x, y) || (eq_ord<F64>(x, y) && (x >> 63))) ? x : y;
+          else z = (lt_ord<F64>(y, x) || (eq_ord<F64>(x, y) && !(x >> 63))) ? x : y;
+          if (is_snan<F64>(x) || is_snan<F64>(y)) or_fflags(FL_NV);
+          wf(rd, z);
+        } else {
+          u64 x = rf_s(rs1), y = rf_s(rs2), z; bool n1 = is_nan<F32>(x), n2 = is_nan<F32>(y);
+          if (n1 && n2) z = F32::QNAN; else if (n1) z = y; else if (n2) z = x;
+          else if (!mx) z = (lt_ord<F32>(x, y) || (eq_ord<F32>(x, y) && (x >> 31))) ? x : y;
+          else z = (lt_ord<F32>(y, x) || (eq_ord<F32>(x, y) && !(x >> 31))) ? x : y;
+          if (is_snan<F32>(x) || is_snan<F32>(y)) or_fflags(FL_NV);
+          wf_s(rd, (u32)z);
+        }
+        mark_fs_dirty(); return; }
+      case OP_FCMP: {                                                                      // float.cpp:694-764
+        u32 k = (u32)r.imm; u64 res = 0;
+        if (dbl) {
+          u64 x = m.rf(rs1), y = m.rf(rs2);
+          if (is_nan<F64>(x) || is_nan<F64>(y)) { if (k != 2 || is_snan<F64>(x) || is_snan<F64>(y)) or_fflags(FL_NV); }
+          else res = k == 2 ? eq_ord<F64>(x, y) : k == 1 ? lt_ord<F64>(x, y) : (lt_ord<F64>(x, y) || eq_ord<F64>(x, y));
+        } else {
+          u64 x = rf_s(rs1), y = rf_s(rs2);
+          if (is_nan<F32>(x) || is_nan<F32>(y)) { if (k != 2 || is_snan<F32>(x) || is_snan<F32>(y)) or_fflags(FL_NV); }
+          else res = k == 2 ? eq_ord<F32>(x, y) : k == 1 ? lt_ord<F32>(x, y) : (lt_ord<F32>(x, y) || eq_ord<F32>(x, y));
+        }
+        wx(rd, res); return; }
+      case OP_FCVT_F2I: {                                                                  // float.cpp:639-669, 898-948
+        if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
+        bool sg = !(rs2 & 1), w = (rs2 & 2) != 0;
+        u64 z = dbl ? f_to_int<F64>(m.rf(rs1), rm, sg, w, fl) : f_to_int<F32>(rf_s(rs1), rm, sg, w, fl);
+        if (!w) z = (u64)(i64)(i32)(u32)z;
+        wx(rd, z); or_fflags(fl); return; }
+      case OP_FCVT_I2F: {
+        if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
+        bool sg = !(rs2 & 1), w = (rs2 & 2) != 0;
+        if (dbl) wf(rd, int_to_f<F64>(a, sg, w, rm, fl)); else wf_s(rd, (u32)int_to_f<F32>(a, sg, w, rm, fl));
+        or_fflags(fl); mark_fs_dirty(); return; }
+      case OP_FCVT_FF: {
+        if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
+        if (dbl) wf(rd, f32_to_f64(rf_s(rs1), fl)); else wf_s(rd, (u32)f64_to_f32(m.rf(rs1), rm, fl));
+        or_fflags(fl); mark_fs_dirty(); return; }
+      case OP_FMV_F2X: wx(rd, dbl ? m.rf(rs1) : (u64)(i64)(i32)(u32)m.rf(rs1)); return;   // raw bits: float.cpp:682-688
+      case OP_FCLASS: wx(rd, dbl ? fclass<F64>(m.rf(rs1)) : fclass<F32>(rf_s(rs1))); return;
+      case OP_FMV_X2F: if (dbl) wf(rd, a); else wf_s(rd, (u32)a); mark_fs_dirty(); return;
+      default: illegal(r, cur_pc); return;
+    }
+  }
+
+  // ---- A extension (amo.cpp)
+  WSP_HD void exec_atomic(const Rec& r, u64 va, u64 b, u64 cur_pc)
+  {
+    u32 op = rec_op(r), rd = rec_rd(r), size = (r.w0 & F_DBL) ? 8 : 4;
+    u64 tval;
+    if (paging_unsupported()) return;
+    if (op == OP_LR) {                                                                     // amo.cpp:142-266
+      if ((va & (size - 1)) || !check_access(va, size, tval)) { take_exception(5, cur_pc, va, false); return; }
+      u64 v = mem_read(va - mem_base, size);
+      if (size == 4) v = (u64)(i64)(i32)v;
+      wx(rd, v);
+      h.flags |= HF_LR_VALID; h.lr_addr = va & ~7ULL;                                      // lrResSize_ = 8 (Hart.hpp:6733)
+      return;
+    }
+    if (op == OP_SC) {                                                                     // amo.cpp:273-420
+      bool exc = (va & (size - 1)) || !check_access(va, size, tval);
+      bool had = (h.flags & HF_LR_VALID) && h.lr_addr <= va && va + size <= h.lr_addr + 8;
+      h.flags &= ~HF_LR_VALID;                                                             // cancelLr(SC): amo.cpp:403-405
+      if (exc) { take_exception(7, cur_pc, va, false); return; }
+      if (!had) { wx(rd, 1); return; }
+      u64 sv = size == 8 ? b : (b & 0xffffffffULL);
+      s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
+      mem_write(va - mem_base, size, sv);
+      if (va + size > text_lo && va < text_hi) h.flags |= HF_CODE_DIRTY;
+      wx(rd, 0);
+      return;
+    }
+    if ((va & (size - 1)) || !check_access(va, size, tval)) { take_exception(7, cur_pc, va, false); return; }   // amo.cpp:28-56
+    u64 ld = mem_read(va - mem_base, size), res;
+    if (size == 4) ld = (u64)(i64)(i32)ld;
+    switch ((u32)r.imm) {
+      case 0: res = b + ld; break; case 1: res = b; break; case 4: res = b ^ ld; break; case 8: res = b | ld; break; case 12: res = b & ld; break;
+      case 16: res = size == 4 ? (u64)(i64)((i32)b < (i32)ld ? (i32)b : (i32)ld) : (u64)((i64)b < (i64)ld ? (i64)b : (i64)ld); break;
+      case 20: res = size == 4 ? (u64)(i64)((i32)b > (i32)ld ? (i32)b : (i32)ld) : (u64)((i64)b > (i64)ld ? (i64)b : (i64)ld); break;
+      case 24: res = size == 4 ? (u64)((u32)b < (u32)ld ? (u32)b : (u32)ld) : (b < ld ? b : ld); break;
+      default: res = size == 4 ? (u64)((u32)b > (u32)ld ? (u32)b : (u32)ld) : (b > ld ? b : ld); break;
+    }
+    if (!do_store(va, size, res, cur_pc)) return;
+    wx(rd, ld);
+  }
+
+  // ---- one decoded instruction. `op` is passed separately so the GPU kernel can hand in a
+  // wave-uniform copy (scalar branch over the switch); a = x[rs1], b = second operand.
+  WSP_HD void exec(u32 op, const Rec& r, u64 a, u64 b, u64 cur_pc)
+  {
+    u32 rd = rec_rd(r);
+    u32 size = (r.w0 & F_SIZE4) ? 4 : 2;
+    bool zca = ext(ISA_C);
+    switch (op) {
+      case OP_ADD: wx(rd, a + b); break;
+      case OP_SUB: wx(rd, a - b); break;
+      case OP_SLL: wx(rd, a << (b & 63)); break;
+      case OP_SLT: wx(rd, (i64)a < (i64)b); break;
+      case OP_SLTU: wx(rd, a < b); break;
+      case OP_XOR: wx(rd, a ^ b); break;
+      case OP_SRL: wx(rd, a >> (b & 63)); break;
+      case OP_SRA: wx(rd, (u64)((i64)a >> (b & 63))); break;
+      case OP_OR: wx(rd, a | b); break;
+      case OP_AND: wx(rd, a & b); break;
+      case OP_ADDW: wx(rd, (u64)(i64)(i32)((u32)a + (u32)b)); break;
+      case OP_SUBW: wx(rd, (u64)(i64)(i32)((u32)a - (u32)b)); break;
+      case OP_SLLW: wx(rd, (u64)(i64)(i32)((u32)a << (b & 31))); break;
+      case OP_SRLW: wx(rd, (u64)(i64)(i32)((u32)a >> (b & 31))); break;
+      case OP_SRAW: wx(rd, (u64)(i64)((i32)a >> (b & 31))); break;
+      case OP_MUL: wx(rd, a * b); break;                                                     // Hart.cpp:13964-14100
+      case OP_MULH: { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; wx(rd, hi); break; }
+      case OP_MULHSU: { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; wx(rd, hi); break; }
+      case OP_MULHU: wx(rd, wsf::mul64x64(a, b).hi); break;
+      case OP_DIV: wx(rd, b == 0 ? ~0ULL : ((i64)a == INT64_MIN && (i64)b == -1) ? a : (u64)((i64)a / (i64)b)); break;   // Hart.cpp:14111-14170
+      case OP_DIVU: wx(rd, b == 0 ? ~0ULL : a / b); break;
+      case OP_REM: wx(rd, b == 0 ? a : ((i64)a == INT64_MIN && (i64)b == -1) ? 0 : (u64)((i64)a % (i64)b)); break;
+      case OP_REMU: wx(rd, b == 0 ? a : a % b); break;
+      case OP_MULW: wx(rd, (u64)(i64)(i32)((u32)a * (u32)b)); break;
+      case OP_DIVW: { i32 x = (i32)a, y = (i32)b; wx(rd, (u64)(i64)(y == 0 ? -1 : (x == INT32_MIN && y == -1) ? x : x / y)); break; }
+      case OP_DIVUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? ~0u : x / y)); break; }
+      case OP_REMW: { i32 x = (i32)a, y = (i32)b; wx(rd, (u64)(i64)(y == 0 ? x : (x == INT32_MIN && y == -1) ? 0 : x % y)); break; }
+      case OP_REMUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? x : x % y)); break; }
+      case OP_AUIPC: wx(rd, cur_pc + (u64)(i64)r.imm); break;
+      case OP_JAL: {
+        u64 t = cur_pc + (u64)(i64)r.imm;
+        if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                  // Hart.cpp:11687-11690
+        wx(rd, cur_pc + size); h.pc = t & ~1ULL; break; }
+      case OP_JALR: {
+        u64 t = (a + (u64)(i64)r.imm) & ~1ULL;
+        if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                  // Hart.cpp:11711-11714
+        wx(rd, cur_pc + size); h.pc = t; break; }
+      case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
+        bool take = op == OP_BEQ ? a == b : op == OP_BNE ? a != b : op == OP_BLT ? (i64)a < (i64)b
+                  : op == OP_BGE ? (i64)a >= (i64)b : op == OP_BLTU ? a < b : a >= b;
+        if (take) {
+          u64 t = cur_pc + (u64)(i64)r.imm;
+          if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                // Hart.cpp:1652-1656
+          h.pc = t & ~1ULL;
+        }
+        break; }
+      case OP_LB: case OP_LH: case OP_LW: case OP_LD: case OP_LBU: case OP_LHU: case OP_LWU: {
+        u32 k = op - OP_LB; u32 sz = 1u << (k & 3); u64 v;
+        if (!do_load(a + (u64)(i64)r.imm, sz, cur_pc, v)) break;
+        if (k == 0) v = (u64)(i64)(int8_t)v; else if (k == 1) v = (u64)(i64)(int16_t)v; else if (k == 2) v = (u64)(i64)(i32)v;
+        wx(rd, v); break; }
+      case OP_SB: case OP_SH: case OP_SW: case OP_SD: do_store(a + (u64)(i64)r.imm, 1u << (op - OP_SB), b, cur_pc); break;
+      case OP_NOP: break;
+      case OP_ECALL: take_exception(h.priv == PRV_M ? 11 : h.priv == PRV_S ? 9 : 8, cur_pc, 0, true); break;   // Hart.cpp:12006-12014
+      case OP_EBREAK: take_exception(3, cur_pc, cur_pc, true); break;                        // Hart.cpp:12094-12101
+      case OP_MRET: {                                                                        // Hart.cpp:12247-12336
+        if (h.priv < PRV_M) { illegal(r, cur_pc); break; }
+        u64 v = h.mstatus; u32 saved = (v >> MST_MPP_SH) & 3;
+        v = (v & ~MST_MIE) | ((v & MST_MPIE) ? MST_MIE : 0);
+        u32 least = ext(ISA_U) ? PRV_U : ext(ISA_S) ? PRV_S : PRV_M;
+        v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)least << MST_MPP_SH);
+        v |= MST_MPIE;
+        if (saved != PRV_M) v &= ~MST_MPRV;
+        csr_store(C_MSTATUS, v); s.chg |= CH_MSTATUS;
+        h.pc = m.cold(CI_MEPC) & ~1ULL; h.priv = saved; break; }
+      case OP_SRET: {                                                                        // Hart.cpp:12428-12560
+        if (h.priv < PRV_S || ((h.mstatus & MST_TSR) && h.priv == PRV_S)) { illegal(r, cur_pc); break; }
+        u64 v = h.mstatus; u32 saved = (v & MST_SPP) ? PRV_S : PRV_U;
+        v = (v & ~MST_SIE) | ((v & MST_SPIE) ? MST_SIE : 0);
+        v = ext(ISA_U) ? (v & ~MST_SPP) : (v | MST_SPP);
+        v |= MST_SPIE; v &= ~MST_MPRV;
+        h.mstatus = legalize_mstatus(v); s.chg |= CH_SSTATUS;
+        h.pc = m.cold(CI_SEPC) & ~1ULL; h.priv = saved; break; }
+      case OP_WFI:                                                                           // Hart.cpp:12618
+        if ((h.priv == PRV_U && ext(ISA_S)) || (h.priv != PRV_M && (h.mstatus & MST_TW))) illegal(r, cur_pc);
+        break;
+      case OP_SFENCE_VMA:                                                                    // Hart.cpp:12108
+        if (h.priv == PRV_U || (h.priv == PRV_S && (h.mstatus & MST_TVM))) illegal(r, cur_pc);
+        break;
+      case OP_CSRRW: case OP_CSRRS: case OP_CSRRC: exec_csr(r, op - OP_CSRRW, (r.w0 & F_IMM) ? (u64)rec_rs1(r) : a, cur_pc); break;
+      case OP_LR: case OP_SC: case OP_AMO: exec_atomic(r, a, b, cur_pc); break;
+      case OP_FLW: case OP_FLD: {                                                            // float.cpp:281-298, 1019-1036
+        if (!fp_on()) { illegal(r, cur_pc); break; }
+        u64 v;
+        if (!do_load(a + (u64)(i64)r.imm, op == OP_FLW ? 4 : 8, cur_pc, v)) break;
+        if (op == OP_FLW) wf_s(rd, (u32)v); else wf(rd, v);
+        mark_fs_dirty(); break; }
+      case OP_FSW: case OP_FSD: {                                                            // float.cpp:303-321, 1041-1057
+        if (!fp_on()) { illegal(r, cur_pc); break; }
+        u64 v = m.rf(rec_rs2(r));
+        do_store(a + (u64)(i64)r.imm, op == OP_FSW ? 4 : 8, op == OP_FSW ? (v & 0xffffffffULL) : v, cur_pc);
+        break; }
+      case OP_FADD: case OP_FSUB: case OP_FMUL: case OP_FDIV: case OP_FSQRT: case OP_FMA: case OP_FSGNJ: case OP_FMINMAX:
+      case OP_FCMP: case OP_FCVT_F2I: case OP_FCVT_I2F: case OP_FCVT_FF: case OP_FMV_F2X: case OP_FCLASS: case OP_FMV_X2F:
+        exec_fp(r, a, cur_pc); break;
+      default: illegal(r, cur_pc); break;
+    }
+  }
+
+  // ---- fetch from RAM + decode (slow path; also the only path for self-modified code)
+  // fetchInstNoTrap (Hart.cpp:3052-3206), bare translation. Returns 0 ok, 1 fault (tval), 2 stop.
+  WSP_HD int fetch_slow(u64 pc, Rec& r, u64& tval)
+  {
+    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return 2; }
+    if (h.priv != PRV_M) { tval = pc; return 1; }       // PMP: no entry matches, S/U denied
+    u32 inst;
+    if (!(pc & 3)) {
+      if (!in_mem(pc, 4)) { tval = pc; return 1; }
+      inst = m.ld32(pc - mem_base);
+      if ((inst & 3) != 3) inst &= 0xffff;
+    } else {
+      if (!in_mem(pc, 2)) { tval = pc; return 1; }
+      inst = m.ld16(pc - mem_base);
+      if ((inst & 3) == 3) {
+        if (!in_mem(pc + 2, 2)) { tval = pc + 2; return 1; }
+        inst |= (u32)m.ld16(pc + 2 - mem_base) << 16;
+      }
+    }
+    r = decode(inst, isa);
+    return 0;
+  }
+
+  // ---- one loop iteration of Hart::untilAddress (Hart.cpp:6025-6201), split around the dispatch so
+  // that the GPU kernel can run the execute part wave-uniformly.  step_begin does the bookkeeping and
+  // the fetch and returns true when `rec` must be executed (operands a, b already read).
+  template <bool TRACE> WSP_HD bool step_begin(const Rec* recs, Rec& rec, u64& a, u64& b, u64& cur_pc, u32& priv0)
+  {
+    cur_pc = h.pc; priv0 = h.priv;
+    s.chg = 0;
+    h.exec++;
+    if (!(h.flags & HF_INH_CY)) h.cycle++;
+    int fr = 0; u64 tval = 0;
+    bool fast = !(h.flags & HF_CODE_DIRTY) && priv0 == PRV_M && cur_pc >= text_lo && cur_pc < text_hi;
+    if (fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint4 q = *reinterpret_cast<const uint4*>(&recs[(cur_pc - text_lo) >> 1]);
+      rec.w0 = q.x; rec.imm = (i32)q.y; rec.raw = q.z; rec.pad = 0;
+#else
+      rec = recs[(cur_pc - text_lo) >> 1];
+#endif
+      if ((rec.w0 & 0xff) == OP_SLOWFETCH) fast = false;
+    }
+    if (!fast) fr = fetch_slow(cur_pc, rec, tval);
+    if (fr == 1) {
+      take_exception(1, cur_pc, tval, true);
+      if (h.status != ST_RUNNING) {                 // consecutive-illegal stop inside the fetch fault
+        h.retired++; if (!(h.flags & HF_INH_IR)) h.instret++;
+        commit<TRACE>(cur_pc, 0, 2, priv0, 0);
+      } else {
+        if (!(h.flags & HF_INH_CY)) h.cycle++;      // fetchInstWithTrigger (Hart.cpp:5966-5967)
+        commit<TRACE>(cur_pc, 0, 2, priv0, 1);
+      }
+      return false;
+    }
+    if (fr != 0) return false;
+    h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);   // Hart.cpp:6120
+    a = m.rx(rec_rs1(rec));
+    b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
+    return true;
+  }
+  // retire + commit record (Hart.cpp:6128-6179; logStop printTrace.cpp:965-976)
+  template <bool TRACE> WSP_HD void step_end(const Rec& rec, u64 cur_pc, u32 priv0)
+  {
+    if (h.status == ST_STOP_UNSUPPORTED) return;
+    const u32 size = (rec.w0 & F_SIZE4) ? 4 : 2;
+    if (h.status == ST_RUNNING && (s.chg & CH_EXC)) { commit<TRACE>(cur_pc, rec.raw, size, priv0, 1); return; }
+    if (!(h.flags & HF_INH_IR)) h.instret++;
+    h.retired++;
+    commit<TRACE>(cur_pc, rec.raw, size, priv0, 0);
+  }
+
+  // ---- fold one commit record into the running trace hash
+  template <bool TRACE> WSP_HD void commit(u64 cur_pc, u32 raw, u32 size, u32 priv0, u32 trap)
+  {
+    if (!TRACE) return;
+    u64 t = h.thash;
+    t = fold(t, cur_pc);
+    t = fold(t, (u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48));
+    u32 c = s.chg; bool any = false;
+    if ((c & CH_IREG) && s.ireg) { t = fold(t, (u64)s.ireg ^ (1ULL << 60)); t = fold(t, s.ival); any = true; }
+    if (c & CH_FREG) { t = fold(t, (u64)s.freg ^ (2ULL << 60)); t = fold(t, s.fval); any = true; }
+    if (c & CH_MEM) { t = fold(t, s.maddr ^ (4ULL << 60)); t = fold(t, s.mval); any = true; }
+    const u64 K = 5ULL << 60;
+    bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
+    if (gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
+    if (c & CH_SSTATUS) { t = fold(t, (u64)C_SSTATUS ^ K); t = fold(t, csr_peek(C_SSTATUS)); any = true; }
+    if (c & CH_SEPC) { t = fold(t, (u64)C_SEPC ^ K); t = fold(t, m.cold(CI_SEPC)); any = true; }
+    if (c & CH_SCAUSE) { t = fold(t, (u64)C_SCAUSE ^ K); t = fold(t, m.cold(CI_SCAUSE)); any = true; }
+    if (c & CH_STVAL) { t = fold(t, (u64)C_STVAL ^ K); t = fold(t, m.cold(CI_STVAL)); any = true; }
+    if (c & CH_MSTATUS) { t = fold(t, (u64)C_MSTATUS ^ K); t = fold(t, csr_peek(C_MSTATUS)); any = true; }
+    if ((c & CH_GEN) && !gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
+    if (c & CH_MEPC) { t = fold(t, (u64)C_MEPC ^ K); t = fold(t, m.cold(CI_MEPC)); any = true; }
+    if (c & CH_MCAUSE) { t = fold(t, (u64)C_MCAUSE ^ K); t = fold(t, m.cold(CI_MCAUSE)); any = true; }
+    if (c & CH_MTVAL) { t = fold(t, (u64)C_MTVAL ^ K); t = fold(t, m.cold(CI_MTVAL)); any = true; }
+    if (!any) { t = fold(t, 1ULL << 60); t = fold(t, 0); }                                   // printTrace.cpp:491-493
+    h.thash = t;
+  }
+};
+
+}  // namespace wsp

@@ -1,0 +1,812 @@
+// whisper_amd: HIP kernels (gfx950) + host front end + C ABI (include/whisper_amd.h).
+//
+// Execution model: one lane = one hart, one 64-lane wavefront per workgroup steps up
+// to 64 harts in lock step.  Integer and FP register files are staged in LDS as [reg][lane]
+// (bank-conflict free for both converged and diverged register numbers), the per-step state
+// (struct wsp::Hot) stays in VGPRs for the whole slice, cold CSRs / RAM arenas / pre-decoded
+// programs live in HBM.  Dispatch picks the op of the first pending lane, makes it wave-uniform
+// with readlane and runs that op for every lane that fetched the same op; converged harts cost
+// one pass per step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include "wsp_core.h"
+#include "../../include/whisper_amd.h"
+
+using namespace wsp;
+
+// ------------------------------------------------------------------------------------------ layout
+enum { H64_PC, H64_MSTATUS, H64_CYCLE, H64_INSTRET, H64_EXEC, H64_RETIRED, H64_THASH, H64_LR_ADDR, H64_EXEC_LAST_ILL, H64_STOP_VALUE, H64_COUNT };
+enum { H32_FCSR, H32_PRIV, H32_STATUS, H32_CONSEC_ILL, H32_HTIF_DEV, H32_FLAGS, H32_COUNT };
+
+struct ProgDev { u64 text_lo, text_hi; const Rec* recs; };
+
+struct DevState {
+  u32 n_harts, n_waves, lpw, lpw_shift, S, isa, hart_id_base, pad;
+  u64 mem_base, mem_size;
+  u64* x; u64* f; u64* hot64; u32* hot32; u64* cold;
+  u64* tohost; u64* max_exec; u32* prog;
+  u8* arena;
+  const ProgDev* progs;
+  u32* running;
+};
+
+__host__ __device__ static inline u32 slot_of(const DevState& d, u32 hart) { return (hart >> d.lpw_shift) * 64 + (hart & (d.lpw - 1)); }
+__host__ __device__ static inline size_t arena_off(const DevState& d, u32 hart, u64 off)
+{
+  u32 w = hart >> d.lpw_shift, l = hart & (d.lpw - 1);
+  return (size_t)w * d.lpw * d.mem_size + ((((size_t)(off >> 3) << d.lpw_shift) + l) << 3) + (off & 7);
+}
+
+// ------------------------------------------------------------------------------------------ device memory policy
+struct DevMem {
+  u64* xs; u64* fs; u64* cold_; u8* arena; u32 S, lpw_shift;
+  __device__ __forceinline__ u64 rx(u32 r) const { return xs[r << lpw_shift]; }
+  __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r << lpw_shift] = v; }
+  __device__ __forceinline__ u64 rf(u32 r) const { return fs[r << lpw_shift]; }
+  __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r << lpw_shift] = v; }
+  __device__ __forceinline__ u64& cold(u32 i) { return cold_[(size_t)i * S]; }
+  __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
+  __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
+  __device__ __forceinline__ u16 ld16(u64 o) const { return *(const u16*)p(o); }
+  __device__ __forceinline__ u32 ld32(u64 o) const { return *(const u32*)p(o); }
+  __device__ __forceinline__ u64 ld64(u64 o) const { return *(const u64*)p(o); }
+  __device__ __forceinline__ void st8(u64 o, u8 v) { *p(o) = v; }
+  __device__ __forceinline__ void st16(u64 o, u16 v) { *(u16*)p(o) = v; }
+  __device__ __forceinline__ void st32(u64 o, u32 v) { *(u32*)p(o) = v; }
+  __device__ __forceinline__ void st64(u64 o, u64 v) { *(u64*)p(o) = v; }
+};
+
+// ------------------------------------------------------------------------------------------ step kernel
+extern __shared__ __align__(16) u64 wsp_lds[];
+
+template <bool TRACE, bool FP>
+__global__ void __launch_bounds__(64) wsp_step_kernel(DevState d, u64 max_steps)
+{
+  const u32 lane = threadIdx.x, wave = blockIdx.x;
+  const u32 hart = wave * d.lpw + lane;
+  const bool active = lane < d.lpw && hart < d.n_harts;
+  const u32 ln = active ? lane : 0;
+  const u32 slot = wave * 64 + ln;
+  const u32 S = d.S;
+
+  Lane<DevMem> L;
+  L.m.xs = wsp_lds + ln;
+  L.m.fs = wsp_lds + 32 * d.lpw + ln;
+  L.m.cold_ = d.cold + slot;
+  L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
+  L.m.S = S; L.m.lpw_shift = d.lpw_shift;
+  L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + hart;
+  L.tohost = d.tohost[slot];
+  const u64 max_exec = d.max_exec[slot];
+  const u32 pg = d.prog[slot];
+  const Rec* recs = nullptr; L.text_lo = 0; L.text_hi = 0;
+  if (pg != ~0u) { ProgDev p = d.progs[pg]; recs = p.recs; L.text_lo = p.text_lo; L.text_hi = p.text_hi; }
+
+  L.h.pc = d.hot64[H64_PC * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.cycle = d.hot64[H64_CYCLE * S + slot];
+  L.h.instret = d.hot64[H64_INSTRET * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.retired = d.hot64[H64_RETIRED * S + slot];
+  L.h.thash = d.hot64[H64_THASH * S + slot]; L.h.lr_addr = d.hot64[H64_LR_ADDR * S + slot];
+  L.h.exec_last_ill = d.hot64[H64_EXEC_LAST_ILL * S + slot]; L.h.stop_value = d.hot64[H64_STOP_VALUE * S + slot];
+  L.h.fcsr = d.hot32[H32_FCSR * S + slot]; L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.status = d.hot32[H32_STATUS * S + slot];
+  L.h.consec_ill = d.hot32[H32_CONSEC_ILL * S + slot]; L.h.htif_dev = d.hot32[H32_HTIF_DEV * S + slot]; L.h.flags = d.hot32[H32_FLAGS * S + slot];
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  const u32 status_in = L.h.status;
+  if (!active) L.h.status = ST_STOP_LIMIT;
+
+  if (active) {
+    for (u32 r = 0; r < 32; ++r) L.m.wx(r, d.x[(size_t)r * S + slot]);
+    if (FP) for (u32 r = 0; r < 32; ++r) L.m.wf(r, d.f[(size_t)r * S + slot]);
+  }
+  __syncthreads();
+
+  for (u64 it = 0; it < max_steps; ++it) {
+    bool run = L.h.status == ST_RUNNING;
+    if (run && L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; run = false; }
+    if (!__any(run)) break;                              // every lane of the wave has stopped
+
+    // ---- prologue: bookkeeping + fetch (Hart.cpp:6067-6120)
+    Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+    u64 cur_pc = 0, a = 0, b = 0; u32 priv0 = 0;
+    bool todo = false;
+    if (run) todo = L.template step_begin<TRACE>(recs, rec, a, b, cur_pc, priv0);
+    const bool exed = todo;
+
+    // ---- dispatch: wave-uniform op, executed for every lane that fetched it
+    const u32 op = rec.w0 & 0xff;
+    unsigned long long pend = __ballot(todo);
+    while (pend) {
+      const int leader = __ffsll((long long)pend) - 1;
+      const u32 lop = (u32)__builtin_amdgcn_readlane((int)op, leader);
+      const bool mine = todo && op == lop;
+      if (mine) {
+        if (FP || lop < OP_FLW) L.exec(lop, rec, a, b, cur_pc);
+        else L.stop(ST_STOP_UNSUPPORTED, 0xF);
+        todo = false;
+      }
+      pend &= ~__ballot(mine);
+    }
+
+    // ---- epilogue: retire + commit record
+    if (exed) L.template step_end<TRACE>(rec, cur_pc, priv0);
+  }
+
+  __syncthreads();
+  if (active) {
+    for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
+    if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
+    d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_MSTATUS * S + slot] = L.h.mstatus; d.hot64[H64_CYCLE * S + slot] = L.h.cycle;
+    d.hot64[H64_INSTRET * S + slot] = L.h.instret; d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_RETIRED * S + slot] = L.h.retired;
+    d.hot64[H64_THASH * S + slot] = L.h.thash; d.hot64[H64_LR_ADDR * S + slot] = L.h.lr_addr;
+    d.hot64[H64_EXEC_LAST_ILL * S + slot] = L.h.exec_last_ill; d.hot64[H64_STOP_VALUE * S + slot] = L.h.stop_value;
+    d.hot32[H32_FCSR * S + slot] = L.h.fcsr; d.hot32[H32_PRIV * S + slot] = L.h.priv;
+    // a hart that only hit this slice's step budget (not its own instruction limit) stays RUNNING
+    d.hot32[H32_STATUS * S + slot] = L.h.status;
+    d.hot32[H32_CONSEC_ILL * S + slot] = L.h.consec_ill; d.hot32[H32_HTIF_DEV * S + slot] = L.h.htif_dev; d.hot32[H32_FLAGS * S + slot] = L.h.flags;
+  }
+  (void)status_in;
+  const unsigned long long still = __ballot(active && L.h.status == ST_RUNNING);
+  if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
+}
+
+// ------------------------------------------------------------------------------------------ support kernels
+// Pre-decode one program image: thread i decodes the (up to) 4 bytes at byte offset 2*i.
+__global__ void wsp_predecode_kernel(const u8* img, u64 n_bytes, u32 isa, Rec* out)
+{
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 off = i * 2;
+  if (off + 2 > n_bytes) return;
+  u32 lo = img[off] | ((u32)img[off + 1] << 8);
+  Rec r;
+  if ((lo & 3) != 3) r = decode16(lo, isa);
+  else if (off + 4 <= n_bytes) r = decode32(lo | ((u32)img[off + 2] << 16) | ((u32)img[off + 3] << 24), isa);
+  else { r = mk(OP_SLOWFETCH, 0, 0, 0, 0); r.raw = lo; }   // upper half lies outside the decoded range
+  out[i] = r;
+}
+
+__global__ void wsp_decode_words_kernel(const u32* words, u64 n, u32 isa, Rec* out)
+{
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = decode(words[i], isa);
+}
+
+// Copy `n` bytes at arena offset `off` from a linear staging buffer into harts [lo, hi).
+__global__ void wsp_scatter_kernel(DevState d, u32 lo, u32 hi, u64 off, const u8* src, u64 n)
+{
+  u64 w0 = off >> 3, w1 = (off + n + 7) >> 3, nw = w1 - w0;
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 total = nw * (hi - lo);
+  if (i >= total) return;
+  u32 hart = lo + (u32)(i % (hi - lo));            // consecutive threads -> consecutive harts: coalesced stores
+  u64 w = w0 + i / (hi - lo);
+  u64 bo = w << 3;
+  u8* dst = d.arena + arena_off(d, hart, bo);
+  if (bo >= off && bo + 8 <= off + n) { u64 v; memcpy(&v, src + (bo - off), 8); *(u64*)dst = v; return; }
+  for (u32 k = 0; k < 8; ++k) { u64 a = bo + k; if (a >= off && a < off + n) dst[k] = src[a - off]; }
+}
+
+// Gather `n` bytes at arena offset `off` of one hart into a linear buffer.
+__global__ void wsp_gather_kernel(DevState d, u32 hart, u64 off, u8* dst, u64 n)
+{
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = d.arena[arena_off(d, hart, off + i)];
+}
+
+// vals[i] -> x[idx] (res==X) or the dword at arena offset idx (res==MEM) of hart lo+i.
+__global__ void wsp_poke_each_kernel(DevState d, u32 lo, u32 hi, u32 res, u64 idx, const u64* vals)
+{
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lo + i >= hi) return;
+  u32 hart = lo + i;
+  if (res == WSP_RES_X) d.x[(size_t)idx * d.S + slot_of(d, hart)] = vals[i];
+  else *(u64*)(d.arena + arena_off(d, hart, idx)) = vals[i];
+}
+
+// Memory digest: sum over 8-byte words of mix(word ^ GOLDEN*(index+1)).  grid = (chunks, waves),
+// block = 64 lanes; lane l of wave w streams words [c*cw, (c+1)*cw) of hart w*lpw+l: each wave
+// instruction reads lpw*8 contiguous bytes (512 B at 64 lanes per wave).
+__global__ void __launch_bounds__(64) wsp_memhash_kernel(DevState d, u64 words_per_chunk, u64* out /*[S]*/)
+{
+  const u32 lane = threadIdx.x, wave = blockIdx.y;
+  const u32 hart = wave * d.lpw + lane;
+  if (lane >= d.lpw || hart >= d.n_harts) return;
+  const u64 nw = d.mem_size >> 3;
+  u64 k0 = (u64)blockIdx.x * words_per_chunk, k1 = k0 + words_per_chunk;
+  if (k1 > nw) k1 = nw;
+  const u64* base = (const u64*)(d.arena + (size_t)wave * d.lpw * d.mem_size) + lane;
+  u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  u64 k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    u64 w0 = base[(k + 0) << d.lpw_shift], w1 = base[(k + 1) << d.lpw_shift], w2 = base[(k + 2) << d.lpw_shift], w3 = base[(k + 3) << d.lpw_shift];
+    s0 += mix(w0 ^ (GOLDEN * (k + 1))); s1 += mix(w1 ^ (GOLDEN * (k + 2))); s2 += mix(w2 ^ (GOLDEN * (k + 3))); s3 += mix(w3 ^ (GOLDEN * (k + 4)));
+  }
+  for (; k < k1; ++k) s0 += mix(base[k << d.lpw_shift] ^ (GOLDEN * (k + 1)));
+  atomicAdd((unsigned long long*)&out[wave * 64 + lane], (unsigned long long)(s0 + s1 + s2 + s3));
+}
+
+__global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* out)
+{
+  u32 hart = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hart >= d.n_harts) return;
+  const u32 S = d.S, slot = slot_of(d, hart);
+  u64 s = 0;
+  s = fold(s, d.hot64[H64_PC * S + slot]);
+  for (u32 r = 1; r < 32; ++r) s = fold(s, d.x[(size_t)r * S + slot]);
+  for (u32 r = 0; r < 32; ++r) s = fold(s, d.f[(size_t)r * S + slot]);
+  s = fold(s, d.hot32[H32_PRIV * S + slot]);
+  s = fold(s, d.hot32[H32_FCSR * S + slot]);
+  const int c1[] = { CI_STVEC, CI_SCOUNTEREN, CI_SENVCFG, CI_SSCRATCH, CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP };
+  for (int i = 0; i < 8; ++i) s = fold(s, d.cold[(size_t)c1[i] * S + slot]);
+  s = fold(s, d.hot64[H64_MSTATUS * S + slot]);
+  const int c2[] = { CI_MEDELEG, CI_MIDELEG, CI_MIE, CI_MTVEC, CI_MCOUNTEREN, CI_MENVCFG, CI_MCOUNTINHIBIT, CI_MSCRATCH, CI_MEPC, CI_MCAUSE, CI_MTVAL, CI_MIP };
+  for (int i = 0; i < 12; ++i) s = fold(s, d.cold[(size_t)c2[i] * S + slot]);
+  s = fold(s, d.hot64[H64_CYCLE * S + slot]);
+  s = fold(s, d.hot64[H64_INSTRET * S + slot]);
+  s = fold(s, d.hot64[H64_EXEC * S + slot]);          // time CSR == loop iterations (Hart.hpp:3101)
+  wsp_result r;
+  r.status = d.hot32[H32_STATUS * S + slot]; r.priv = d.hot32[H32_PRIV * S + slot];
+  r.stop_value = d.hot64[H64_STOP_VALUE * S + slot]; r.pc = d.hot64[H64_PC * S + slot];
+  r.exec_count = d.hot64[H64_EXEC * S + slot]; r.retired_count = d.hot64[H64_RETIRED * S + slot];
+  r.state_hash = s; r.mem_hash = memhash[slot]; r.trace_hash = d.hot64[H64_THASH * S + slot];
+  out[hart] = r;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPOK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(WSP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* wsp_last_error(void) { return g_err.c_str(); }
+extern "C" const char* wsp_version(void) { return "whisper_amd 0.1 (gfx950)"; }
+
+// Isa::applyIsaString (Isa.cpp:561) for the letters that matter to the hot path.
+static int parse_isa(const char* isa, u32* out, std::string* why)
+{
+  std::string s = isa ? isa : "";
+  for (auto& c : s) c = (char)tolower(c);
+  if (s.rfind("rv64", 0) == 0) s = s.substr(4);
+  else if (s.rfind("rv32", 0) == 0) { if (why) *why = "rv32 is not supported yet"; return WSP_EUNSUPPORTED; }
+  u32 f = 0; size_t us = s.find('_');
+  std::string base = s.substr(0, us);
+  for (char c : base) {
+    switch (c) {
+      case 'i': break;
+      case 'm': f |= ISA_M; break; case 'a': f |= ISA_A; break; case 'f': f |= ISA_F; break; case 'd': f |= ISA_D; break;
+      case 'c': f |= ISA_C; break; case 's': f |= ISA_S; break; case 'u': f |= ISA_U; break;
+      case 'g': f |= ISA_M | ISA_A | ISA_F | ISA_D; break;
+      default: if (why) *why = std::string("ISA letter '") + c + "' is not supported"; return WSP_EUNSUPPORTED;
+    }
+  }
+  while (us != std::string::npos) {
+    size_t nx = s.find('_', us + 1);
+    std::string e = s.substr(us + 1, nx == std::string::npos ? std::string::npos : nx - us - 1);
+    if (e == "zicsr" || e == "zifencei" || e.empty()) {}
+    else if (e == "zicntr") f |= ISA_ZICNTR;
+    else if (e == "zca") f |= ISA_C;
+    else { if (why) *why = "ISA extension '" + e + "' is not supported"; return WSP_EUNSUPPORTED; }
+    us = nx;
+  }
+  if ((f & ISA_D) && !(f & ISA_F)) f &= ~(u32)ISA_D;              // Hart.cpp:585-595
+  if ((f & ISA_S) && !(f & ISA_U)) { if (why) *why = "S without U in the ISA string"; return WSP_EINVAL; }   // Isa.cpp:655-660
+  *out = f;
+  return WSP_OK;
+}
+
+extern "C" uint32_t wsp_isa_flags(const char* isa) { u32 f = 0; std::string w; if (parse_isa(isa, &f, &w) != WSP_OK) { g_err = w; return 0xffffffffu; } return f; }
+
+struct Program {
+  u64 text_lo = 0, text_hi = 0;
+  Rec* d_recs = nullptr;
+  std::map<std::string, u64> symbols;
+};
+
+struct wsp_batch {
+  DevState d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<Program> progs;
+  std::vector<u32> hart_prog;          // host copy, index = hart
+  ProgDev* d_progs = nullptr; size_t d_progs_cap = 0;
+  u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
+  double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
+  bool has_fp = false;
+};
+
+static int upload_progs(wsp_batch* b)
+{
+  std::vector<ProgDev> v(b->progs.size());
+  for (size_t i = 0; i < v.size(); ++i) { v[i].text_lo = b->progs[i].text_lo; v[i].text_hi = b->progs[i].text_hi; v[i].recs = b->progs[i].d_recs; }
+  if (v.size() > b->d_progs_cap) {
+    if (b->d_progs) HIPOK(hipFree(b->d_progs));
+    b->d_progs_cap = std::max<size_t>(16, v.size() * 2);
+    HIPOK(hipMalloc(&b->d_progs, b->d_progs_cap * sizeof(ProgDev)));
+    b->d.progs = b->d_progs;
+  }
+  if (!v.empty()) HIPOK(hipMemcpy(b->d_progs, v.data(), v.size() * sizeof(ProgDev), hipMemcpyHostToDevice));
+  return WSP_OK;
+}
+
+extern "C" void wsp_batch_destroy(wsp_batch* b)
+{
+  if (!b) return;
+  hipSetDevice(b->device);
+  for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results };
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
+{
+  if (!desc || !out) return fail(WSP_EINVAL, "null argument");
+  *out = nullptr;
+  if (desc->xlen != 64) return fail(WSP_EUNSUPPORTED, "only xlen=64 is supported");
+  if (desc->n_harts == 0) return fail(WSP_EINVAL, "n_harts must be > 0");
+  if (desc->mem_size == 0 || (desc->mem_size & 4095)) return fail(WSP_EINVAL, "mem_size must be a non-zero multiple of 4096");
+  if (desc->mem_base + desc->mem_size < desc->mem_base) return fail(WSP_EINVAL, "arena wraps the address space");
+  u32 isa = 0; std::string why;
+  int rc = parse_isa(desc->isa, &isa, &why);
+  if (rc != WSP_OK) return fail(rc, why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device: whisper_amd has no CPU execution path");
+  int dev = desc->device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) return fail(WSP_ENODEV, "device ordinal out of range");
+  HIPOK(hipSetDevice(dev));
+  u32 lpw = desc->lanes_per_wave;
+  if (lpw == 0) {
+    // Small batches are latency bound per wave: spread harts over more waves (fewer lanes each)
+    // until there is at least one wave per SIMD (256 CUs x 4 SIMDs).
+    lpw = 64;
+    while (lpw > 8 && (desc->n_harts + lpw - 1) / lpw < 1024) lpw >>= 1;
+  }
+  if (lpw != 8 && lpw != 16 && lpw != 32 && lpw != 64) return fail(WSP_EINVAL, "lanes_per_wave must be 0, 8, 16, 32 or 64");
+  wsp_batch* b = new wsp_batch();
+  b->device = dev;
+  DevState& d = b->d;
+  d.n_harts = desc->n_harts; d.lpw = lpw; d.lpw_shift = (u32)__builtin_ctz(lpw);
+  d.n_waves = (desc->n_harts + lpw - 1) / lpw; d.S = d.n_waves * 64; d.isa = isa; d.hart_id_base = desc->hart_id_base;
+  d.mem_base = desc->mem_base; d.mem_size = desc->mem_size;
+  b->has_fp = (isa & ISA_F) != 0;
+  size_t S = d.S, arena_bytes = (size_t)d.n_waves * lpw * d.mem_size;
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if (arena_bytes + S * 1024 > free_b) { delete b; return fail(WSP_ENOMEM, "batch does not fit device memory"); }
+#define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m_ = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); wsp_batch_destroy(b); return fail(WSP_ENOMEM, m_); } \
+    e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
+  ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
+  ALLOC(d.cold, CI_COUNT * S * 8); ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
+  ALLOC(d.arena, arena_bytes); ALLOC(d.running, 4); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
+#undef ALLOC
+  // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
+  std::vector<u64> v64(S);
+  std::fill(v64.begin(), v64.end(), d.mem_base);      hipMemcpy(d.hot64 + (size_t)H64_PC * S, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::fill(v64.begin(), v64.end(), MSTATUS_RESET);   hipMemcpy(d.hot64 + (size_t)H64_MSTATUS * S, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::fill(v64.begin(), v64.end(), ~0ULL);           hipMemcpy(d.tohost, v64.data(), S * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d.max_exec, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::vector<u32> v32(S, (u32)PRV_M);                hipMemcpy(d.hot32 + (size_t)H32_PRIV * S, v32.data(), S * 4, hipMemcpyHostToDevice);
+  std::fill(v32.begin(), v32.end(), ~0u);             hipMemcpy(d.prog, v32.data(), S * 4, hipMemcpyHostToDevice);
+  b->hart_prog.assign(d.n_harts, ~0u);
+  if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
+    wsp_batch_destroy(b); return fail(WSP_EHIP, "stream/event creation failed");
+  }
+  *out = b;
+  return WSP_OK;
+}
+
+static int check_range(wsp_batch* b, u32 lo, u32 hi)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  if (lo >= hi || hi > b->d.n_harts) return fail(WSP_ERANGE, "hart range out of bounds");
+  return WSP_OK;
+}
+
+static int write_arena(wsp_batch* b, u32 lo, u32 hi, u64 addr, const void* bytes, size_t n)
+{
+  DevState& d = b->d;
+  if (n == 0) return WSP_OK;
+  if (addr < d.mem_base || addr - d.mem_base > d.mem_size - n || n > d.mem_size) return fail(WSP_ERANGE, "image outside the hart arena");
+  u8* stage = nullptr;
+  HIPOK(hipMalloc(&stage, n));
+  HIPOK(hipMemcpy(stage, bytes, n, hipMemcpyHostToDevice));
+  u64 off = addr - d.mem_base, nw = ((off + n + 7) >> 3) - (off >> 3), total = nw * (hi - lo);
+  hipLaunchKernelGGL(wsp_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, off, stage, (u64)n);
+  HIPOK(hipGetLastError());
+  HIPOK(hipStreamSynchronize(b->stream));
+  HIPOK(hipFree(stage));
+  return WSP_OK;
+}
+
+static int set_u32_range(wsp_batch* b, u32* base, u32 lo, u32 hi, u32 val, u32 or_mask = 0, bool do_or = false)
+{
+  // per-hart scalars are few: update through the host (setup path, not timed)
+  DevState& d = b->d;
+  for (u32 h = lo; h < hi; ++h) {
+    u32 s = slot_of(d, h), v = val;
+    if (do_or) { HIPOK(hipMemcpy(&v, base + s, 4, hipMemcpyDeviceToHost)); v |= or_mask; }
+    HIPOK(hipMemcpy(base + s, &v, 4, hipMemcpyHostToDevice));
+  }
+  return WSP_OK;
+}
+
+static int set_u64_slots(wsp_batch* b, u64* base, u32 lo, u32 hi, u64 val)
+{
+  DevState& d = b->d;
+  // contiguous runs of slots inside a wave
+  u32 h = lo;
+  std::vector<u64> buf(64, val);
+  while (h < hi) {
+    u32 w = h >> d.lpw_shift, l = h & (d.lpw - 1);
+    u32 cnt = std::min(hi - h, d.lpw - l);
+    HIPOK(hipMemcpy(base + (size_t)w * 64 + l, buf.data(), (size_t)cnt * 8, hipMemcpyHostToDevice));
+    h += cnt;
+  }
+  return WSP_OK;
+}
+
+static int set_u32_slots(wsp_batch* b, u32* base, u32 lo, u32 hi, u32 val)
+{
+  DevState& d = b->d;
+  u32 h = lo;
+  std::vector<u32> buf(64, val);
+  while (h < hi) {
+    u32 w = h >> d.lpw_shift, l = h & (d.lpw - 1);
+    u32 cnt = std::min(hi - h, d.lpw - l);
+    HIPOK(hipMemcpy(base + (size_t)w * 64 + l, buf.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+    h += cnt;
+  }
+  return WSP_OK;
+}
+
+// Register a code region: upload, pre-decode on the device, bind to harts [lo, hi).
+static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vector<u8>& text, const std::map<std::string, u64>& syms)
+{
+  DevState& d = b->d;
+  Program p; p.symbols = syms;
+  if (!text.empty()) {
+    p.text_lo = text_lo; p.text_hi = text_lo + (text.size() & ~(size_t)1);
+    u64 nslots = (p.text_hi - p.text_lo) / 2;
+    u8* dimg = nullptr;
+    HIPOK(hipMalloc(&dimg, text.size()));
+    HIPOK(hipMemcpy(dimg, text.data(), text.size(), hipMemcpyHostToDevice));
+    HIPOK(hipMalloc(&p.d_recs, nslots * sizeof(Rec)));
+    hipLaunchKernelGGL(wsp_predecode_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, b->stream, dimg, (u64)(p.text_hi - p.text_lo), d.isa, p.d_recs);
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(b->stream));
+    HIPOK(hipFree(dimg));
+  }
+  b->progs.push_back(p);
+  u32 id = (u32)b->progs.size() - 1;
+  int rc = upload_progs(b); if (rc) return rc;
+  rc = set_u32_slots(b, d.prog, lo, hi, id); if (rc) return rc;
+  for (u32 h = lo; h < hi; ++h) b->hart_prog[h] = id;
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_load_image(wsp_batch* b, uint32_t lo, uint32_t hi, uint64_t addr, const void* bytes, size_t n, uint32_t flags)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  if (!bytes && n) return fail(WSP_EINVAL, "null image");
+  HIPOK(hipSetDevice(b->device));
+  rc = write_arena(b, lo, hi, addr, bytes, n); if (rc) return rc;
+  if (flags & WSP_LOAD_EXEC) {
+    if (addr & 1) return fail(WSP_EINVAL, "code must be 2-byte aligned");
+    std::vector<u8> t((const u8*)bytes, (const u8*)bytes + n);
+    return add_program(b, lo, hi, addr, t, {});
+  }
+  // data written over a pre-decoded region: those harts must decode from RAM from now on
+  for (u32 h = lo; h < hi; ++h) {
+    u32 pg = b->hart_prog[h];
+    if (pg != ~0u && addr + n > b->progs[pg].text_lo && addr < b->progs[pg].text_hi) {
+      rc = set_u32_range(b, b->d.hot32 + (size_t)H32_FLAGS * b->d.S, h, h + 1, 0, HF_CODE_DIRTY, true); if (rc) return rc;
+    }
+  }
+  return WSP_OK;
+}
+
+// ---- ELF64 little-endian reader (stands in for ELFIO use in Memory::loadElfFile, Memory.cpp:687)
+struct Elf64_Ehdr_ { u8 ident[16]; u16 type, machine; u32 version; u64 entry, phoff, shoff; u32 flags; u16 ehsize, phentsize, phnum, shentsize, shnum, shstrndx; };
+struct Elf64_Phdr_ { u32 type, flags; u64 offset, vaddr, paddr, filesz, memsz, align; };
+struct Elf64_Shdr_ { u32 name, type; u64 flags, addr, offset, size; u32 link, info; u64 addralign, entsize; };
+struct Elf64_Sym_ { u32 name; u8 info, other; u16 shndx; u64 value, size; };
+
+extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, const void* elf, size_t n)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  HIPOK(hipSetDevice(b->device));
+  const u8* e = (const u8*)elf;
+  if (!e || n < sizeof(Elf64_Ehdr_) || memcmp(e, "\177ELF", 4) != 0) return fail(WSP_EFORMAT, "not an ELF file");
+  if (e[4] != 2) return fail(WSP_EFORMAT, "ELF class is not 64-bit");        // Session.cpp:1373-1424 xlen from ELF class
+  if (e[5] != 1) return fail(WSP_EFORMAT, "ELF is not little-endian");
+  Elf64_Ehdr_ eh; memcpy(&eh, e, sizeof eh);
+  if (eh.phoff + (u64)eh.phnum * sizeof(Elf64_Phdr_) > n) return fail(WSP_EFORMAT, "program headers out of file");
+  DevState& d = b->d;
+  u64 xlo = ~0ULL, xhi = 0;
+  std::vector<Elf64_Phdr_> loads;
+  for (u32 i = 0; i < eh.phnum; ++i) {
+    Elf64_Phdr_ ph; memcpy(&ph, e + eh.phoff + (u64)i * eh.phentsize, sizeof ph);
+    if (ph.type != 1 || ph.filesz == 0) continue;                            // PT_LOAD, p_filesz bytes only (Memory.cpp:450-489)
+    if (ph.offset + ph.filesz > n) return fail(WSP_EFORMAT, "segment out of file");
+    if (ph.paddr < d.mem_base || ph.paddr - d.mem_base > d.mem_size - ph.filesz || ph.filesz > d.mem_size)
+      return fail(WSP_ERANGE, "ELF segment outside the hart arena");
+    loads.push_back(ph);
+    if (ph.flags & 1) { xlo = std::min(xlo, ph.paddr); xhi = std::max(xhi, ph.paddr + ph.filesz); }
+  }
+  for (auto& ph : loads) { rc = write_arena(b, lo, hi, ph.paddr, e + ph.offset, ph.filesz); if (rc) return rc; }
+  // symbols + .tdata
+  std::map<std::string, u64> syms; u64 tdata = 0;
+  if (eh.shoff && eh.shoff + (u64)eh.shnum * sizeof(Elf64_Shdr_) <= n) {
+    std::vector<Elf64_Shdr_> sh(eh.shnum);
+    for (u32 i = 0; i < eh.shnum; ++i) memcpy(&sh[i], e + eh.shoff + (u64)i * eh.shentsize, sizeof(Elf64_Shdr_));
+    const char* shstr = (eh.shstrndx < eh.shnum && sh[eh.shstrndx].offset < n) ? (const char*)e + sh[eh.shstrndx].offset : nullptr;
+    for (u32 i = 0; i < eh.shnum; ++i) {
+      if (shstr && sh[i].name < sh[eh.shstrndx].size && strcmp(shstr + sh[i].name, ".tdata") == 0) tdata = sh[i].addr;
+      if (sh[i].type != 2 || sh[i].link >= eh.shnum || sh[i].offset + sh[i].size > n) continue;   // SHT_SYMTAB
+      const Elf64_Shdr_& st = sh[sh[i].link];
+      if (st.offset + st.size > n) continue;
+      size_t cnt = sh[i].size / sizeof(Elf64_Sym_);
+      for (size_t k = 0; k < cnt; ++k) {
+        Elf64_Sym_ sy; memcpy(&sy, e + sh[i].offset + k * sizeof(Elf64_Sym_), sizeof sy);
+        if (sy.name >= st.size) continue;
+        const char* nm = (const char*)e + st.offset + sy.name;
+        if (*nm) syms[nm] = sy.value;
+      }
+    }
+  }
+  std::vector<u8> text;
+  if (xlo < xhi) {
+    if (xhi - xlo > (64u << 20)) return fail(WSP_EUNSUPPORTED, "executable span larger than 64 MiB");
+    text.assign(xhi - xlo, 0);
+    for (auto& ph : loads) if (ph.flags & 1) memcpy(text.data() + (ph.paddr - xlo), e + ph.offset, ph.filesz);
+  }
+  rc = add_program(b, lo, hi, xlo < xhi ? xlo : 0, text, syms); if (rc) return rc;
+  // pc = entry, gp, tp (System.cpp:334-354); tohost (System.cpp:323)
+  if (eh.entry) { rc = set_u64_slots(b, d.hot64 + (size_t)H64_PC * d.S, lo, hi, eh.entry & ~1ULL); if (rc) return rc; }
+  auto gp = syms.find("__global_pointer$");
+  for (u32 h = lo; h < hi; ++h) {
+    u64 cur = 0; u32 s = slot_of(d, h);
+    if (gp != syms.end() && gp->second) { HIPOK(hipMemcpy(&cur, d.x + (size_t)3 * d.S + s, 8, hipMemcpyDeviceToHost)); if (!cur) HIPOK(hipMemcpy(d.x + (size_t)3 * d.S + s, &gp->second, 8, hipMemcpyHostToDevice)); }
+    if (tdata) { HIPOK(hipMemcpy(&cur, d.x + (size_t)4 * d.S + s, 8, hipMemcpyDeviceToHost)); if (!cur) HIPOK(hipMemcpy(d.x + (size_t)4 * d.S + s, &tdata, 8, hipMemcpyHostToDevice)); }
+    if (gp == syms.end() && !tdata) break;
+  }
+  auto th = syms.find("tohost");
+  if (th != syms.end()) { rc = set_u64_slots(b, d.tohost, lo, hi, th->second); if (rc) return rc; }
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_load_elf(wsp_batch* b, uint32_t lo, uint32_t hi, const char* path)
+{
+  if (!path) return fail(WSP_EINVAL, "null path");
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(WSP_EIO, std::string("cannot open ") + path);
+  std::vector<u8> buf; u8 tmp[65536]; size_t k;
+  while ((k = fread(tmp, 1, sizeof tmp, fp)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+  fclose(fp);
+  return wsp_batch_load_elf_mem(b, lo, hi, buf.data(), buf.size());
+}
+
+extern "C" int wsp_batch_symbol(wsp_batch* b, uint32_t hart, const char* name, uint64_t* addr)
+{
+  int rc = check_range(b, hart, hart + 1); if (rc) return rc;
+  u32 pg = b->hart_prog[hart];
+  if (pg == ~0u) return fail(WSP_EINVAL, "no ELF loaded for this hart");
+  auto it = b->progs[pg].symbols.find(name ? name : "");
+  if (it == b->progs[pg].symbols.end()) return fail(WSP_EINVAL, std::string("symbol not found: ") + (name ? name : ""));
+  *addr = it->second;
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_set_stop(wsp_batch* b, uint32_t lo, uint32_t hi, uint64_t tohost, uint64_t max_inst)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  HIPOK(hipSetDevice(b->device));
+  if (tohost != ~0ULL) { rc = set_u64_slots(b, b->d.tohost, lo, hi, tohost); if (rc) return rc; }
+  return set_u64_slots(b, b->d.max_exec, lo, hi, max_inst);
+}
+
+// location of a modelled CSR in device state: returns 0 hot64, 1 hot32, 2 cold, -1 none
+static int csr_loc(u32 num, u32* ix)
+{
+  switch (num) {
+    case C_FCSR: *ix = H32_FCSR; return 1;
+    case C_MSTATUS: *ix = H64_MSTATUS; return 0;
+    case C_MCYCLE: *ix = H64_CYCLE; return 0; case C_MINSTRET: *ix = H64_INSTRET; return 0;
+    case C_MEDELEG: *ix = CI_MEDELEG; return 2; case C_MIDELEG: *ix = CI_MIDELEG; return 2; case C_MIE: *ix = CI_MIE; return 2;
+    case C_MIP: *ix = CI_MIP; return 2; case C_MTVEC: *ix = CI_MTVEC; return 2; case C_MCOUNTEREN: *ix = CI_MCOUNTEREN; return 2;
+    case C_MENVCFG: *ix = CI_MENVCFG; return 2; case C_MCOUNTINHIBIT: *ix = CI_MCOUNTINHIBIT; return 2; case C_MSCRATCH: *ix = CI_MSCRATCH; return 2;
+    case C_MEPC: *ix = CI_MEPC; return 2; case C_MCAUSE: *ix = CI_MCAUSE; return 2; case C_MTVAL: *ix = CI_MTVAL; return 2;
+    case C_STVEC: *ix = CI_STVEC; return 2; case C_SCOUNTEREN: *ix = CI_SCOUNTEREN; return 2; case C_SENVCFG: *ix = CI_SENVCFG; return 2;
+    case C_SSCRATCH: *ix = CI_SSCRATCH; return 2; case C_SEPC: *ix = CI_SEPC; return 2; case C_SCAUSE: *ix = CI_SCAUSE; return 2;
+    case C_STVAL: *ix = CI_STVAL; return 2; case C_SATP: *ix = CI_SATP; return 2;
+    default: return -1;
+  }
+}
+
+extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_t idx, void* val, size_t size)
+{
+  int rc = check_range(b, hart, hart + 1); if (rc) return rc;
+  if (!val) return fail(WSP_EINVAL, "null value");
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d; u32 s = slot_of(d, hart); size_t S = d.S;
+  u64 v = 0;
+  switch (res) {
+    case WSP_RES_PC: HIPOK(hipMemcpy(&v, d.hot64 + H64_PC * S + s, 8, hipMemcpyDeviceToHost)); break;
+    case WSP_RES_X: if (idx > 31) return fail(WSP_ERANGE, "x register"); HIPOK(hipMemcpy(&v, d.x + idx * S + s, 8, hipMemcpyDeviceToHost)); break;
+    case WSP_RES_F: if (idx > 31) return fail(WSP_ERANGE, "f register"); HIPOK(hipMemcpy(&v, d.f + idx * S + s, 8, hipMemcpyDeviceToHost)); break;
+    case WSP_RES_CSR: {
+      u32 ix; u32 n = (u32)idx;
+      if (n == C_FFLAGS || n == C_FRM) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + H32_FCSR * S + s, 4, hipMemcpyDeviceToHost)); v = n == C_FFLAGS ? (f & 0x1f) : ((f >> 5) & 7); break; }
+      if (n == C_MISA) { v = MISA_RESET; break; }
+      if (n == C_MHARTID) { v = d.hart_id_base + hart; break; }
+      if (n == C_SSTATUS) { HIPOK(hipMemcpy(&v, d.hot64 + H64_MSTATUS * S + s, 8, hipMemcpyDeviceToHost)); v &= SSTATUS_RMASK; break; }
+      int loc = csr_loc(n, &ix);
+      if (loc == 0) HIPOK(hipMemcpy(&v, d.hot64 + ix * S + s, 8, hipMemcpyDeviceToHost));
+      else if (loc == 1) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + ix * S + s, 4, hipMemcpyDeviceToHost)); v = f; }
+      else if (loc == 2) HIPOK(hipMemcpy(&v, d.cold + ix * S + s, 8, hipMemcpyDeviceToHost));
+      else return fail(WSP_EUNSUPPORTED, "CSR not modelled");
+      break; }
+    case WSP_RES_MEM: {
+      if (idx < d.mem_base || idx - d.mem_base > d.mem_size - size || size > d.mem_size) return fail(WSP_ERANGE, "memory peek outside arena");
+      u8* tmp = nullptr; HIPOK(hipMalloc(&tmp, size));
+      hipLaunchKernelGGL(wsp_gather_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, b->stream, d, hart, idx - d.mem_base, tmp, (u64)size);
+      HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream));
+      HIPOK(hipMemcpy(val, tmp, size, hipMemcpyDeviceToHost)); HIPOK(hipFree(tmp));
+      return WSP_OK; }
+    default: return fail(WSP_EINVAL, "unknown resource");
+  }
+  memcpy(val, &v, std::min<size_t>(size, 8));
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_t idx, const void* val, size_t size)
+{
+  int rc = check_range(b, hart, hart + 1); if (rc) return rc;
+  if (!val) return fail(WSP_EINVAL, "null value");
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d; u32 s = slot_of(d, hart); size_t S = d.S;
+  u64 v = 0; memcpy(&v, val, std::min<size_t>(size, 8));
+  switch (res) {
+    case WSP_RES_PC: v &= ~1ULL; HIPOK(hipMemcpy(d.hot64 + H64_PC * S + s, &v, 8, hipMemcpyHostToDevice)); break;
+    case WSP_RES_X: if (idx > 31) return fail(WSP_ERANGE, "x register"); if (idx) HIPOK(hipMemcpy(d.x + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
+    case WSP_RES_F: if (idx > 31) return fail(WSP_ERANGE, "f register"); HIPOK(hipMemcpy(d.f + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
+    case WSP_RES_CSR: {
+      u32 ix; u32 n = (u32)idx; int loc = csr_loc(n, &ix);
+      if (n == C_MSTATUS) v = (MSTATUS_RESET & ~MSTATUS_WMASK) | (v & (MSTATUS_WMASK | MST_SD));
+      if (loc == 0) HIPOK(hipMemcpy(d.hot64 + ix * S + s, &v, 8, hipMemcpyHostToDevice));
+      else if (loc == 1) { u32 f = (u32)v & 0xff; HIPOK(hipMemcpy(d.hot32 + ix * S + s, &f, 4, hipMemcpyHostToDevice)); }
+      else if (loc == 2) {
+        HIPOK(hipMemcpy(d.cold + ix * S + s, &v, 8, hipMemcpyHostToDevice));
+        if (n == C_MCOUNTINHIBIT) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + H32_FLAGS * S + s, 4, hipMemcpyDeviceToHost)); f = (f & ~(HF_INH_CY | HF_INH_IR)) | ((v & 1) ? (u32)HF_INH_CY : 0) | ((v & 4) ? (u32)HF_INH_IR : 0); HIPOK(hipMemcpy(d.hot32 + H32_FLAGS * S + s, &f, 4, hipMemcpyHostToDevice)); }
+      } else return fail(WSP_EUNSUPPORTED, "CSR not modelled");
+      break; }
+    case WSP_RES_MEM: return wsp_batch_load_image(b, hart, hart + 1, idx, val, size, 0);
+    default: return fail(WSP_EINVAL, "unknown resource");
+  }
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_poke_each(wsp_batch* b, uint32_t lo, uint32_t hi, uint32_t res, uint64_t idx, const uint64_t* vals)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  if (!vals) return fail(WSP_EINVAL, "null values");
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d;
+  u64 key = idx;
+  if (res == WSP_RES_X) { if (idx == 0 || idx > 31) return fail(WSP_ERANGE, "x register"); }
+  else if (res == WSP_RES_MEM) {
+    if ((idx & 7) || idx < d.mem_base || idx - d.mem_base > d.mem_size - 8) return fail(WSP_ERANGE, "memory dword outside arena or unaligned");
+    key = idx - d.mem_base;
+  } else return fail(WSP_EINVAL, "poke_each supports X and MEM");
+  u64* dv = nullptr; size_t n = hi - lo;
+  HIPOK(hipMalloc(&dv, n * 8)); HIPOK(hipMemcpy(dv, vals, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(wsp_poke_each_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, res, key, dv);
+  HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream)); HIPOK(hipFree(dv));
+  return WSP_OK;
+}
+
+template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 steps)
+{
+  DevState& d = b->d;
+  size_t lds = (size_t)d.lpw * 32 * 8 * (FP ? 2 : 1);
+  hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, steps);
+  return hipGetLastError();
+}
+
+extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flags)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  HIPOK(hipSetDevice(b->device));
+  const u64 SLICE = 1ULL << 24;
+  u64 remaining = max_steps; u32 running = 0;
+  b->last_kernel_s = 0; b->last_launches = 0;
+  bool trace = (flags & WSP_RUN_TRACE_HASH) != 0;
+  do {
+    u64 n = std::min(remaining, SLICE);
+    HIPOK(hipMemsetAsync(b->d.running, 0, 4, b->stream));
+    HIPOK(hipEventRecord(b->ev0, b->stream));
+    hipError_t e = trace ? (b->has_fp ? launch_step<true, true>(b, n) : launch_step<true, false>(b, n))
+                         : (b->has_fp ? launch_step<false, true>(b, n) : launch_step<false, false>(b, n));
+    if (e != hipSuccess) return fail(WSP_EHIP, std::string("step kernel launch: ") + hipGetErrorString(e));
+    HIPOK(hipEventRecord(b->ev1, b->stream));
+    HIPOK(hipMemcpyAsync(&running, b->d.running, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPOK(hipStreamSynchronize(b->stream));
+    float ms = 0; HIPOK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->last_kernel_s += ms * 1e-3; b->last_launches++;
+    remaining -= n;
+  } while (running && remaining);
+  return (int64_t)running;
+}
+
+extern "C" int wsp_batch_last_run_stats(wsp_batch* b, double* s, uint32_t* launches)
+{ if (!b) return fail(WSP_EINVAL, "null batch"); if (s) *s = b->last_kernel_s; if (launches) *launches = b->last_launches; return WSP_OK; }
+
+extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
+{
+  if (!b || !out) return fail(WSP_EINVAL, "null argument");
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d;
+  HIPOK(hipMemsetAsync(b->d_memhash, 0, (size_t)d.S * 8, b->stream));
+  u64 nw = d.mem_size >> 3;
+  // enough chunks that the grid has >= ~8 waves per CU even for small batches
+  u64 chunks = 1;
+  while (chunks * d.n_waves < 4096 && chunks * 2 <= nw / 64) chunks *= 2;
+  u64 wpc = (nw + chunks - 1) / chunks;
+  HIPOK(hipEventRecord(b->ev0, b->stream));
+  hipLaunchKernelGGL(wsp_memhash_kernel, dim3((unsigned)chunks, d.n_waves), dim3(64), 0, b->stream, d, wpc, b->d_memhash);
+  HIPOK(hipGetLastError());
+  HIPOK(hipEventRecord(b->ev1, b->stream));
+  hipLaunchKernelGGL(wsp_results_kernel, dim3((d.n_harts + 127) / 128), dim3(128), 0, b->stream, d, b->d_memhash, b->d_results);
+  HIPOK(hipGetLastError());
+  HIPOK(hipMemcpyAsync(out, b->d_results, (size_t)d.n_harts * sizeof(wsp_result), hipMemcpyDeviceToHost, b->stream));
+  HIPOK(hipStreamSynchronize(b->stream));
+  float ms = 0; HIPOK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+  b->last_hash_s = ms * 1e-3; b->last_hash_bytes = (u64)d.n_harts * d.mem_size;
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_last_hash_stats(wsp_batch* b, double* s, uint64_t* bytes)
+{ if (!b) return fail(WSP_EINVAL, "null batch"); if (s) *s = b->last_hash_s; if (bytes) *bytes = b->last_hash_bytes; return WSP_OK; }
+
+extern "C" int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap)
+{
+  u64 lo = 0, hi = 0;
+  int rc = wsp_batch_symbol(b, hart, "begin_signature", &lo); if (rc) return rc;
+  rc = wsp_batch_symbol(b, hart, "end_signature", &hi); if (rc) return rc;
+  if (hi < lo || ((hi - lo) & 3)) return fail(WSP_EFORMAT, "bad signature bounds");
+  size_t n = (hi - lo) / 4;
+  if (n > cap) return fail(WSP_ERANGE, "signature buffer too small");
+  if (n) { rc = wsp_batch_peek(b, hart, WSP_RES_MEM, lo, words, n * 4); if (rc) return rc; }
+  return (int64_t)n;
+}
+
+extern "C" int wsp_decode_words_host(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out)
+{
+  u32 f; std::string why; int rc = parse_isa(isa, &f, &why); if (rc) return fail(rc, why);
+  for (size_t i = 0; i < n; ++i) { Rec r = decode(words[i], f); out[i].w0 = r.w0; out[i].imm = r.imm; out[i].raw = r.raw; out[i].pad = 0; }
+  return WSP_OK;
+}
+
+extern "C" int wsp_decode_words(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out)
+{
+  u32 f; std::string why; int rc = parse_isa(isa, &f, &why); if (rc) return fail(rc, why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device");
+  if (n == 0) return WSP_OK;
+  u32* dw = nullptr; Rec* dr = nullptr;
+  HIPOK(hipMalloc(&dw, n * 4)); HIPOK(hipMalloc(&dr, n * sizeof(Rec)));
+  HIPOK(hipMemcpy(dw, words, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(wsp_decode_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dw, (u64)n, f, dr);
+  HIPOK(hipGetLastError()); HIPOK(hipDeviceSynchronize());
+  HIPOK(hipMemcpy(out, dr, n * sizeof(Rec), hipMemcpyDeviceToHost));
+  HIPOK(hipFree(dw)); HIPOK(hipFree(dr));
+  return WSP_OK;
+}

@@ -1,0 +1,563 @@
+"""Seeded synthetic workloads for the BASELINE.json configs.
+
+No RISC-V toolchain or riscv-arch-test checkout exists offline, so every program is generated
+here with rvasm.Asm and wrapped into an ELF (elfio.write_elf).  The same bytes are fed to the
+oracle and to the device.
+  readme_program()      config 0: README-style tohost program (compressed forms)
+  archtest_suite()      config 1: arch-test style I/M/C signature tests, one program per mnemonic
+  compute_kernel()      config 2: CoreMark-style RV64IMAFD kernel, per-instance seed in a0
+  fuzz_program()        random legal/illegal instruction mix with a skipping trap handler (M-mode)
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+
+from .elfio import PF_R, PF_W, PF_X, write_elf
+from .rvasm import CSR, Asm
+
+MASK64 = (1 << 64) - 1
+BASE = 0x80000000
+
+
+@dataclass
+class Program:
+    name: str
+    isa: str
+    elf: bytes
+    entry: int
+    segments: list          # [(paddr, bytes, flags)]
+    symbols: dict
+    mem_base: int = BASE
+    mem_size: int = 1 << 16
+    max_inst: int = 1 << 22
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def tohost(self):
+        return self.symbols.get("tohost")
+
+
+def _finish(a: Asm, name, isa, data: Asm | None = None, mem_size=1 << 16, max_inst=1 << 22, extra_syms=None, meta=None):
+    text = a.assemble()
+    segs = [(a.base, text, PF_R | PF_X)]
+    syms = dict(a.symbols)
+    if data is not None:
+        segs.append((data.base, data.assemble(), PF_R | PF_W))
+        syms.update(data.symbols)
+    if extra_syms:
+        syms.update(extra_syms)
+    entry = syms.get("_start", a.base)
+    elf = write_elf(segs, entry, syms)
+    return Program(name, isa, elf, entry, segs, syms, BASE, mem_size, max_inst, meta or {})
+
+
+def _exit_tohost(a: Asm, tohost_addr, value=1, tmp1=5, tmp2=6):
+    a.li(tmp1, value)
+    a.li(tmp2, tohost_addr)
+    a.sd(tmp1, 0, tmp2)
+    a.jal(0, a.pc)   # j . (never reached after the stop)
+
+
+# ------------------------------------------------------------------------------------------ config 0
+def readme_program() -> Program:
+    """README.md:167-185 style: x=1; y=2; z=x+y; write 1 to tohost (RV64 rendition, c.* forms)."""
+    data_base = BASE + 0x1000
+    a = Asm(BASE)
+    a.label("_start")
+    a.c_li(10, 1)
+    a.c_li(11, 2)
+    a.c_add(10, 11)
+    a.li(5, data_base)
+    a.c_li(6, 1)
+    a.sd(6, 0, 5)
+    a.jal(0, a.pc)
+    d = Asm(data_base)
+    d.label("tohost")
+    d.dword(0)
+    d.label("fromhost")
+    d.dword(0)
+    return _finish(a, "readme", "rv64imc_zicsr", d, mem_size=1 << 14, max_inst=1000)
+
+
+# ------------------------------------------------------------------------------------------ config 1
+_CORNERS = [0, 1, 2, MASK64, MASK64 - 1, 1 << 63, (1 << 63) - 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x100000000,
+            0x5555555555555555, 0xAAAAAAAAAAAAAAAA, 0x0123456789ABCDEF, 63, 64, 31, 32]
+
+
+def _fnv(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for ch in s.encode():
+        h = ((h ^ ch) * 0x100000001B3) & MASK64
+    return h
+
+
+def _archtest_operands(mn: str, n_rand=6):
+    rng = random.Random(_fnv(mn))
+    ops = [(x, y) for x in _CORNERS[:10] for y in _CORNERS[:10]]
+    for i in range(64):
+        ops.append((1 << i, rng.getrandbits(64)))
+    for _ in range(n_rand * 8):
+        ops.append((rng.getrandbits(64), rng.getrandbits(64)))
+    return ops
+
+
+_RR = ["add", "sub", "sll", "slt", "sltu", "xor", "srl", "sra", "or_", "and_", "addw", "subw", "sllw", "srlw", "sraw",
+       "mul", "mulh", "mulhsu", "mulhu", "div", "divu", "rem", "remu", "mulw", "divw", "divuw", "remw", "remuw"]
+_RI = ["addi", "slti", "sltiu", "xori", "ori", "andi", "addiw"]
+_SH = [("slli", 64), ("srli", 64), ("srai", 64), ("slliw", 32), ("srliw", 32), ("sraiw", 32)]
+_BR = ["beq", "bne", "blt", "bge", "bltu", "bgeu"]
+_LD = [("lb", 1), ("lh", 2), ("lw", 4), ("ld", 8), ("lbu", 1), ("lhu", 2), ("lwu", 4)]
+_ST = [("sb", 1), ("sh", 2), ("sw", 4), ("sd", 8)]
+_CRR = ["c_sub", "c_xor", "c_or", "c_and", "c_subw", "c_addw", "c_mv", "c_add"]
+
+
+def archtest_program(mn: str) -> Program:
+    """One arch-test style program: exercise `mn` over corner + seeded random operands, store every
+    result into begin_signature..end_signature (model_test.h:33-41 conventions), then halt through
+    tohost (RVMODEL_HALT, model_test.h:23-27)."""
+    data_base = BASE + 0x4000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("scratch")
+    pat = bytes((i * 37 + 11) & 0xFF for i in range(256))
+    d.data(pat)
+    d.align_data(16)
+    d.label("begin_signature")
+    sig_words = 0
+    a.label("_start")
+    SIG, T0, T1, T2 = 31, 5, 6, 7
+    sig_cap = 0x2000
+    a.li(SIG, data_base + 0x200)      # patched below once begin_signature is known: same address by construction
+    rng = random.Random(_fnv(mn) ^ 0x5EED)
+
+    def emit_store(reg):
+        nonlocal sig_words
+        a.sd(reg, 0, SIG)
+        a.addi(SIG, SIG, 8)
+        sig_words += 2
+
+    if mn in _RR:
+        for x, y in _archtest_operands(mn):
+            a.li(T0, x); a.li(T1, y)
+            getattr(a, mn)(T2, T0, T1)
+            emit_store(T2)
+    elif mn in _RI:
+        for x, _ in _archtest_operands(mn)[:120]:
+            a.li(T0, x)
+            getattr(a, mn)(T2, T0, rng.randint(-2048, 2047))
+            emit_store(T2)
+    elif mn in dict(_SH):
+        lim = dict(_SH)[mn]
+        for x, _ in _archtest_operands(mn)[:120]:
+            a.li(T0, x)
+            getattr(a, mn)(T2, T0, rng.randrange(lim))
+            emit_store(T2)
+    elif mn in _BR:
+        for i, (x, y) in enumerate(_archtest_operands(mn)[:120]):
+            a.li(T0, x); a.li(T1, y); a.li(T2, 0)
+            lbl = f"bt{i}"
+            getattr(a, mn)(T0, T1, lbl)
+            a.li(T2, 1)
+            a.label(lbl)
+            emit_store(T2)
+    elif mn in dict(_LD):
+        sz = dict(_LD)[mn]
+        a.li(T0, data_base + 0x10 + 64)
+        for i in range(96):
+            off = rng.randrange(-64, 128)
+            if i % 3:
+                off -= off % sz        # mostly aligned, some misaligned
+            getattr(a, mn)(T2, off, T0)
+            emit_store(T2)
+    elif mn in dict(_ST):
+        sz = dict(_ST)[mn]
+        a.li(T0, data_base + 0x10 + 64)
+        for i in range(64):
+            off = rng.randrange(-64, 120)
+            if i % 3:
+                off -= off % sz
+            a.li(T1, rng.getrandbits(64))
+            getattr(a, mn)(T1, off, T0)
+            a.ld(T2, (off // 8) * 8, T0)
+            emit_store(T2)
+            a.ld(T2, (off // 8) * 8 + 8, T0)
+            emit_store(T2)
+    elif mn in ("lui", "auipc"):
+        for i in range(64):
+            getattr(a, mn)(T2, rng.getrandbits(20))
+            if mn == "auipc":
+                a.auipc(T1, 0); a.sub(T2, T2, T1)
+            emit_store(T2)
+    elif mn in ("jal", "jalr"):
+        for i in range(32):
+            lbl = f"jt{i}"
+            if mn == "jal":
+                a.jal(T2, lbl)
+            else:
+                a.la(T0, lbl); a.jalr(T2, T0, 0)
+            a.li(T2, 0xBAD)
+            a.label(lbl)
+            a.auipc(T1, 0); a.sub(T2, T2, T1)
+            emit_store(T2)
+    elif mn in _CRR:
+        for x, y in _archtest_operands(mn)[:100]:
+            a.li(8, x); a.li(9, y)
+            getattr(a, mn)(8, 9)
+            emit_store(8)
+    elif mn in ("c_addi", "c_addiw", "c_li", "c_andi", "c_slli", "c_srli", "c_srai", "c_lui"):
+        for x, _ in _archtest_operands(mn)[:100]:
+            a.li(8, x)
+            if mn in ("c_slli", "c_srli", "c_srai"):
+                getattr(a, mn)(8, rng.randrange(1, 64))
+            elif mn == "c_lui":
+                v = rng.choice([i for i in range(-32, 32) if i != 0]); a.c_lui(8, v)
+            else:
+                getattr(a, mn)(8, rng.randrange(-32, 32))
+            emit_store(8)
+    elif mn in ("c_lw", "c_ld", "c_sw", "c_sd", "c_lwsp", "c_ldsp", "c_swsp", "c_sdsp"):
+        a.li(9, data_base + 0x10); a.li(2, data_base + 0x10)
+        for i in range(32):
+            a.li(8, rng.getrandbits(64))
+            if mn == "c_lw": a.c_lw(8, 9, 4 * rng.randrange(32))
+            elif mn == "c_ld": a.c_ld(8, 9, 8 * rng.randrange(30))
+            elif mn == "c_sw": o = 4 * rng.randrange(32); a.c_sw(8, 9, o); a.ld(8, (o // 8) * 8, 9)
+            elif mn == "c_sd": o = 8 * rng.randrange(30); a.c_sd(8, 9, o); a.ld(8, o, 9)
+            elif mn == "c_lwsp": a.c_lwsp(8, 4 * rng.randrange(60))
+            elif mn == "c_ldsp": a.c_ldsp(8, 8 * rng.randrange(30))
+            elif mn == "c_swsp": o = 4 * rng.randrange(60); a.c_swsp(8, o); a.ld(8, (o // 8) * 8, 2)
+            else: o = 8 * rng.randrange(30); a.c_sdsp(8, o); a.ld(8, o, 2)
+            emit_store(8)
+    elif mn in ("c_j", "c_beqz", "c_bnez", "c_jr", "c_jalr"):
+        for i in range(32):
+            lbl = f"ct{i}"
+            a.li(8, rng.choice([0, 1, rng.getrandbits(64)])); a.li(T2, 0)
+            if mn == "c_j": a.c_j(lbl)
+            elif mn == "c_beqz": a.c_beqz(8, lbl)
+            elif mn == "c_bnez": a.c_bnez(8, lbl)
+            elif mn == "c_jr": a.la(9, lbl); a.c_jr(9)
+            else: a.la(9, lbl); a.c_jalr(9)
+            a.li(T2, 1)
+            a.label(lbl)
+            emit_store(T2)
+    else:
+        raise ValueError(mn)
+    assert sig_words * 4 <= sig_cap, (mn, sig_words)
+    _exit_tohost(a, data_base)
+    # signature region
+    while d.pc < data_base + 0x200:
+        d.dword(0)
+    assert d.symbols["begin_signature"] <= data_base + 0x200
+    d.symbols["begin_signature"] = data_base + 0x200
+    d.zeros(sig_words * 4)
+    d.label("end_signature")
+    return _finish(a, f"arch-{mn}", "rv64imc_zicsr", d, mem_size=1 << 16, max_inst=200000, meta=dict(mnemonic=mn))
+
+
+def archtest_mnemonics():
+    return (_RR + _RI + [s for s, _ in _SH] + _BR + [s for s, _ in _LD] + [s for s, _ in _ST] + ["lui", "auipc", "jal", "jalr"] +
+            _CRR + ["c_addi", "c_addiw", "c_li", "c_andi", "c_slli", "c_srli", "c_srai", "c_lui", "c_lw", "c_ld", "c_sw",
+                    "c_sd", "c_lwsp", "c_ldsp", "c_swsp", "c_sdsp", "c_j", "c_beqz", "c_bnez", "c_jr", "c_jalr"])
+
+
+def archtest_suite():
+    return [archtest_program(m) for m in archtest_mnemonics()]
+
+
+# ------------------------------------------------------------------------------------------ config 2
+def splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def compute_seed(i: int) -> int:
+    return splitmix64(0xC0FFEE ^ i)
+
+
+def compute_kernel(iters: int = 4, fp: bool = True) -> Program:
+    """CoreMark-style mix, seed in a0 (per instance): LCG-filled 16x16 integer matrix multiply,
+    linked-list walk, bit-serial CRC16 (data-dependent branches), then an FP section (daxpy,
+    Horner fma, div/sqrt chain, fcvt round trips under every rounding mode, single precision mix).
+    Result words are stored to `results`; exit by writing 1 to tohost."""
+    data_base = BASE + 0x2000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("seed"); d.dword(0)
+    d.label("results"); d.zeros(8 * 32)
+    d.label("matA"); d.zeros(16 * 16 * 4)
+    d.label("matB"); d.zeros(16 * 16 * 4)
+    d.label("matC"); d.zeros(16 * 16 * 4)
+    d.label("nodes"); d.zeros(64 * 16)
+    d.label("buf"); d.zeros(256)
+    d.label("vecx"); d.zeros(64 * 8)
+    d.label("vecy"); d.zeros(64 * 8)
+    d.label("fconst")
+    import struct as _st
+    for v in (1.0, 0.5, 3.0, 1e-3, 1.0000001, 7.25, 1e300, 1e-300):
+        d.data(_st.pack("<d", v))
+    S = d.symbols
+    # registers
+    SEED, RES, I, J, K, T0, T1, T2, T3, P, Q, ACC, ITER = 10, 11, 12, 13, 14, 5, 6, 7, 28, 15, 16, 17, 18
+
+    def lcg(reg):  # reg = reg * 6364136223846793005 + 1442695040888963407
+        a.mul(reg, reg, 20); a.add(reg, reg, 21)
+
+    a.label("_start")
+    a.li(T0, 0x6000 if fp else 0)
+    if fp:
+        a.csrs(CSR["mstatus"], T0)
+    a.li(RES, S["results"])
+    a.li(20, 6364136223846793005); a.li(21, 1442695040888963407)
+    a.li(T0, S["seed"]); a.ld(T1, 0, T0); a.xor(SEED, SEED, T1)
+    a.li(ITER, iters)
+    a.label("outer")
+    # ---- 1. fill A, B with LCG; C = A*B (32-bit), checksum
+    a.li(P, S["matA"]); a.li(I, 512)
+    a.label("fill")
+    lcg(SEED); a.srli(T0, SEED, 40); a.sw(T0, 0, P); a.addi(P, P, 4); a.addi(I, I, -1); a.bnez(I, "fill")
+    a.li(I, 0); a.li(ACC, 0)
+    a.label("mm_i")
+    a.li(J, 0)
+    a.label("mm_j")
+    a.li(K, 0); a.li(T3, 0)
+    a.slli(P, I, 6); a.li(T0, S["matA"]); a.add(P, P, T0)          # &A[i][0]
+    a.slli(Q, J, 2); a.li(T0, S["matB"]); a.add(Q, Q, T0)          # &B[0][j]
+    a.label("mm_k")
+    a.lw(T0, 0, P); a.lw(T1, 0, Q); a.mulw(T0, T0, T1); a.addw(T3, T3, T0)
+    a.addi(P, P, 4); a.addi(Q, Q, 64); a.addi(K, K, 1); a.li(T0, 16); a.blt(K, T0, "mm_k")
+    a.slli(T0, I, 6); a.slli(T1, J, 2); a.add(T0, T0, T1); a.li(T1, S["matC"]); a.add(T0, T0, T1); a.sw(T3, 0, T0)
+    a.add(ACC, ACC, T3); a.addi(J, J, 1); a.li(T0, 16); a.blt(J, T0, "mm_j")
+    a.addi(I, I, 1); a.li(T0, 16); a.blt(I, T0, "mm_i")
+    a.sd(ACC, 0, RES)
+    # ---- 2. linked list: node i -> (i*k+1) mod 64 with k odd from the seed; values from LCG; walk 256 steps
+    a.li(P, S["nodes"]); a.li(I, 0); a.srli(K, SEED, 7); a.andi(K, K, 62); a.addi(K, K, 5)
+    a.label("ll_build")
+    a.mul(T0, I, K); a.addi(T0, T0, 1); a.andi(T0, T0, 63); a.slli(T0, T0, 4); a.li(T1, S["nodes"]); a.add(T0, T0, T1)
+    a.slli(T1, I, 4); a.add(T1, T1, P); a.sd(T0, 0, T1); lcg(SEED); a.sd(SEED, 8, T1)
+    a.addi(I, I, 1); a.li(T0, 64); a.blt(I, T0, "ll_build")
+    a.li(I, 256); a.li(ACC, 0); a.mv(Q, P)
+    a.label("ll_walk")
+    a.ld(T0, 8, Q); a.andi(T1, T0, 1); a.beqz(T1, "ll_even"); a.add(ACC, ACC, T0); a.j("ll_next")
+    a.label("ll_even"); a.xor(ACC, ACC, T0)
+    a.label("ll_next"); a.ld(Q, 0, Q); a.addi(I, I, -1); a.bnez(I, "ll_walk")
+    a.sd(ACC, 8, RES)
+    # ---- 3. CRC16 (0xA001) over 64 LCG bytes, bit serial
+    a.li(P, S["buf"]); a.li(I, 64)
+    a.label("crc_fill"); lcg(SEED); a.srli(T0, SEED, 33); a.sb(T0, 0, P); a.addi(P, P, 1); a.addi(I, I, -1); a.bnez(I, "crc_fill")
+    a.li(P, S["buf"]); a.li(I, 64); a.li(ACC, 0xFFFF); a.li(T3, 0xA001)
+    a.label("crc_byte"); a.lbu(T0, 0, P); a.xor(ACC, ACC, T0); a.li(J, 8)
+    a.label("crc_bit"); a.andi(T1, ACC, 1); a.srli(ACC, ACC, 1); a.beqz(T1, "crc_nox"); a.xor(ACC, ACC, T3)
+    a.label("crc_nox"); a.addi(J, J, -1); a.bnez(J, "crc_bit")
+    a.addi(P, P, 1); a.addi(I, I, -1); a.bnez(I, "crc_byte")
+    a.sd(ACC, 16, RES)
+    # ---- 4. atomics: amoadd/amoswap/lr-sc on the results area
+    a.addi(T0, RES, 24); a.amoadd_d(T1, SEED, T0); a.amoxor_w(T1, ACC, T0); a.lr_d(T1, T0); a.addi(T1, T1, 3); a.sc_d(T2, T1, T0)
+    a.sd(T2, 32, RES)
+    if fp:
+        # ---- 5. FP: x[i] = int->double(seed bits), y[i] = a*x[i] + y[i]; Horner; div/sqrt; fcvt under all rms
+        a.li(P, S["vecx"]); a.li(Q, S["vecy"]); a.li(I, 64)
+        a.li(T0, S["fconst"]); a.fld(0, 0, T0); a.fld(1, 8, T0); a.fld(2, 16, T0); a.fld(3, 24, T0); a.fld(4, 32, T0); a.fld(5, 40, T0)
+        a.label("fp_fill")
+        lcg(SEED); a.srai(T0, SEED, 20); a.fcvt_d_l(6, T0); a.fmul_d(6, 6, 3); a.fsd(6, 0, P)
+        lcg(SEED); a.srli(T0, SEED, 30); a.fcvt_d_lu(7, T0); a.fdiv_d(7, 7, 5); a.fsd(7, 0, Q)
+        a.addi(P, P, 8); a.addi(Q, Q, 8); a.addi(I, I, -1); a.bnez(I, "fp_fill")
+        a.li(P, S["vecx"]); a.li(Q, S["vecy"]); a.li(I, 64); a.fmv_d_x(8, 0)
+        a.label("daxpy")
+        a.fld(6, 0, P); a.fld(7, 0, Q); a.fmadd_d(7, 4, 6, 7); a.fsd(7, 0, Q); a.fadd_d(8, 8, 7)
+        a.fmul_d(9, 6, 6); a.fnmsub_d(9, 9, 1, 7); a.fsub_d(8, 8, 9)
+        a.addi(P, P, 8); a.addi(Q, Q, 8); a.addi(I, I, -1); a.bnez(I, "daxpy")
+        a.fsd(8, 40, RES)
+        # Horner in x = vecx[3] scaled into (0,2): p = ((((c*x+1)*x+0.5)*x+3)*x+1e-3)
+        a.li(P, S["vecx"]); a.fld(6, 24, P)
+        a.fsgnjx_d(6, 6, 6); a.fadd_d(7, 6, 0); a.fdiv_d(6, 6, 7); a.fadd_d(6, 6, 6)     # x = 2|v|/(|v|+1)
+        a.fmv_d_x(9, 0); a.fadd_d(9, 9, 4)
+        for c in (0, 1, 2, 3):
+            a.fmadd_d(9, 9, 6, c)
+        a.fsd(9, 48, RES)
+        # div / sqrt chain
+        a.fsqrt_d(10, 7); a.fdiv_d(11, 0, 10); a.fmul_d(11, 11, 11); a.fmsub_d(11, 11, 7, 0); a.fsd(11, 56, RES)
+        # conversions under every rounding mode + flags readback
+        for rm in range(5):
+            a.fcvt_l_d(T0, 9, rm); a.fcvt_w_d(T1, 8, rm); a.add(T0, T0, T1); a.fcvt_wu_d(T1, 11, rm); a.add(T0, T0, T1)
+            a.fcvt_s_d(12, 9, rm); a.fcvt_d_s(13, 12); a.fsub_d(13, 13, 9); a.fmv_x_d(T1, 13); a.xor(T0, T0, T1)
+            a.sd(T0, 64 + 8 * rm, RES)
+        # single precision mix with dynamic rounding mode from the seed
+        a.srli(T0, SEED, 13); a.andi(T0, T0, 3); a.csrw(CSR["frm"], T0)
+        a.fcvt_s_d(14, 8); a.fcvt_s_d(15, 6); a.fmul_s(16, 14, 15); a.fadd_s(16, 16, 15); a.fdiv_s(17, 16, 14); a.fsqrt_s(18, 15)
+        a.fmadd_s(19, 16, 17, 18); a.fnmadd_s(19, 19, 15, 14); a.fmin_s(20, 19, 18); a.fmax_s(21, 19, 18)
+        a.flt_s(T0, 20, 21); a.feq_s(T1, 20, 20); a.fclass_s(T2, 19); a.slli(T1, T1, 8); a.or_(T0, T0, T1); a.slli(T2, T2, 16); a.or_(T0, T0, T2)
+        a.fmv_x_w(T1, 19); a.slli(T1, T1, 32); a.xor(T0, T0, T1); a.sd(T0, 104, RES)
+        a.fsw(19, 112, RES); a.flw(22, 112, RES); a.fcvt_w_s(T0, 22); a.fcvt_lu_s(T1, 21); a.add(T0, T0, T1); a.sd(T0, 120, RES)
+        a.csrr(T0, CSR["fcsr"]); a.sd(T0, 128, RES)
+        a.csrw(CSR["frm"], 0)
+    a.addi(ITER, ITER, -1)
+    a.beqz(ITER, "done")
+    a.j("outer")
+    a.label("done")
+    a.csrr(T0, CSR["minstret"]); a.sd(T0, 136, RES)
+    _exit_tohost(a, S["tohost"])
+    isa = "rv64imafdc_zicsr" if fp else "rv64imac_zicsr"
+    return _finish(a, "compute", isa, d, mem_size=1 << 16, max_inst=1 << 26, meta=dict(iters=iters))
+
+
+# ------------------------------------------------------------------------------------------ fuzz
+def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = True) -> Program:
+    """Random instruction mix (M-mode, bare): ALU, loads/stores into mapped and unmapped addresses,
+    forward branches, M, A, F/D, CSR accesses, ecall/ebreak/illegal words.  A trap handler skips the
+    trapping instruction (length from the low two bits at mepc) and returns."""
+    rng = random.Random(seed)
+    data_base = BASE + 0x4000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("data")
+    d.data(bytes(rng.getrandbits(8) for _ in range(1024)))
+    fvals = [0, 0x8000000000000000, 0x3FF0000000000000, 0xBFF0000000000000, 0x7FF0000000000000, 0xFFF0000000000000,
+             0x7FF8000000000000, 0x7FF0000000000001, 0x0000000000000001, 0x000FFFFFFFFFFFFF, 0x0010000000000000,
+             0x7FEFFFFFFFFFFFFF, 0x4340000000000000, 0xC3E0000000000000, 0x3FE0000000000000, 0x41DFFFFFFFC00000,
+             0xFFFFFFFF3F800000, 0xFFFFFFFF7F800000, 0xFFFFFFFF7FC00000, 0xFFFFFFFF7F800001, 0xFFFFFFFF00000001,
+             0xFFFFFFFF00800000, 0xFFFFFFFF7F7FFFFF, 0xFFFFFFFFCF000000, 0xFFFFFFFF4F000000, 0x000000003F800000]
+    d.label("fdata")
+    for v in fvals:
+        d.dword(v)
+    for _ in range(32 - len(fvals)):
+        d.dword(rng.getrandbits(64))
+    S = d.symbols
+    H1, H2 = 30, 31     # reserved for the trap handler
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    a.csrr(H1, CSR["mepc"]); a.lhu(H2, 0, H1); a.andi(H2, H2, 3); a.addi(H2, H2, -3)
+    a.bnez(H2, "h2"); a.addi(H1, H1, 2)
+    a.label("h2"); a.addi(H1, H1, 2); a.csrw(CSR["mepc"], H1); a.mret()
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    if fp:
+        a.li(5, 0x2000); a.csrs(CSR["mstatus"], 5)
+        a.li(5, S["fdata"])
+        for i in range(32):
+            a.fld(i, 8 * i, 5)
+    for r in range(1, 30):
+        a.li(r, rng.choice([rng.getrandbits(64), rng.getrandbits(12), S["data"] + 8 * rng.randrange(100), (1 << 63), MASK64, 0]))
+    regs = list(range(0, 30))
+    ptrs = [8, 9, 18, 19]
+    for r in ptrs:
+        a.li(r, S["data"] + 256 + 8 * rng.randrange(32))
+    rr_ops = _RR
+    labels = 0
+    pending = []   # (countdown, label)
+    amo = ["amoswap", "amoadd", "amoxor", "amoand", "amoor", "amomin", "amomax", "amominu", "amomaxu"]
+    fp3 = ["fadd", "fsub", "fmul", "fdiv", "fsgnj", "fsgnjn", "fsgnjx", "fmin", "fmax"]
+    safe_csrs = [CSR["mscratch"], CSR["mepc"], CSR["mcause"], CSR["mtval"], CSR["fflags"], CSR["frm"], CSR["fcsr"],
+                 CSR["mcycle"], CSR["minstret"], CSR["mhartid"], CSR["misa"], CSR["mie"], CSR["mip"], CSR["mcounteren"],
+                 CSR["cycle"], CSR["sstatus"], CSR["sepc"], 0x7C0, CSR["mvendorid"], CSR["menvcfg"], CSR["mcountinhibit"], CSR["mstatus"]]
+    for i in range(n):
+        for p in list(pending):
+            p[0] -= 1
+            if p[0] <= 0:
+                a.label(p[1]); pending.remove(p)
+        k = rng.random()
+        rd = rng.choice([r for r in regs if r not in ptrs]); rs1 = rng.choice(regs); rs2 = rng.choice(regs)
+        if k < 0.30:
+            getattr(a, rng.choice(rr_ops))(rd, rs1, rs2)
+        elif k < 0.42:
+            getattr(a, rng.choice(_RI))(rd, rs1, rng.randint(-2048, 2047))
+        elif k < 0.47:
+            m, lim = rng.choice(_SH); getattr(a, m)(rd, rs1, rng.randrange(lim))
+        elif k < 0.50:
+            (a.lui if rng.random() < 0.5 else a.auipc)(rd, rng.getrandbits(20))
+        elif k < 0.62:
+            m, sz = rng.choice(_LD + _ST)
+            base = rng.choice(ptrs) if rng.random() < 0.9 else rs1
+            off = rng.randrange(-256, 256)
+            if rng.random() < 0.8:
+                off -= off % sz
+            if m.startswith("l"):
+                getattr(a, m)(rd, off, base)
+            else:
+                getattr(a, m)(rs2, off, base)
+        elif k < 0.70:
+            lbl = f"L{labels}"; labels += 1
+            getattr(a, rng.choice(_BR))(rs1, rs2, lbl)
+            pending.append([rng.randrange(1, 6), lbl])
+        elif k < 0.72:
+            lbl = f"L{labels}"; labels += 1
+            a.jal(rd if rng.random() < 0.5 else 0, lbl)
+            pending.append([rng.randrange(1, 4), lbl])
+        elif k < 0.77:
+            sfx = rng.choice(["w", "d"]); base = rng.choice(ptrs + [rs1])
+            r = rng.random()
+            if r < 0.25:
+                getattr(a, f"lr_{sfx}")(rd, base)
+            elif r < 0.5:
+                getattr(a, f"sc_{sfx}")(rd, rs2, base)
+            else:
+                getattr(a, f"{rng.choice(amo)}_{sfx}")(rd, rs2, base)
+        elif k < 0.90 and fp:
+            f1, f2, f3, fd = (rng.randrange(32) for _ in range(4)); sfx = rng.choice("sd")
+            rm = rng.choice([0, 1, 2, 3, 4, 7, 7, 7, 5])
+            r = rng.random()
+            if r < 0.35:
+                op = rng.choice(fp3)
+                if op in ("fadd", "fsub", "fmul", "fdiv"):
+                    getattr(a, f"{op}_{sfx}")(fd, f1, f2, rm)
+                else:
+                    getattr(a, f"{op}_{sfx}")(fd, f1, f2)
+            elif r < 0.50:
+                getattr(a, f"{rng.choice(['fmadd', 'fmsub', 'fnmsub', 'fnmadd'])}_{sfx}")(fd, f1, f2, f3, rm)
+            elif r < 0.56:
+                getattr(a, f"fsqrt_{sfx}")(fd, f1, rm)
+            elif r < 0.68:
+                getattr(a, f"fcvt_{rng.choice(['w', 'wu', 'l', 'lu'])}_{sfx}")(rd, f1, rm)
+            elif r < 0.78:
+                getattr(a, f"fcvt_{sfx}_{rng.choice(['w', 'wu', 'l', 'lu'])}")(fd, rs1, rm)
+            elif r < 0.84:
+                getattr(a, f"{rng.choice(['feq', 'flt', 'fle'])}_{sfx}")(rd, f1, f2)
+            elif r < 0.88:
+                getattr(a, f"fclass_{sfx}")(rd, f1)
+            elif r < 0.92:
+                rng.choice([a.fmv_x_w, a.fmv_x_d])(rd, f1) if rng.random() < 0.5 else rng.choice([a.fmv_w_x, a.fmv_d_x])(fd, rs1)
+            elif r < 0.96:
+                (a.fcvt_s_d if rng.random() < 0.5 else a.fcvt_d_s)(fd, f1)
+            else:
+                base = rng.choice(ptrs); off = 8 * rng.randrange(-16, 16)
+                rng.choice([a.flw, a.fld])(fd, off, base) if rng.random() < 0.5 else rng.choice([a.fsw, a.fsd])(f1, off, base)
+        elif k < 0.94:
+            csr = rng.choice(safe_csrs)
+            op = rng.choice(["csrrw", "csrrs", "csrrc", "csrrwi", "csrrsi", "csrrci"])
+            if csr == CSR["mstatus"]:
+                op = rng.choice(["csrrs", "csrrc", "csrrsi", "csrrci"]); src = rng.choice([0, 3, 5])  # keep FS/MIE sane-ish
+                getattr(a, op)(rd, csr, src if op.endswith("i") else 0)
+            else:
+                getattr(a, op)(rd, csr, rng.randrange(32) if op.endswith("i") else rs1)
+        elif k < 0.96:
+            rng.choice([a.ecall, a.ebreak, a.fence, a.fence_i, a.wfi])()
+        elif k < 0.98 and compressed:
+            c = rng.random()
+            if c < 0.3: a.c_addi(rd if rd else 1, rng.randrange(-32, 32))
+            elif c < 0.5: a.c_li(rd if rd else 1, rng.randrange(-32, 32))
+            elif c < 0.7: a.c_mv(rd if rd else 1, rs2 if rs2 else 1)
+            elif c < 0.85: a.c_add(rd if rd else 1, rs2 if rs2 else 1)
+            else: a.c_nop()
+        else:
+            w = rng.getrandbits(32)
+            if rng.random() < 0.5:
+                w |= 3
+                a.word(w)        # random 32-bit word (mostly illegal, sometimes a valid instruction)
+            else:
+                a.half(rng.choice([0, 0x0000, 0xFFFF & ~3 & w, 0x8000, 0x6000, 0xE000]) & ~0x3 | rng.choice([0, 0, 1, 2]))
+    for p in pending:
+        a.label(p[1])
+    a.align(4)
+    _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
+    return _finish(a, f"fuzz-{seed}", "rv64imafdc_zicsr" if fp else "rv64imac_zicsr", d, mem_size=1 << 16, max_inst=20000,
+                   meta=dict(seed=seed))
