@@ -113,6 +113,12 @@ int  wsp_batch_last_hash_stats(wsp_batch* b, double* kernel_seconds, uint64_t* b
  * end_signature of `hart`; writes up to cap words, returns the word count or a negative error. */
 int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap);
 
+/* Checkpoint / resume of the whole batch on the device (the role of System::saveSnapshot and
+ * --loadfrom, System.cpp:562, snapshot.cpp:17: here the device state arrays are the checkpoint).
+ * snapshot keeps one device-resident copy; restore rewinds every hart to it. */
+int  wsp_batch_snapshot(wsp_batch* b);
+int  wsp_batch_restore(wsp_batch* b);
+
 /* Run the device decoder (the one the step kernel uses) over n instruction words. */
 int  wsp_decode_words(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out);
 /* The same decoder compiled for the host (no device needed; used by CPU-only tests). */

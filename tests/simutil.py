@@ -59,8 +59,9 @@ def result_tuple(status, value, pc, execn, retired, state_hash, mem_hash, trace_
                 trace_hash=trace_hash)
 
 
-def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0):
-    h = rvoracle.Hart(isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, tohost=prog.tohost, reset_pc=prog.entry)
+def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart_id=0):
+    h = rvoracle.Hart(isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, tohost=prog.tohost, reset_pc=prog.entry,
+                      hart_id=hart_id)
     for paddr, data, _ in prog.segments:
         h.write_mem(paddr, data)
     if seed_a0 is not None:
@@ -72,9 +73,9 @@ def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0):
     return r, h, log
 
 
-def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True):
+def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0):
     L = shim()
-    s = L.hs_create(rvoracle.isa_flags(prog.isa), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, 0)
+    s = L.hs_create(rvoracle.isa_flags(prog.isa), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id)
     try:
         for paddr, data, _ in prog.segments:
             assert L.hs_write_mem(s, paddr, data, len(data)) == 0

@@ -36,7 +36,7 @@ def _run_batch(progs, seeds=None, lanes=0, trace=True, same_elf=False, max_steps
 def _check(progs, res, seeds=None, trace=True):
     bad = []
     for i, p in enumerate(progs):
-        ro, h, _ = S.run_oracle(p, seed_a0=seeds[i][0] if seeds else None, seed_mem=seeds[i][1] if seeds else None)
+        ro, h, _ = S.run_oracle(p, seed_a0=seeds[i][0] if seeds else None, seed_mem=seeds[i][1] if seeds else None, hart_id=i)
         rd = dict(res[i])
         if not trace:
             ro = dict(ro); ro["trace_hash"] = 0
@@ -125,7 +125,7 @@ def test_instruction_limit_and_peek_poke():
         res = [r.as_dict() for r in b.results()]
         assert all(r["status"] == W.ST_STOP_LIMIT and r["exec"] == 1000 for r in res)
         pq = WL.compute_kernel(iters=1); pq.max_inst = 1000
-        ro, _, _ = S.run_oracle(pq, seed_a0=0x1234)
+        ro, _, _ = S.run_oracle(pq, seed_a0=0x1234, hart_id=1)
         ro = dict(ro); ro["trace_hash"] = 0
         assert res[1] == ro
     finally:

@@ -87,6 +87,8 @@ def lib():
         L.wsp_batch_last_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
         L.wsp_batch_signature.restype = C.c_int64
         L.wsp_batch_signature.argtypes = [vp, u32, C.POINTER(u32), C.c_size_t]
+        L.wsp_batch_snapshot.argtypes = [vp]
+        L.wsp_batch_restore.argtypes = [vp]
         L.wsp_decode_words.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
         L.wsp_decode_words_host.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
         L.wsp_isa_flags.restype = u32
@@ -187,6 +189,12 @@ class Batch:
         s = C.c_double(); n = C.c_uint64()
         _check(self.L.wsp_batch_last_hash_stats(self.h, C.byref(s), C.byref(n)))
         return s.value, n.value
+
+    def snapshot(self):
+        _check(self.L.wsp_batch_snapshot(self.h))
+
+    def restore(self):
+        _check(self.L.wsp_batch_restore(self.h))
 
     def signature(self, hart, cap=1 << 16):
         arr = (C.c_uint32 * cap)()

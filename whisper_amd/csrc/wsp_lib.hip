@@ -316,7 +316,17 @@ struct wsp_batch {
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
   double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
   bool has_fp = false;
+  void* snap[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+
+struct SnapPart { void* live; size_t bytes; };
+static void snap_parts(wsp_batch* b, SnapPart out[9])
+{
+  DevState& d = b->d; size_t S = d.S;
+  out[0] = { d.x, 32 * S * 8 }; out[1] = { d.f, 32 * S * 8 }; out[2] = { d.hot64, H64_COUNT * S * 8 }; out[3] = { d.hot32, H32_COUNT * S * 4 };
+  out[4] = { d.cold, CI_COUNT * S * 8 }; out[5] = { d.tohost, S * 8 }; out[6] = { d.max_exec, S * 8 }; out[7] = { d.prog, S * 4 };
+  out[8] = { d.arena, (size_t)d.n_waves * d.lpw * d.mem_size };
+}
 
 static int upload_progs(wsp_batch* b)
 {
@@ -339,6 +349,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
   void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results };
   for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->stream) hipStreamDestroy(b->stream);
@@ -786,6 +797,30 @@ extern "C" int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* wo
   if (n > cap) return fail(WSP_ERANGE, "signature buffer too small");
   if (n) { rc = wsp_batch_peek(b, hart, WSP_RES_MEM, lo, words, n * 4); if (rc) return rc; }
   return (int64_t)n;
+}
+
+extern "C" int wsp_batch_snapshot(wsp_batch* b)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  HIPOK(hipSetDevice(b->device));
+  SnapPart parts[9]; snap_parts(b, parts);
+  for (int i = 0; i < 9; ++i) {
+    if (!b->snap[i]) { if (hipMalloc(&b->snap[i], parts[i].bytes) != hipSuccess) return fail(WSP_ENOMEM, "snapshot allocation failed"); }
+    HIPOK(hipMemcpyAsync(b->snap[i], parts[i].live, parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
+  }
+  HIPOK(hipStreamSynchronize(b->stream));
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_restore(wsp_batch* b)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  if (!b->snap[0]) return fail(WSP_EINVAL, "no snapshot taken");
+  HIPOK(hipSetDevice(b->device));
+  SnapPart parts[9]; snap_parts(b, parts);
+  for (int i = 0; i < 9; ++i) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
+  HIPOK(hipStreamSynchronize(b->stream));
+  return WSP_OK;
 }
 
 extern "C" int wsp_decode_words_host(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out)
