@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="harts per wavefront (0 = auto)")
     ap.add_argument("--trace", action="store_true", help="fold the commit-trace digest while running")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nofp", action="store_true", help="diagnostic: integer-only variant of the kernel (not the BASELINE config)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +95,7 @@ def main():
     import whisper_amd as W
     from whisper_amd import workloads as WL
 
-    prog = WL.compute_kernel(iters=args.iters)
+    prog = WL.compute_kernel(iters=args.iters, fp=not args.nofp)
     n = args.harts
     base = rank * n
     b = W.Batch(n, isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, lanes_per_wave=args.lanes,

@@ -28,7 +28,32 @@ struct HostMem {
   void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
 };
 
-struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<Rec> recs; u64 max_exec; };
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
+
+template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
+{
+  Lane<HostMem>& L = s->L;
+  L.update_hot_flag();
+  while (L.h.status == ST_RUNNING) {
+    if (L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; break; }
+    // same structure as the GPU kernel: hot harts try the pre-decoded fetch + inline subset first
+    Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+    if (s->use_fast && (L.h.flags & HF_HOT) && L.hot_fetch(s->recs.data(), rec)) {
+      const u64 cur_pc = L.h.pc;
+      const u64 a = L.m.rx(rec_rs1(rec));
+      const u64 b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : L.m.rx(rec_rs2(rec));
+      L.h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
+      L.h.exec++; L.h.cycle++;
+      if (L.exec_fast<TRACE>(rec.w0 & 0xff, rec, a, b, cur_pc)) { L.h.instret++; L.h.retired++; L.trace_fast<TRACE>(rec, cur_pc); continue; }
+      L.s.chg = 0;
+      L.exec(rec.w0 & 0xff, rec, a, b, cur_pc);
+      L.step_end<TRACE>(rec, cur_pc, PRV_M);
+      L.update_hot_flag();
+      continue;
+    }
+    L.cold_step<TRACE>();
+  }
+}
 
 extern "C" {
 Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id)
@@ -62,6 +87,7 @@ void hs_predecode(Sim* s, u64 addr, u64 n)
   }
   s->L.text_lo = addr; s->L.text_hi = addr + n;
 }
+void hs_use_fast(Sim* s, int f) { s->use_fast = f; }
 void hs_set_pc(Sim* s, u64 pc) { s->L.h.pc = pc & ~1ULL; }
 void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = v; }
 u64 hs_get_x(Sim* s, u32 i) { return s->L.m.x[i & 31]; }
@@ -72,17 +98,8 @@ u64 hs_csr(Sim* s, u32 num) { return s->L.csr_peek(num); }
 void hs_poke_csr(Sim* s, u32 num, u64 v) { s->L.csr_store(num, v); s->L.s.chg = 0; }
 int hs_run(Sim* s, u64 max_exec, int trace)
 {
-  Lane<HostMem>& L = s->L;
-  while (L.h.status == ST_RUNNING) {
-    if (L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; break; }
-    Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
-    u64 a = 0, b = 0, cur_pc = 0; u32 priv0 = 0;
-    bool todo = trace ? L.step_begin<true>(s->recs.data(), rec, a, b, cur_pc, priv0) : L.step_begin<false>(s->recs.data(), rec, a, b, cur_pc, priv0);
-    if (!todo) continue;
-    L.exec(rec.w0 & 0xff, rec, a, b, cur_pc);
-    if (trace) L.step_end<true>(rec, cur_pc, priv0); else L.step_end<false>(rec, cur_pc, priv0);
-  }
-  return (int)L.h.status;
+  if (trace) run_t<true>(s, max_exec); else run_t<false>(s, max_exec);
+  return (int)s->L.h.status;
 }
 u64 hs_stop_value(Sim* s) { return s->L.h.stop_value; }
 u64 hs_exec(Sim* s) { return s->L.h.exec; }

@@ -291,7 +291,10 @@ enum ColdIx {
   CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP, CI_COUNT
 };
 
-enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8 };
+// HF_HOT: the hart may use the pre-decoded fetch and the trap-free inline subset: M-mode, MPRV clear,
+// code not self-modified, no counter inhibited (so every hot step advances exec, cycle, instret and
+// retired by exactly one).  Recomputed by update_hot_flag() after anything that can change it.
+enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16 };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -746,6 +749,106 @@ template <class MEM> struct Lane {
     wx(rd, ld);
   }
 
+  // ---- the common, trap-free subset executed inline in the GPU hot loop (caller guarantees HF_HOT).
+  // Returns false -- before any side effect -- when the instruction needs the full exec(): anything
+  // that can trap, touch tohost / code / CSRs, FP, A, division.  Must behave exactly like exec() for
+  // what it accepts.  Register-write / store capture for the commit record only when TRACE.
+  WSP_HD void update_hot_flag()
+  {
+    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV);
+    h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
+  }
+  template <bool TRACE> WSP_HD void wx_fast(u32 rd, u64 v)
+  {
+    m.wx(rd, rd ? v : 0);                       // x0 slot always holds zero: no branch
+    if (TRACE) { s.chg = CH_IREG; s.ireg = rd; s.ival = v; }
+  }
+  // pre-decoded fetch: false when the slot is not trustworthy (outside the decoded text, straddling)
+  WSP_HD bool hot_fetch(const Rec* recs, Rec& rec) const
+  {
+    const u64 idx = h.pc - text_lo;
+    if (idx >= text_hi - text_lo) return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (idx << 3));
+    rec.w0 = q.x; rec.imm = (i32)q.y; rec.raw = q.z; rec.pad = 0;
+#else
+    rec = recs[idx >> 1];
+#endif
+    return (rec.w0 & 0xff) != OP_SLOWFETCH;
+  }
+  template <bool TRACE> WSP_HD bool exec_fast(u32 op, const Rec& r, u64 a, u64 b, u64 cur_pc)
+  {
+    const u32 rd = rec_rd(r);
+    if (TRACE) s.chg = 0;
+    switch (op) {
+      case OP_ADD: wx_fast<TRACE>(rd, a + b); return true;
+      case OP_SUB: wx_fast<TRACE>(rd, a - b); return true;
+      case OP_SLL: wx_fast<TRACE>(rd, a << (b & 63)); return true;
+      case OP_SLT: wx_fast<TRACE>(rd, (i64)a < (i64)b); return true;
+      case OP_SLTU: wx_fast<TRACE>(rd, a < b); return true;
+      case OP_XOR: wx_fast<TRACE>(rd, a ^ b); return true;
+      case OP_SRL: wx_fast<TRACE>(rd, a >> (b & 63)); return true;
+      case OP_SRA: wx_fast<TRACE>(rd, (u64)((i64)a >> (b & 63))); return true;
+      case OP_OR: wx_fast<TRACE>(rd, a | b); return true;
+      case OP_AND: wx_fast<TRACE>(rd, a & b); return true;
+      case OP_ADDW: wx_fast<TRACE>(rd, (u64)(i64)(i32)((u32)a + (u32)b)); return true;
+      case OP_SUBW: wx_fast<TRACE>(rd, (u64)(i64)(i32)((u32)a - (u32)b)); return true;
+      case OP_SLLW: wx_fast<TRACE>(rd, (u64)(i64)(i32)((u32)a << (b & 31))); return true;
+      case OP_SRLW: wx_fast<TRACE>(rd, (u64)(i64)(i32)((u32)a >> (b & 31))); return true;
+      case OP_SRAW: wx_fast<TRACE>(rd, (u64)(i64)((i32)a >> (b & 31))); return true;
+      case OP_MUL: wx_fast<TRACE>(rd, a * b); return true;
+      case OP_MULW: wx_fast<TRACE>(rd, (u64)(i64)(i32)((u32)a * (u32)b)); return true;
+      case OP_AUIPC: wx_fast<TRACE>(rd, cur_pc + (u64)(i64)r.imm); return true;
+      case OP_NOP: return true;
+      case OP_JAL: {
+        if (!ext(ISA_C)) return false;
+        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL; return true; }
+      case OP_JALR: {
+        if (!ext(ISA_C)) return false;
+        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (a + (u64)(i64)r.imm) & ~1ULL; return true; }
+      case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
+        if (!ext(ISA_C)) return false;
+        bool take = op == OP_BEQ ? a == b : op == OP_BNE ? a != b : op == OP_BLT ? (i64)a < (i64)b
+                  : op == OP_BGE ? (i64)a >= (i64)b : op == OP_BLTU ? a < b : a >= b;
+        if (take) h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL;
+        return true; }
+      case OP_LB: case OP_LH: case OP_LW: case OP_LD: case OP_LBU: case OP_LHU: case OP_LWU: {
+        const u32 k = op - OP_LB, sz = 1u << (k & 3);
+        const u64 va = a + (u64)(i64)r.imm;
+        if ((va & (sz - 1)) || !in_mem(va, sz) || va == tohost) return false;
+        const u64 off = va - mem_base; u64 v;
+        switch (k) {
+          case 0: v = (u64)(i64)(int8_t)m.ld8(off); break; case 1: v = (u64)(i64)(int16_t)m.ld16(off); break;
+          case 2: v = (u64)(i64)(i32)m.ld32(off); break; case 3: v = m.ld64(off); break;
+          case 4: v = m.ld8(off); break; case 5: v = m.ld16(off); break; default: v = m.ld32(off); break;
+        }
+        wx_fast<TRACE>(rd, v); return true; }
+      case OP_SB: case OP_SH: case OP_SW: case OP_SD: {
+        const u32 k = op - OP_SB, sz = 1u << k;
+        const u64 va = a + (u64)(i64)r.imm;
+        if ((va & (sz - 1)) || !in_mem(va, sz) || va == tohost || va == tohost + 4 || (va + sz > text_lo && va < text_hi)) return false;
+        const u64 off = va - mem_base;
+        const u64 sv = k == 3 ? b : (b & ((1ULL << (8 * sz)) - 1));
+        switch (k) { case 0: m.st8(off, (u8)sv); break; case 1: m.st16(off, (u16)sv); break; case 2: m.st32(off, (u32)sv); break; default: m.st64(off, sv); break; }
+        if (TRACE) { s.chg = CH_MEM; s.maddr = va; s.mval = sv; }
+        return true; }
+      default: return false;
+    }
+  }
+  // trace fold for an instruction that went through exec_fast (no trap, no CSR change, M-mode)
+  template <bool TRACE> WSP_HD void trace_fast(const Rec& rec, u64 cur_pc)
+  {
+    if (!TRACE) return;
+    u64 t = h.thash;
+    t = fold(t, cur_pc);
+    t = fold(t, (u64)rec.raw | ((u64)PRV_M << 32) | ((u64)((rec.w0 & F_SIZE4) ? 4 : 2) << 48));
+    u64 k = 1ULL << 60, v = 0;
+    if ((s.chg & CH_IREG) && s.ireg) { k = (u64)s.ireg ^ (1ULL << 60); v = s.ival; }
+    else if (s.chg & CH_MEM) { k = s.maddr ^ (4ULL << 60); v = s.mval; }
+    t = fold(t, k); t = fold(t, v);
+    h.thash = t;
+  }
+
   // ---- one decoded instruction. `op` is passed separately so the GPU kernel can hand in a
   // wave-uniform copy (scalar branch over the switch); a = x[rs1], b = second operand.
   WSP_HD void exec(u32 op, const Rec& r, u64 a, u64 b, u64 cur_pc)
@@ -876,27 +979,21 @@ template <class MEM> struct Lane {
     return 0;
   }
 
-  // ---- one loop iteration of Hart::untilAddress (Hart.cpp:6025-6201), split around the dispatch so
-  // that the GPU kernel can run the execute part wave-uniformly.  step_begin does the bookkeeping and
-  // the fetch and returns true when `rec` must be executed (operands a, b already read).
-  template <bool TRACE> WSP_HD bool step_begin(const Rec* recs, Rec& rec, u64& a, u64& b, u64& cur_pc, u32& priv0)
+  // ---- one loop iteration of Hart::untilAddress (Hart.cpp:6025-6201) on the general (cold) path:
+  // bookkeeping, fetch from RAM incl. fetch faults, full exec(), retire + commit record.  The hot path
+  // (HF_HOT harts at a pre-decoded pc executing the exec_fast subset) is the same step with the
+  // bookkeeping reduced to "all four counters advance by one"; see the kernel / host shim drivers.
+  WSP_HD void cold_begin(u64& cur_pc, u32& priv0)
   {
     cur_pc = h.pc; priv0 = h.priv;
     s.chg = 0;
     h.exec++;
     if (!(h.flags & HF_INH_CY)) h.cycle++;
-    int fr = 0; u64 tval = 0;
-    bool fast = !(h.flags & HF_CODE_DIRTY) && priv0 == PRV_M && cur_pc >= text_lo && cur_pc < text_hi;
-    if (fast) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const uint4 q = *reinterpret_cast<const uint4*>(&recs[(cur_pc - text_lo) >> 1]);
-      rec.w0 = q.x; rec.imm = (i32)q.y; rec.raw = q.z; rec.pad = 0;
-#else
-      rec = recs[(cur_pc - text_lo) >> 1];
-#endif
-      if ((rec.w0 & 0xff) == OP_SLOWFETCH) fast = false;
-    }
-    if (!fast) fr = fetch_slow(cur_pc, rec, tval);
+  }
+  template <bool TRACE> WSP_HD bool fetch_slow_path(Rec& rec, u64& a, u64& b, u64 cur_pc, u32 priv0)
+  {
+    u64 tval = 0;
+    int fr = fetch_slow(cur_pc, rec, tval);
     if (fr == 1) {
       take_exception(1, cur_pc, tval, true);
       if (h.status != ST_RUNNING) {                 // consecutive-illegal stop inside the fetch fault
@@ -923,6 +1020,14 @@ template <class MEM> struct Lane {
     if (!(h.flags & HF_INH_IR)) h.instret++;
     h.retired++;
     commit<TRACE>(cur_pc, rec.raw, size, priv0, 0);
+  }
+  // a complete cold step
+  template <bool TRACE> WSP_HD void cold_step()
+  {
+    u64 cur_pc, a = 0, b = 0; u32 priv0; Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+    cold_begin(cur_pc, priv0);
+    if (fetch_slow_path<TRACE>(rec, a, b, cur_pc, priv0)) { exec(rec.w0 & 0xff, rec, a, b, cur_pc); step_end<TRACE>(rec, cur_pc, priv0); }
+    update_hot_flag();
   }
 
   // ---- fold one commit record into the running trace hash

@@ -64,10 +64,85 @@ struct DevMem {
 };
 
 // ------------------------------------------------------------------------------------------ step kernel
+#ifndef WSP_WAVES_PER_EU
+#define WSP_WAVES_PER_EU 2
+#endif
 extern __shared__ __align__(16) u64 wsp_lds[];
 
+__device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
+{
+  L.m.xs = wsp_lds + ln;
+  L.m.fs = wsp_lds + 32 * d.lpw + ln;
+  L.m.cold_ = d.cold + slot;
+  L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
+  L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
+  L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + wave * d.lpw + ln;
+  L.tohost = d.tohost[slot];
+  const u32 pg = d.prog[slot];
+  recs = nullptr; L.text_lo = 0; L.text_hi = 0;
+  if (pg != ~0u) { ProgDev p = d.progs[pg]; recs = p.recs; L.text_lo = p.text_lo; L.text_hi = p.text_hi; }
+}
+
+__device__ __forceinline__ void wsp_load_hot(Lane<DevMem>& L, const DevState& d, u32 slot)
+{
+  const u32 S = d.S;
+  L.h.pc = d.hot64[H64_PC * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.cycle = d.hot64[H64_CYCLE * S + slot];
+  L.h.instret = d.hot64[H64_INSTRET * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.retired = d.hot64[H64_RETIRED * S + slot];
+  L.h.thash = d.hot64[H64_THASH * S + slot]; L.h.lr_addr = d.hot64[H64_LR_ADDR * S + slot];
+  L.h.exec_last_ill = d.hot64[H64_EXEC_LAST_ILL * S + slot]; L.h.stop_value = d.hot64[H64_STOP_VALUE * S + slot];
+  L.h.fcsr = d.hot32[H32_FCSR * S + slot]; L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.status = d.hot32[H32_STATUS * S + slot];
+  L.h.consec_ill = d.hot32[H32_CONSEC_ILL * S + slot]; L.h.htif_dev = d.hot32[H32_HTIF_DEV * S + slot]; L.h.flags = d.hot32[H32_FLAGS * S + slot];
+}
+
+__device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevState& d, u32 slot)
+{
+  const u32 S = d.S;
+  d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_MSTATUS * S + slot] = L.h.mstatus; d.hot64[H64_CYCLE * S + slot] = L.h.cycle;
+  d.hot64[H64_INSTRET * S + slot] = L.h.instret; d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_RETIRED * S + slot] = L.h.retired;
+  d.hot64[H64_THASH * S + slot] = L.h.thash; d.hot64[H64_LR_ADDR * S + slot] = L.h.lr_addr;
+  d.hot64[H64_EXEC_LAST_ILL * S + slot] = L.h.exec_last_ill; d.hot64[H64_STOP_VALUE * S + slot] = L.h.stop_value;
+  d.hot32[H32_FCSR * S + slot] = L.h.fcsr; d.hot32[H32_PRIV * S + slot] = L.h.priv; d.hot32[H32_STATUS * S + slot] = L.h.status;
+  d.hot32[H32_CONSEC_ILL * S + slot] = L.h.consec_ill; d.hot32[H32_HTIF_DEV * S + slot] = L.h.htif_dev; d.hot32[H32_FLAGS * S + slot] = L.h.flags;
+}
+
+// What the hot loop keeps in registers per hart.  Everything else of wsp::Hot stays in HBM between
+// cold steps; exec/cycle/instret/retired are synchronised lazily: a hot step advances all four by
+// exactly one (HF_HOT guarantees no inhibit, no trap), so the HBM copies are brought up to date
+// from the difference between the register exec counter and the stored one.
+struct HotRegs { u64 pc, exec, thash; u32 flags, status; };
+
+// The general path, out of line: rebuilds the full lane from HBM, runs either one complete cold
+// step (mode 0) or the full exec()+retire of an instruction the hot prologue already fetched and
+// counted (mode 1), stores the lane back.
+template <bool TRACE>
+__device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, u32 mode, u32 op_in, u32 w0, i32 imm, u32 raw,
+                                         u64 a, u64 b, u64 cur_pc, HotRegs hr)
+{
+  const DevState& d = *dp;
+  const u32 slot = wave * 64 + ln;
+  Lane<DevMem> L; const Rec* recs;
+  wsp_lane_setup(L, d, wave, ln, slot, recs);
+  wsp_load_hot(L, d, slot);
+  const u64 dlt = hr.exec - L.h.exec;
+  const u64 done = mode ? dlt - 1 : dlt;          // mode 1: the current instruction is counted in exec/cycle only
+  L.h.cycle += dlt; L.h.instret += done; L.h.retired += done;
+  L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  if (mode) {
+    const u32 op = (u32)__builtin_amdgcn_readfirstlane((int)op_in);   // wave-uniform by construction of the dispatch loop
+    Rec rec; rec.w0 = w0; rec.imm = imm; rec.raw = raw; rec.pad = 0;
+    L.exec(op, rec, a, b, cur_pc);
+    L.template step_end<TRACE>(rec, cur_pc, PRV_M);
+    L.update_hot_flag();
+  } else
+    L.template cold_step<TRACE>();
+  wsp_store_hot(L, d, slot);
+  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.flags = L.h.flags; r.status = L.h.status;
+  return r;
+}
+
 template <bool TRACE, bool FP>
-__global__ void __launch_bounds__(64) wsp_step_kernel(DevState d, u64 max_steps)
+__global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState d, const DevState* dp, u64 max_steps)
 {
   const u32 lane = threadIdx.x, wave = blockIdx.x;
   const u32 hart = wave * d.lpw + lane;
@@ -76,28 +151,16 @@ __global__ void __launch_bounds__(64) wsp_step_kernel(DevState d, u64 max_steps)
   const u32 slot = wave * 64 + ln;
   const u32 S = d.S;
 
-  Lane<DevMem> L;
-  L.m.xs = wsp_lds + ln;
-  L.m.fs = wsp_lds + 32 * d.lpw + ln;
-  L.m.cold_ = d.cold + slot;
-  L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
-  L.m.S = S; L.m.lpw_shift = d.lpw_shift;
-  L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + hart;
-  L.tohost = d.tohost[slot];
+  Lane<DevMem> L; const Rec* recs;
+  wsp_lane_setup(L, d, wave, ln, slot, recs);
+  L.h.pc = d.hot64[H64_PC * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.thash = d.hot64[H64_THASH * S + slot];
+  L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
+  L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot];
+  L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / flags
+  L.s.chg = 0; L.s.ireg = 0; L.s.ival = 0; L.s.maddr = 0; L.s.mval = 0;
   const u64 max_exec = d.max_exec[slot];
-  const u32 pg = d.prog[slot];
-  const Rec* recs = nullptr; L.text_lo = 0; L.text_hi = 0;
-  if (pg != ~0u) { ProgDev p = d.progs[pg]; recs = p.recs; L.text_lo = p.text_lo; L.text_hi = p.text_hi; }
-
-  L.h.pc = d.hot64[H64_PC * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.cycle = d.hot64[H64_CYCLE * S + slot];
-  L.h.instret = d.hot64[H64_INSTRET * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.retired = d.hot64[H64_RETIRED * S + slot];
-  L.h.thash = d.hot64[H64_THASH * S + slot]; L.h.lr_addr = d.hot64[H64_LR_ADDR * S + slot];
-  L.h.exec_last_ill = d.hot64[H64_EXEC_LAST_ILL * S + slot]; L.h.stop_value = d.hot64[H64_STOP_VALUE * S + slot];
-  L.h.fcsr = d.hot32[H32_FCSR * S + slot]; L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.status = d.hot32[H32_STATUS * S + slot];
-  L.h.consec_ill = d.hot32[H32_CONSEC_ILL * S + slot]; L.h.htif_dev = d.hot32[H32_HTIF_DEV * S + slot]; L.h.flags = d.hot32[H32_FLAGS * S + slot];
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
-  const u32 status_in = L.h.status;
-  if (!active) L.h.status = ST_STOP_LIMIT;
+  const u64 exec0 = L.h.exec;
+  const u64 stop_at = exec0 >= max_exec ? exec0 : ((max_exec - exec0 < max_steps) ? max_exec : exec0 + max_steps);
 
   if (active) {
     for (u32 r = 0; r < 32; ++r) L.m.wx(r, d.x[(size_t)r * S + slot]);
@@ -105,17 +168,23 @@ __global__ void __launch_bounds__(64) wsp_step_kernel(DevState d, u64 max_steps)
   }
   __syncthreads();
 
-  for (u64 it = 0; it < max_steps; ++it) {
-    bool run = L.h.status == ST_RUNNING;
-    if (run && L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; run = false; }
-    if (!__any(run)) break;                              // every lane of the wave has stopped
+  while (true) {
+    const bool run = L.h.status == ST_RUNNING && L.h.exec < stop_at;
+    if (!__any(run)) break;                              // every lane of the wave has stopped or used its budget
 
-    // ---- prologue: bookkeeping + fetch (Hart.cpp:6067-6120)
+    // ---- fetch: pre-decoded record for hot harts, everything else takes a complete cold step
     Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
-    u64 cur_pc = 0, a = 0, b = 0; u32 priv0 = 0;
-    bool todo = false;
-    if (run) todo = L.template step_begin<TRACE>(recs, rec, a, b, cur_pc, priv0);
-    const bool exed = todo;
+    bool todo = run && (L.h.flags & HF_HOT) && L.hot_fetch(recs, rec);
+    if (run && !todo) {
+      HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.flags = L.h.flags; hr.status = L.h.status;
+      hr = wsp_cold<TRACE>(dp, wave, ln, 0, 0, 0, 0, 0, 0, 0, 0, hr);
+      L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
+    }
+    const u64 cur_pc = L.h.pc;
+    const u64 a = L.m.rx(rec_rs1(rec));
+    const u64 b2 = L.m.rx(rec_rs2(rec));
+    const u64 b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : b2;
+    if (todo) { L.h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2); L.h.exec++; }
 
     // ---- dispatch: wave-uniform op, executed for every lane that fetched it
     const u32 op = rec.w0 & 0xff;
@@ -125,31 +194,36 @@ __global__ void __launch_bounds__(64) wsp_step_kernel(DevState d, u64 max_steps)
       const u32 lop = (u32)__builtin_amdgcn_readlane((int)op, leader);
       const bool mine = todo && op == lop;
       if (mine) {
-        if (FP || lop < OP_FLW) L.exec(lop, rec, a, b, cur_pc);
-        else L.stop(ST_STOP_UNSUPPORTED, 0xF);
+        // Launder the uniform op and the operands: without this the compiler (a) proves lop == op
+        // inside this branch and switches on the per-lane VGPR copy (a divergent, exec-masked
+        // switch), and (b) hoists every case body out of the dispatch loop because a and b are
+        // loop invariant, computing all ~40 results per step and spilling them.
+        u32 uop = lop; u64 aa = a, bb = b;
+        asm volatile("" : "+v"(uop), "+v"(aa), "+v"(bb));
+        uop = (u32)__builtin_amdgcn_readfirstlane((int)uop);
+        if (L.template exec_fast<TRACE>(uop, rec, aa, bb, cur_pc)) L.template trace_fast<TRACE>(rec, cur_pc);
+        else {
+          HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.flags = L.h.flags; hr.status = L.h.status;
+          hr = wsp_cold<TRACE>(dp, wave, ln, 1, uop, rec.w0, rec.imm, rec.raw, aa, bb, cur_pc, hr);
+          L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
+        }
         todo = false;
       }
       pend &= ~__ballot(mine);
     }
-
-    // ---- epilogue: retire + commit record
-    if (exed) L.template step_end<TRACE>(rec, cur_pc, priv0);
   }
 
   __syncthreads();
   if (active) {
+    if (L.h.status == ST_RUNNING && L.h.exec >= max_exec) L.h.status = ST_STOP_LIMIT;   // Hart.cpp:6025
     for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
     if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
-    d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_MSTATUS * S + slot] = L.h.mstatus; d.hot64[H64_CYCLE * S + slot] = L.h.cycle;
-    d.hot64[H64_INSTRET * S + slot] = L.h.instret; d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_RETIRED * S + slot] = L.h.retired;
-    d.hot64[H64_THASH * S + slot] = L.h.thash; d.hot64[H64_LR_ADDR * S + slot] = L.h.lr_addr;
-    d.hot64[H64_EXEC_LAST_ILL * S + slot] = L.h.exec_last_ill; d.hot64[H64_STOP_VALUE * S + slot] = L.h.stop_value;
-    d.hot32[H32_FCSR * S + slot] = L.h.fcsr; d.hot32[H32_PRIV * S + slot] = L.h.priv;
-    // a hart that only hit this slice's step budget (not its own instruction limit) stays RUNNING
-    d.hot32[H32_STATUS * S + slot] = L.h.status;
-    d.hot32[H32_CONSEC_ILL * S + slot] = L.h.consec_ill; d.hot32[H32_HTIF_DEV * S + slot] = L.h.htif_dev; d.hot32[H32_FLAGS * S + slot] = L.h.flags;
+    // bring the lazily synchronised counters up to date
+    const u64 dlt = L.h.exec - d.hot64[H64_EXEC * S + slot];
+    d.hot64[H64_CYCLE * S + slot] += dlt; d.hot64[H64_INSTRET * S + slot] += dlt; d.hot64[H64_RETIRED * S + slot] += dlt;
+    d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_THASH * S + slot] = L.h.thash;
+    d.hot32[H32_FLAGS * S + slot] = L.h.flags; d.hot32[H32_STATUS * S + slot] = L.h.status;
   }
-  (void)status_in;
   const unsigned long long still = __ballot(active && L.h.status == ST_RUNNING);
   if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
 }
@@ -313,6 +387,7 @@ struct wsp_batch {
   std::vector<Program> progs;
   std::vector<u32> hart_prog;          // host copy, index = hart
   ProgDev* d_progs = nullptr; size_t d_progs_cap = 0;
+  DevState* d_state = nullptr;
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
   double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
   bool has_fp = false;
@@ -347,7 +422,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
   if (!b) return;
   hipSetDevice(b->device);
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
-  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results };
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -380,7 +455,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     lpw = 64;
     while (lpw > 8 && (desc->n_harts + lpw - 1) / lpw < 1024) lpw >>= 1;
   }
-  if (lpw != 8 && lpw != 16 && lpw != 32 && lpw != 64) return fail(WSP_EINVAL, "lanes_per_wave must be 0, 8, 16, 32 or 64");
+  if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
   wsp_batch* b = new wsp_batch();
   b->device = dev;
   DevState& d = b->d;
@@ -396,7 +471,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
   ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
   ALLOC(d.cold, CI_COUNT * S * 8); ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
-  ALLOC(d.arena, arena_bytes); ALLOC(d.running, 4); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
+  ALLOC(d.arena, arena_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
 #undef ALLOC
   // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
   std::vector<u64> v64(S);
@@ -728,7 +803,9 @@ template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 s
 {
   DevState& d = b->d;
   size_t lds = (size_t)d.lpw * 32 * 8 * (FP ? 2 : 1);
-  hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, steps);
+  hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps);
   return hipGetLastError();
 }
 
