@@ -69,6 +69,9 @@ struct DevMem {
 #endif
 extern __shared__ __align__(16) u64 wsp_lds[];
 
+__device__ __forceinline__ u32 ln_of(const DevState& d)
+{ const u32 lane = threadIdx.x; return (lane < d.lpw && blockIdx.x * d.lpw + lane < d.n_harts) ? lane : 0; }
+
 __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
 {
   L.m.xs = wsp_lds + ln;
@@ -109,7 +112,7 @@ __device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevSt
 // cold steps; exec/cycle/instret/retired are synchronised lazily: a hot step advances all four by
 // exactly one (HF_HOT guarantees no inhibit, no trap), so the HBM copies are brought up to date
 // from the difference between the register exec counter and the stored one.
-struct HotRegs { u64 pc, exec, thash; u32 flags, status; };
+struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status; };
 
 // The general path, out of line: rebuilds the full lane from HBM, runs either one complete cold
 // step (mode 0) or the full exec()+retire of an instruction the hot prologue already fetched and
@@ -137,7 +140,7 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, u
   } else
     L.template cold_step<TRACE>();
   wsp_store_hot(L, d, slot);
-  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.flags = L.h.flags; r.status = L.h.status;
+  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status;
   return r;
 }
 
@@ -158,9 +161,24 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot];
   L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / flags
   L.s.chg = 0; L.s.ireg = 0; L.s.ival = 0; L.s.maddr = 0; L.s.mval = 0;
-  const u64 max_exec = d.max_exec[slot];
-  const u64 exec0 = L.h.exec;
-  const u64 stop_at = exec0 >= max_exec ? exec0 : ((max_exec - exec0 < max_steps) ? max_exec : exec0 + max_steps);
+  u64 stop_at;
+  {
+    const u64 max_exec = d.max_exec[slot], exec0 = L.h.exec;
+    stop_at = exec0 >= max_exec ? exec0 : ((max_exec - exec0 < max_steps) ? max_exec : exec0 + max_steps);
+  }
+  // A cold call is a context switch: every per-lane value of the hot loop is either passed through
+  // HotRegs or rebuilt from the kernel arguments afterwards, so nothing but SGPR kernel arguments is
+  // live across the call and the hot loop's register allocation is not shaped by the call ABI.
+#define WSP_COLD_CALL(MODE, OP, W0, IMM, RAW, A, B, PC)                                                        \
+  do {                                                                                                          \
+    HotRegs hr_; hr_.pc = L.h.pc; hr_.exec = L.h.exec; hr_.thash = L.h.thash; hr_.stop_at = stop_at;           \
+    hr_.flags = L.h.flags; hr_.status = L.h.status;                                                             \
+    hr_ = wsp_cold<TRACE>(dp, blockIdx.x, ln_of(d), MODE, OP, W0, IMM, RAW, A, B, PC, hr_);                    \
+    const u32 ln2_ = ln_of(d);                                                                                  \
+    wsp_lane_setup(L, d, blockIdx.x, ln2_, blockIdx.x * 64 + ln2_, recs);                                       \
+    L.h.pc = hr_.pc; L.h.exec = hr_.exec; L.h.thash = hr_.thash; stop_at = hr_.stop_at;                         \
+    L.h.flags = hr_.flags; L.h.status = hr_.status;                                                             \
+  } while (0)
 
   if (active) {
     for (u32 r = 0; r < 32; ++r) L.m.wx(r, d.x[(size_t)r * S + slot]);
@@ -175,11 +193,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     // ---- fetch: pre-decoded record for hot harts, everything else takes a complete cold step
     Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
     bool todo = run && (L.h.flags & HF_HOT) && L.hot_fetch(recs, rec);
-    if (run && !todo) {
-      HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.flags = L.h.flags; hr.status = L.h.status;
-      hr = wsp_cold<TRACE>(dp, wave, ln, 0, 0, 0, 0, 0, 0, 0, 0, hr);
-      L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
-    }
+    if (run && !todo) WSP_COLD_CALL(0, 0, 0, 0, 0, 0, 0, 0);
     const u64 cur_pc = L.h.pc;
     const u64 a = L.m.rx(rec_rs1(rec));
     const u64 b2 = L.m.rx(rec_rs2(rec));
@@ -202,11 +216,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         asm volatile("" : "+v"(uop), "+v"(aa), "+v"(bb));
         uop = (u32)__builtin_amdgcn_readfirstlane((int)uop);
         if (L.template exec_fast<TRACE>(uop, rec, aa, bb, cur_pc)) L.template trace_fast<TRACE>(rec, cur_pc);
-        else {
-          HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.flags = L.h.flags; hr.status = L.h.status;
-          hr = wsp_cold<TRACE>(dp, wave, ln, 1, uop, rec.w0, rec.imm, rec.raw, aa, bb, cur_pc, hr);
-          L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
-        }
+        else WSP_COLD_CALL(1, uop, rec.w0, rec.imm, rec.raw, aa, bb, cur_pc);
         todo = false;
       }
       pend &= ~__ballot(mine);
@@ -215,7 +225,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 
   __syncthreads();
   if (active) {
-    if (L.h.status == ST_RUNNING && L.h.exec >= max_exec) L.h.status = ST_STOP_LIMIT;   // Hart.cpp:6025
+    if (L.h.status == ST_RUNNING && L.h.exec >= d.max_exec[slot]) L.h.status = ST_STOP_LIMIT;   // Hart.cpp:6025
     for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
     if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
     // bring the lazily synchronised counters up to date
