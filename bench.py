@@ -93,11 +93,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import whisper_amd as W
+    from whisper_amd import shard
     from whisper_amd import workloads as WL
 
     prog = WL.compute_kernel(iters=args.iters, fp=not args.nofp)
     n = args.harts
-    base = rank * n
+    base, _ = shard.weak_range(n, rank)
+    gdev = torch.device("cuda", local_rank) if world > 1 else None
     b = W.Batch(n, isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, lanes_per_wave=args.lanes,
                 device=local_rank if world > 1 else -1, hart_id_base=base)
     b.load_elf_bytes(prog.elf)
@@ -120,9 +122,7 @@ def main():
         left = b.run(trace_hash=args.trace)
         res = b.results()
         if dist is not None:
-            rec = torch.frombuffer(bytearray(bytes(res)), dtype=torch.uint8).cuda()
-            out = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(out, rec)
+            shard.gather_results(bytes(res), dist, gdev)     # final gather of pass/fail + digests (RCCL)
         if left:
             raise RuntimeError(f"{left} harts still running")
         if timed:
@@ -141,13 +141,8 @@ def main():
 
     per_step_insts = sum(r.exec_count for r in res)
     ok = all(r.status == W.ST_STOP_TOHOST and r.stop_value == 1 for r in res)
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    tot = torch.tensor([float(per_step_insts)], dtype=torch.float64)
-    if dist is not None:
-        tmax = tmax.cuda(); tot = tot.cuda()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item()); total_insts = float(tot.item()) * args.steps
+    dt, tot = shard.reduce_totals(dt, float(per_step_insts), dist, gdev)
+    total_insts = tot * args.steps
 
     if rank == 0:
         # cheap end-to-end sanity against the oracle for a few harts of rank 0 (parity proper: tests/)

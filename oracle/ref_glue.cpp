@@ -14,6 +14,7 @@ extern "C" {
 }
 
 using namespace WdRiscv;
+extern "C" int ref_csr_name(unsigned num, char* buf, int n);
 
 static Decoder& dec(int rv64)
 {
@@ -46,7 +47,15 @@ int ref_disassemble(int rv64, uint32_t inst, char* buf, int n)
 {
   static Disassembler dis64, dis32;
   static bool init = false;
-  if (!init) { dis64.enableRv64(true); dis32.enableRv64(false); init = true; }
+  if (!init) {
+    dis64.enableRv64(true); dis32.enableRv64(false); init = true;
+    // Hart.cpp wires the disassembler to its CSR file the same way (CSR names instead of cNNN).
+    auto cb = [](unsigned ix) -> std::string_view {
+      static thread_local char nm[64];
+      return ref_csr_name(ix, nm, sizeof nm) ? std::string_view(nm) : std::string_view();
+    };
+    dis64.setCsrNameCallback(cb); dis32.setCsrNameCallback(cb);
+  }
   std::string s;
   (rv64 ? dis64 : dis32).disassembleInst(inst, dec(rv64), s);
   strncpy(buf, s.c_str(), n - 1);
@@ -61,5 +70,68 @@ uint32_t ref_expand16(int rv64, uint16_t inst) { return dec(rv64).expandCompress
 void     ref_sf_set_rm(int rm)   { softfloat_roundingMode = uint_fast8_t(rm); }
 void     ref_sf_clear_flags()    { softfloat_exceptionFlags = 0; }
 unsigned ref_sf_flags()          { return softfloat_exceptionFlags; }
+
+}
+
+// ---------------------------------------------------------------------------------------------
+// The reference's CSR file (CsRegs.hpp:935, CsRegs.cpp) standing alone: names for the
+// disassembler (what Hart does through setCsrNameCallback) and the architectural read/write/poke
+// masks, so the oracle's CSR restatement can be checked field by field.
+#include "CsRegs.hpp"
+
+namespace {
+// Most of CsRegs' configuration surface is protected (Hart is its friend); a derived class may
+// re-export it without touching the reference.
+struct OpenCsRegs : CsRegs<uint64_t> {
+  using Base = CsRegs<uint64_t>;
+  using Base::Base;
+  using Base::peek; using Base::poke; using Base::reset; using Base::enableSupervisorMode; using Base::enableUserMode;
+  using Base::enableRvc; using Base::enableRvf; using Base::enableZicntr; using Base::enableHypervisorMode; using Base::enableVector;
+};
+struct CsrBox {
+  PmpManager pmp;
+  PmaManager pma;
+  OpenCsRegs regs;
+  explicit CsrBox(uint64_t mem) : pma(mem), regs(pmp, pma) {}
+};
+CsrBox* g_names = nullptr;
+}
+
+extern "C" {
+
+// Hart::processExtensions order for the CSR-relevant switches (Hart.cpp:553-621), then reset (Hart.cpp:948).
+void* ref_csr_new(int rvs, int rvu, int rvf, int rvc, int zicntr)
+{
+  auto* b = new CsrBox(uint64_t(1) << 32);
+  b->regs.enableSupervisorMode(rvs);
+  b->regs.enableUserMode(rvu);
+  b->regs.enableHypervisorMode(false);
+  b->regs.enableRvc(rvc);
+  b->regs.enableRvf(rvf);
+  b->regs.enableVector(false);
+  b->regs.enableZicntr(zicntr);
+  b->regs.reset();
+  return b;
+}
+void ref_csr_free(void* p) { delete static_cast<CsrBox*>(p); }
+int ref_csr_read(void* p, unsigned num, unsigned priv, uint64_t* v)
+{ return static_cast<CsrBox*>(p)->regs.read(CsrNumber(num), PrivilegeMode(priv), *v); }
+int ref_csr_write(void* p, unsigned num, unsigned priv, uint64_t v)
+{ return static_cast<CsrBox*>(p)->regs.write(CsrNumber(num), PrivilegeMode(priv), v); }
+int ref_csr_peek(void* p, unsigned num, uint64_t* v)
+{ return static_cast<CsrBox*>(p)->regs.peek(CsrNumber(num), *v); }
+int ref_csr_poke(void* p, unsigned num, uint64_t v)
+{ return static_cast<CsrBox*>(p)->regs.poke(CsrNumber(num), v); }
+int ref_csr_implemented(void* p, unsigned num)
+{ auto* c = static_cast<CsrBox*>(p)->regs.findCsr(CsrNumber(num)); return c && c->isImplemented(); }
+int ref_csr_name(unsigned num, char* buf, int n)
+{
+  if (!g_names) g_names = new CsrBox(uint64_t(1) << 32);
+  auto* c = g_names->regs.findCsr(CsrNumber(num));
+  if (!c) return 0;
+  std::string s(c->getName());
+  strncpy(buf, s.c_str(), n - 1); buf[n - 1] = 0;
+  return int(s.size());
+}
 
 }

@@ -209,6 +209,15 @@ static u64 mstatus_read_mask(const rvo_hart* h)
   return m;
 }
 
+/* CY/TM/IR of m/scounteren read as zero while cycle/time/instret are not implemented (CsRegs.cpp:1524-1539, 2117-2130). */
+static u64 counteren_rmask(const rvo_hart* h) { return ext(h, RVO_ISA_ZICNTR) ? ~0ULL : ~7ULL; }
+
+/* CsRegs::enableRvc (CsRegs.hpp:2119-2127): xEPC bit 0 reads zero with C, bits 1:0 without; the stored value keeps bit 1. */
+static u64 epc_rmask(const rvo_hart* h) { return ext(h, RVO_ISA_C) ? ~1ULL : ~3ULL; }
+
+/* CsRegs::legalizeEnvcfg (CsRegs.cpp:6719-6727): a reserved CBIE value (2) keeps the old field. */
+static u64 legalize_envcfg(u64 prev, u64 next) { return ((next >> 4) & 3) == 2 ? (next & ~0x30ULL) | (prev & 0x30) : next; }
+
 static void record_csr(rvo_hart* h, unsigned num)
 {
   for (int i = 0; i < h->ch_ncsr; ++i) if (h->ch_csr[i] == num) return;   /* CsRegs.cpp:4673 */
@@ -250,17 +259,17 @@ static u64 csr_peek(const rvo_hart* h, unsigned num)
     case C_FRM: return (h->fcsr >> 5) & 7;
     case C_FCSR: return h->fcsr;
     case C_SSTATUS: return h->mstatus & SSTATUS_RMASK;
-    case C_SIE: return h->mie & h->mideleg & 0x2222;
-    case C_SIP: return h->mip & h->mideleg & 0x2222;
-    case C_STVEC: return h->stvec; case C_SCOUNTEREN: return h->scounteren; case C_SENVCFG: return h->senvcfg;
-    case C_SSCRATCH: return h->sscratch; case C_SEPC: return h->sepc; case C_SCAUSE: return h->scause;
+    case C_SIE: return h->mie & h->mideleg & ~0x1444ULL;                /* CsRegs::readSie (CsRegs.cpp:195-229) */
+    case C_SIP: return h->mip & h->mideleg & ~0x1444ULL;
+    case C_STVEC: return h->stvec; case C_SCOUNTEREN: return h->scounteren & counteren_rmask(h); case C_SENVCFG: return h->senvcfg;
+    case C_SSCRATCH: return h->sscratch; case C_SEPC: return h->sepc & epc_rmask(h); case C_SCAUSE: return h->scause;
     case C_STVAL: return h->stval; case C_SATP: return h->satp;
     case C_MSTATUS: return h->mstatus & mstatus_read_mask(h);
     case C_MISA: return misa_value();
     case C_MEDELEG: return h->medeleg; case C_MIDELEG: return h->mideleg; case C_MIE: return h->mie;
-    case C_MTVEC: return h->mtvec; case C_MCOUNTEREN: return h->mcounteren; case C_MENVCFG: return h->menvcfg;
+    case C_MTVEC: return h->mtvec; case C_MCOUNTEREN: return h->mcounteren & counteren_rmask(h); case C_MENVCFG: return h->menvcfg;
     case C_MCOUNTINHIBIT: return h->mcountinhibit;
-    case C_MSCRATCH: return h->mscratch; case C_MEPC: return h->mepc; case C_MCAUSE: return h->mcause;
+    case C_MSCRATCH: return h->mscratch; case C_MEPC: return h->mepc & epc_rmask(h); case C_MCAUSE: return h->mcause;
     case C_MTVAL: return h->mtval; case C_MIP: return h->mip;
     case C_MCYCLE: case C_CYCLE: return h->cycle;
     case C_MINSTRET: case C_INSTRET: return h->instret;
@@ -278,16 +287,20 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record);
 int rvo_poke_csr(rvo_hart* h, unsigned num, u64 v)
 { if (csr_class(h, num) != 1) return -1; csr_store(h, num, v, 0); h->ch_ncsr = 0; return 0; }
 
+/* M ecall (11), double trap (16), reserved (17) hardwired zero (CsRegs.cpp:4726-4732); VS ecall (10) and the guest
+ * page fault / virtual instruction causes (23:20) read as zero without H (CsRegs.cpp:1780-1788). */
+#define MEDELEG_MASK (~((1ULL << 11) | (1ULL << 16) | (1ULL << 17) | (0xFULL << 20) | (1ULL << 10)))
+#define MIE_WMASK(h) (0x999ULL | (ext(h, RVO_ISA_S) ? 0x222ULL : 0))
+#define MIP_WMASK(h) (ext(h, RVO_ISA_S) ? 0x222ULL : 0)           /* CsRegs.cpp:4770 read-only + S bits (CsRegs.cpp:1509-1521) */
 /* Value update of CsRegs::write (CsRegs.cpp:3908-4165) for the modelled subset. */
 static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
 {
-  int c = ext(h, RVO_ISA_C);
   switch (num) {
     case C_FFLAGS: h->fcsr = (h->fcsr & ~0x1fULL) | (v & 0x1f); break;         /* CsRegs.cpp:4462-4472 */
     case C_FRM:    h->fcsr = (h->fcsr & ~0xe0ULL) | ((v & 7) << 5); break;
     case C_FCSR:   h->fcsr = v & 0xff; break;
     case C_MSTATUS: {                                                           /* CsRegs.cpp:3964-3976 */
-      u64 nv = (h->mstatus & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK);
+      u64 nv = (h->mstatus & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK & mstatus_read_mask(h));   /* value &= writeMask & readMask */
       h->mstatus = legalize_mstatus(h, nv);
       break; }
     case C_SSTATUS: {
@@ -296,22 +309,22 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
       h->mstatus = legalize_mstatus(h, nv);
       break; }
     case C_MISA: break;                                                         /* write mask 0 */
-    case C_MEDELEG: h->medeleg = v & ~((1ULL << 11) | (1ULL << 16) | (1ULL << 14)) ; break;  /* CsRegs.cpp:4728-4732 */
-    case C_MIDELEG: h->mideleg = v & 0x222; break;
-    case C_MIE: { u64 m = 0x888 | (ext(h, RVO_ISA_S) ? 0x222 : 0); h->mie = (h->mie & ~m) | (v & m); break; }
-    case C_MIP: { u64 m = ext(h, RVO_ISA_S) ? 0x222 : 0; h->mip = (h->mip & ~m) | (v & m); break; }
-    case C_SIE: { u64 m = h->mideleg & 0x222; h->mie = (h->mie & ~m) | (v & m); break; }
-    case C_SIP: { u64 m = h->mideleg & 0x002; h->mip = (h->mip & ~m) | (v & m); break; }
+    case C_MEDELEG: h->medeleg = v & MEDELEG_MASK; break;
+    case C_MIDELEG: h->mideleg = v & ~0x1444ULL; break;       /* CsRegs.cpp:4734 all bits; VS/SGEI read-only zero without H (CsRegs.cpp:1766-1771) */
+    case C_MIE: { u64 m = MIE_WMASK(h);   /* CsRegs.cpp:4739: 0xfff less S/VS bits; legacy U bits 0,4,8 writable */ h->mie = (h->mie & ~m) | (v & m); break; }
+    case C_MIP: { u64 m = MIP_WMASK(h); h->mip = (h->mip & ~m) | (v & m); break; }
+    case C_SIE: { u64 m = 0x222ULL & MIE_WMASK(h) & h->mideleg; h->mie = (h->mie & ~m) | (v & m); break; }   /* CsRegs::writeSie (CsRegs.cpp:2745-2790) */
+    case C_SIP: { u64 m = 0x002ULL & MIP_WMASK(h) & h->mideleg; h->mip = (h->mip & ~m) | (v & m); break; }   /* CsRegs::writeSip (CsRegs.cpp:2680-2740) */
     case C_MTVEC: h->mtvec = v & ~2ULL; break;
     case C_STVEC: h->stvec = v & ~2ULL; break;
     case C_MCOUNTEREN: h->mcounteren = v & 0xffffffffULL; break;
     case C_SCOUNTEREN: h->scounteren = v; break;
-    case C_MENVCFG: h->menvcfg = v & 0xe0000003000000f5ULL; break;
-    case C_SENVCFG: h->senvcfg = v & 0x00000003000000f5ULL; break;
+    case C_MENVCFG: h->menvcfg = legalize_envcfg(h->menvcfg, v) & 0xe0000003000000f5ULL; break;
+    case C_SENVCFG: h->senvcfg = legalize_envcfg(h->senvcfg, v) & 0x00000003000000f5ULL; break;
     case C_MCOUNTINHIBIT: h->mcountinhibit = v & 0xfffffffdULL; break;
     case C_MSCRATCH: h->mscratch = v; break;
     case C_SSCRATCH: h->sscratch = v; break;
-    case C_MEPC: h->mepc = v & ~1ULL; (void)c; break;
+    case C_MEPC: h->mepc = v & ~1ULL; break;
     case C_SEPC: h->sepc = v & ~1ULL; break;
     case C_MCAUSE: h->mcause = v; break;
     case C_SCAUSE: h->scause = v; break;
@@ -418,6 +431,53 @@ static void take_exception_ex(rvo_hart* h, unsigned cause, u64 epc, u64 tval, in
     tvec = h->stvec;
   }
   h->pc = (tvec & ~3ULL) & ~1ULL;
+}
+
+/* Hart::isInterruptPossible (Hart.cpp:7028-7083, 7135-7157) without H/AIA/NMI: pending = mip (no SEI pin,
+ * no timer source in a bare system), M-destined = mip & mie & ~mideleg, S-destined = mip & mie & mideleg. */
+static int interrupt_possible(const rvo_hart* h, unsigned* cause, unsigned* next)
+{
+  static const unsigned char m_order[] = { 11, 3, 7, 9, 1, 5, 12, 13 };                 /* mInterrupts_ (Hart.cpp:141-143) */
+  static const unsigned char s_order[] = { 11, 3, 7, 9, 1, 5, 12, 10, 2, 6, 13 };       /* sInterrupts_ (Hart.cpp:146-149) */
+  u64 pend = h->mip & h->mie;
+  if (!pend) return 0;
+  u64 mdest = pend & ~h->mideleg;
+  if (((h->mstatus & MST_MIE) || h->priv != PRV_M) && mdest)
+    for (unsigned i = 0; i < sizeof m_order; ++i)
+      if ((mdest >> m_order[i]) & 1) { *cause = m_order[i]; *next = PRV_M; return 1; }
+  if (h->priv == PRV_M) return 0;
+  u64 sdest = pend & h->mideleg;
+  if (((h->mstatus & MST_SIE) || h->priv == PRV_U) && sdest)
+    for (unsigned i = 0; i < sizeof s_order; ++i)
+      if ((sdest >> s_order[i]) & 1) { *cause = s_order[i]; *next = PRV_S; return 1; }
+  return 0;
+}
+
+/* Hart::initiateInterrupt -> initiateTrap(interrupt=true) (Hart.cpp:3287-3300, 3565-3905). */
+static void take_interrupt(rvo_hart* h, unsigned cause, unsigned next, u64 epc)
+{
+  unsigned orig = h->priv;
+  h->priv = next;
+  u64 cv = (1ULL << 63) | cause, tvec;
+  if (next == PRV_M) {
+    csr_store(h, C_MEPC, epc & ~1ULL, 1); csr_store(h, C_MCAUSE, cv, 1); csr_store(h, C_MTVAL, 0, 1);
+    u64 v = h->mstatus;
+    v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)orig << MST_MPP_SH);
+    v = (v & ~MST_MPIE) | ((v & MST_MIE) ? MST_MPIE : 0);
+    v &= ~MST_MIE;
+    write_mstatus_raw(h, v);
+    tvec = h->mtvec;
+  } else {
+    csr_store(h, C_SEPC, epc & ~1ULL, 1); csr_store(h, C_SCAUSE, cv, 1); csr_store(h, C_STVAL, 0, 1);
+    u64 v = h->mstatus;
+    v = (v & ~MST_SPP) | ((u64)(orig & 1) << 8);
+    v = (v & ~MST_SPIE) | ((v & MST_SIE) ? MST_SPIE : 0);
+    v &= ~MST_SIE;
+    h->mstatus = v; record_csr(h, C_SSTATUS);
+    tvec = h->stvec;
+  }
+  u64 base = tvec & ~3ULL;
+  h->pc = (tvec & 3) == 1 ? base + 4ULL * cause : base;      /* vectored mode applies to interrupts only (Hart.cpp:3849-3853) */
 }
 
 /* di == nullptr call sites: illegal, ecall, ebreak, fetch faults, misaligned targets. */
@@ -854,7 +914,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
           v |= MST_MPIE;
           if (saved != PRV_M) v &= ~MST_MPRV;
           csr_store(h, C_MSTATUS, v, 1);
-          h->pc = h->mepc & ~1ULL; h->priv = saved; return;
+          h->pc = h->mepc & epc_rmask(h); h->priv = saved; return;      /* readSignExtend(MEPC) applies the read mask */
         }
         if (inst == 0x10200073) {                                                              /* sret: Hart.cpp:12428-12560 */
           if (!ext(h, RVO_ISA_S)) goto ill;
@@ -866,7 +926,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
           v |= MST_SPIE;
           v &= ~MST_MPRV;                                    /* savedMode is never M for sret */
           h->mstatus = legalize_mstatus(h, v); record_csr(h, C_SSTATUS);
-          h->pc = h->sepc & ~1ULL; h->priv = saved; return;
+          h->pc = h->sepc & epc_rmask(h); h->priv = saved; return;
         }
         if (inst == 0x10500073) {                                                              /* wfi: Hart.cpp:12618 */
           if (h->priv == PRV_U && ext(h, RVO_ISA_S)) goto ill;
@@ -1134,6 +1194,22 @@ int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)
     if (!(h->mcountinhibit & 1)) h->cycle++;                 /* Hart.cpp:6072-6074 */
     unsigned priv0 = h->priv;
     u32 inst = 0; u64 tval = 0;
+    {                                                        /* processExternalInterrupt (Hart.cpp:7216-7262) */
+      unsigned icause, inext;
+      if (interrupt_possible(h, &icause, &inext)) {
+        if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); break; }
+        /* the interrupted instruction is read for the log only: PMA check, no PMP, no trap (Hart::readInst, Hart.cpp:2997) */
+        u32 iw = 0;
+        if (in_mem(h, h->pc, 2)) {
+          iw = (u32)ld_le(h->mem + (h->pc - h->cfg.mem_base), 2);
+          if ((iw & 3) == 3 && in_mem(h, h->pc + 2, 2)) iw |= (u32)ld_le(h->mem + (h->pc + 2 - h->cfg.mem_base), 2) << 16;
+        }
+        take_interrupt(h, icause, inext, h->pc);
+        if (!(h->mcountinhibit & 1)) h->cycle++;             /* Hart.cpp:7255-7256 */
+        finish_commit(h, iw, (iw & 3) == 3 ? 4 : 2, priv0, 2, log, cap, n);
+        continue;
+      }
+    }
     int fr = fetch(h, h->pc, &inst, &tval);
     if (fr == 2) break;
     if (fr == 1) {
@@ -1189,7 +1265,7 @@ u64 rvo_state_hash(const rvo_hart* h)
       case C_FCSR: v = h->fcsr; break; case C_STVEC: v = h->stvec; break; case C_SCOUNTEREN: v = h->scounteren; break;
       case C_SENVCFG: v = h->senvcfg; break; case C_SSCRATCH: v = h->sscratch; break; case C_SEPC: v = h->sepc; break;
       case C_SCAUSE: v = h->scause; break; case C_STVAL: v = h->stval; break; case C_SATP: v = h->satp; break;
-      case C_MSTATUS: v = h->mstatus; break;
+      case C_MSTATUS: v = h->mstatus; break; case C_MCOUNTEREN: v = h->mcounteren; break; case C_MEPC: v = h->mepc; break;
       default: v = csr_peek(h, num); break;
     }
     s = rvo_fold(s, v);

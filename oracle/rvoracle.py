@@ -229,6 +229,11 @@ def format_commit(c, hart_ix=0, disasm=None) -> str:
     (printTrace.cpp:139-209, 302-517): continuation lines joined by '  +\\n'."""
     op = f"{c.inst:08x}" if c.size == 4 else f"{c.inst & 0xffff:04x}"
     txt = disasm if disasm is not None else ""
+    # printTrace.cpp:338-346 appends the data address of scalar loads/stores; the commit record carries it for
+    # stores (the m change) only, so load lines lack the suffix (text-log parity is SURVEY 8f row 2, not this round)
+    for kind, key, _ in c.changes():
+        if kind == CH_M:
+            txt += f" [0x{key:x}]"
     if c.trap == 1:
         txt += " (exception)"
     elif c.trap == 2:

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Transcribe the reference traces captured in SURVEY.md Appendix D into JSON fixtures.
+
+The traces were produced by the real reference (Whisper v1.861 System/Hart driven directly) in the
+survey session; they are the only outputs of the reference run loop available offline (Hart.cpp needs
+Boost, which this image lacks, so the run loop itself is unbuildable here - DESIGN.md section 3).
+This script only extracts text: program words come from the opcode column of the log itself.
+
+  python tests/golden/make_appendix_d.py [SURVEY.md]   ->  tests/golden/appendix_d.json
+"""
+import json
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LINE = re.compile(r"^#(\d+) (\d+) +([MSU]) ([0-9a-f]{16}) +([0-9a-f]{4,8}) ([rfmcv]) ([0-9a-f]{16}) ([0-9a-f]{16}) ?(.*?)(  \+)?$")
+
+
+def blocks(text):
+    app = text[text.index("## Appendix D"):]
+    return re.findall(r"```\n(.*?)```", app, flags=re.S)
+
+
+def parse(block):
+    recs, extra = [], []
+    for ln in block.splitlines():
+        m = LINE.match(ln.rstrip())
+        if m:
+            tag, hart, priv, pc, op, kind, key, val, txt, cont = m.groups()
+            recs.append(dict(tag=int(tag), hart=int(hart), priv=priv, pc=int(pc, 16), op=op, kind=kind, key=int(key, 16),
+                             val=int(val, 16), text=txt.rstrip(), cont=bool(cont)))
+        else:
+            extra.append(ln)
+    return recs, extra
+
+
+def main():
+    survey = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "..", "SURVEY.md")
+    bl = blocks(open(survey).read())
+    fp_recs, fp_extra = parse(bl[0])
+    # program image = opcode column of the records at their pcs (first trace only; all 4-byte)
+    words = {}
+    for r in fp_recs:
+        if r["pc"] >= 0x80000000 and len(r["op"]) == 8:
+            words[r["pc"]] = int(r["op"], 16)
+    final = {}
+    for ln in fp_extra:
+        if ln.startswith("final:"):
+            for k, v in re.findall(r"(\w+)=([0-9a-fx]+)", ln):
+                final[k] = int(v, 16)
+        m = re.match(r"Info: Executed (\d+) instructions and retired (\d+)", ln)
+        if m:
+            final["executed"], final["retired"] = int(m.group(1)), int(m.group(2))
+    sv_recs, _ = parse(bl[2])
+    out = {
+        "source": "SURVEY.md Appendix D (reference Whisper v1.861, captured by the survey session)",
+        "fp_trap": {"isa": "rv64imafdcv_zicsr", "base": 0x80000000, "words": [words[a] for a in sorted(words)],
+                    "records": fp_recs, "final": final,
+                    "stop": "Failed stop: Hart 0: 16 consecutive illegal instructions"},
+        "sv39_first": {"isa": "rv64imafdcsu_zicsr", "records": [r for r in sv_recs if r["tag"] == 1],
+                       "pokes": {"mstatus_mpp": 1, "mepc": 0x40000100}, "next_pc": 0x40000100, "next_priv": "S"},
+    }
+    with open(os.path.join(HERE, "appendix_d.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("records:", len(fp_recs), "words:", [hex(w) for w in out["fp_trap"]["words"]], "final:", final)
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,7 @@ u64 hs_get_f(Sim* s, u32 i) { return s->L.m.f[i & 31]; }
 void hs_set_f(Sim* s, u32 i, u64 v) { s->L.m.f[i & 31] = v; }
 u64 hs_get_pc(Sim* s) { return s->L.h.pc; }
 u64 hs_csr(Sim* s, u32 num) { return s->L.csr_peek(num); }
+u64 hs_cold_raw(Sim* s, u32 ix) { return ix < CI_COUNT ? s->L.m.cold_[ix] : 0; }
 void hs_poke_csr(Sim* s, u32 num, u64 v) { s->L.csr_store(num, v); s->L.s.chg = 0; }
 int hs_run(Sim* s, u64 max_exec, int trace)
 {

@@ -111,6 +111,16 @@ def test_fuzz_programs():
     _check(progs, res)
 
 
+def test_fuzz_programs_with_interrupts():
+    """S/U-enabled ISA, software-raised supervisor interrupts taken in M mode (direct and vectored mtvec), random
+    mie/mip/mideleg/sie/sip traffic: trace hash covers every interrupt record."""
+    progs = [WL.fuzz_program(s, n=300, interrupts=True) for s in range(120)]
+    b, left, res = _run_batch(progs)
+    b.close()
+    assert left == 0
+    _check(progs, res)
+
+
 def test_instruction_limit_and_peek_poke():
     p = WL.compute_kernel(iters=1)
     b = W.Batch(3, isa=p.isa, mem_base=p.mem_base, mem_size=p.mem_size)

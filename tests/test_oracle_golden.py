@@ -1,0 +1,98 @@
+"""Pin the CPU oracle against the reference outputs held in tests/golden/ (SURVEY.md Appendix D,
+captured from the real reference) - CPU only."""
+import json
+import os
+
+import pytest
+
+from simutil import rvoracle
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_d.json")))
+KIND = {"r": rvoracle.CH_R, "f": rvoracle.CH_F, "m": rvoracle.CH_M, "c": rvoracle.CH_C, "v": rvoracle.CH_V}
+
+
+def _group(records):
+    out = {}
+    for r in records:
+        out.setdefault(r["tag"], []).append(r)
+    return out
+
+
+def _run_fp_trap():
+    g = GOLD["fp_trap"]
+    # reference run: 4 GiB RAM from 0, program poked at 0x80000000, mtvec=0 (trap vector = zeroed RAM)
+    h = rvoracle.Hart(isa="rv64imafdc_zicsr", mem_base=0, mem_size=0x80000000 + (1 << 16), reset_pc=g["base"])
+    img = b"".join(w.to_bytes(4, "little") for w in g["words"])
+    h.write_mem(g["base"], img)
+    st, log = h.run(1 << 20, log_cap=64)
+    return g, h, st, log
+
+
+def test_fp_trap_trace_records():
+    g, h, st, log = _run_fp_trap()
+    gold = _group(g["records"])
+    by_tag = {c.tag: c for c in log}
+    assert len(log) == g["final"]["executed"]
+    for tag, recs in gold.items():
+        c = by_tag[tag]
+        assert c.pc == recs[0]["pc"], tag
+        op = f"{c.inst:08x}" if c.size == 4 else f"{c.inst & 0xffff:04x}"
+        assert op == recs[0]["op"], tag
+        assert rvoracle.PRIV_STR[c.priv] == recs[0]["priv"]
+        want = [(KIND[r["kind"]], r["key"], r["val"]) for r in recs]
+        if recs[-1]["cont"]:          # capture elided the rest of this record ("... identical ...")
+            assert c.changes()[:len(want)] == want, f"tag {tag}"
+        else:
+            assert c.changes() == want, f"tag {tag}"
+        assert (c.trap == 1) == ("(exception)" in recs[0]["text"]), tag
+    # the capture states #8..#23 are identical illegal-instruction traps at pc 0: mepc=0, mcause=2, mtval=0
+    assert by_tag[8].changes()[1:] == [(KIND["c"], 0x341, 0), (KIND["c"], 0x342, 2), (KIND["c"], 0x343, 0)]
+    for tag in range(9, 24):
+        assert by_tag[tag].changes() == by_tag[8].changes() and by_tag[tag].pc == 0 and by_tag[tag].trap == 1
+
+
+def test_fp_trap_final_state():
+    g, h, st, log = _run_fp_trap()
+    f = g["final"]
+    assert st == rvoracle.STOP_ILLEGAL and h.stop_value == 3            # "16 consecutive illegal instructions"
+    assert (h.exec_count, h.retired) == (f["executed"], f["retired"])
+    assert h.pc == f["pc"] and h.f(2) == f["f2"]
+    assert h.csr(0x300) == f["mstatus"] and h.csr(0x342) == f["mcause"] and h.csr(0x341) == f["mepc"]
+    assert h.csr(0xB00) == f["mcycle"] and h.csr(0xB02) == f["minstret"]
+
+
+@pytest.mark.skipif(rvoracle.ref() is None, reason="oracle/_ref (reference Disassembler) not built")
+def test_fp_trap_log_text():
+    """Full text lines, disassembly by the reference's own Disassembler compiled into oracle/_ref."""
+    g, h, st, log = _run_fp_trap()
+    gold = _group(g["records"])
+    for c in log:
+        if c.tag not in gold:
+            continue
+        recs = gold[c.tag]
+        is_fetch_fault_or_zero = c.size == 2 and (c.inst & 0xffff) == 0
+        dis = "illegal" if is_fetch_fault_or_zero else rvoracle.ref_disassemble(c.inst)
+        got = [ln.rstrip() for ln in rvoracle.format_commit(c, 0, dis).split("\n")]
+        want = []
+        for r in recs:
+            op = r["op"]
+            want.append((f"#{r['tag']} {r['hart']}  {r['priv']} {r['pc']:016x} {op:>8s} {r['kind']} {r['key']:016x} {r['val']:016x} "
+                         f"{r['text']}").rstrip() + ("  +" if r["cont"] else ""))
+        if recs[-1]["cont"]:
+            got = got[:len(want)]
+        assert got == want, c.tag
+
+
+def test_sv39_sample_first_record_mret():
+    g = GOLD["sv39_first"]
+    r = g["records"][0]
+    h = rvoracle.Hart(isa="rv64imafdcsu_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+    h.write_mem(0x80000000, int(r["op"], 16).to_bytes(4, "little"))
+    ms = h.csr(0x300)
+    h.set_csr(0x300, (ms & ~(3 << 11)) | (g["pokes"]["mstatus_mpp"] << 11))
+    h.set_csr(0x341, g["pokes"]["mepc"])
+    st, log = h.run(1, log_cap=4)
+    c = log[0]
+    assert (c.tag, c.pc, c.inst) == (1, r["pc"], int(r["op"], 16))
+    assert c.changes() == [(KIND[r["kind"]], r["key"], r["val"])]
+    assert h.pc == g["next_pc"] and rvoracle.PRIV_STR[h.priv] == g["next_priv"]

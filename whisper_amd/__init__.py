@@ -18,6 +18,7 @@ ST_RUNNING, ST_STOP_TOHOST, ST_STOP_ILLEGAL, ST_STOP_LIMIT, ST_STOP_UNSUPPORTED 
 RES_PC, RES_X, RES_F, RES_CSR, RES_MEM = range(5)
 RUN_TRACE_HASH = 1
 LOAD_EXEC = 1
+OK, EINVAL, ENODEV, ENOMEM, EIO, EFORMAT, ERANGE, EUNSUPPORTED, EHIP = 0, -1, -2, -3, -4, -5, -6, -7, -8
 NO_LIMIT = 2**64 - 1
 
 

@@ -319,6 +319,9 @@ static constexpr u64 MST_SIE = 1ULL << 1, MST_MIE = 1ULL << 3, MST_SPIE = 1ULL <
 static constexpr u64 MST_MPRV = 1ULL << 17, MST_TVM = 1ULL << 20, MST_TW = 1ULL << 21, MST_TSR = 1ULL << 22, MST_SD = 1ULL << 63;
 static constexpr int MST_VS_SH = 9, MST_MPP_SH = 11, MST_FS_SH = 13, MST_XS_SH = 15;
 static constexpr u64 MSTATUS_WMASK = 0x7FFFAAULL;             // CsRegs.cpp:4704
+// medeleg: M ecall (11), double trap (16), reserved (17) hardwired zero (CsRegs.cpp:4726-4732); VS ecall (10) and the
+// guest page fault / virtual instruction causes (23:20) read as zero without H (CsRegs.cpp:1780-1788)
+static constexpr u64 MEDELEG_MASK = ~((1ULL << 11) | (1ULL << 16) | (1ULL << 17) | (0xFULL << 20) | (1ULL << 10));
 static constexpr u64 SSTATUS_WMASK = 0x000DE722ULL;           // CsRegs.cpp:4979
 static constexpr u64 SSTATUS_RMASK = 0x80000003000DE762ULL;   // CsRegs.cpp:4990
 static constexpr u64 MISA_RESET = 0x800000000034112dULL;      // CsRegs.cpp:4721-4724 (read-only)
@@ -412,6 +415,71 @@ template <class MEM> struct Lane {
   }
   WSP_HD void illegal(const Rec& r, u64 cur_pc) { take_exception(2, cur_pc, r.raw, true); }
 
+  // ---- interrupts: Hart::isInterruptPossible (Hart.cpp:7028-7083, 7135-7157) without H/AIA/NMI.  A bare system has no
+  // timer or external source, so pending = mip as software left it; M-destined = mip & mie & ~mideleg, S-destined =
+  // mip & mie & mideleg.  Priority order = mInterrupts_ / sInterrupts_ (Hart.cpp:141-149).
+  WSP_HD bool interrupt_possible(u32& cause, u32& next)
+  {
+    const u64 pend = m.cold(CI_MIP) & m.cold(CI_MIE);
+    if (!pend) return false;
+    const u64 deleg = m.cold(CI_MIDELEG);
+    const u64 mdest = pend & ~deleg;
+    if (((h.mstatus & MST_MIE) || h.priv != PRV_M) && mdest) {
+      const u8 order[8] = { 11, 3, 7, 9, 1, 5, 12, 13 };
+      for (u32 i = 0; i < 8; ++i) if ((mdest >> order[i]) & 1) { cause = order[i]; next = PRV_M; return true; }
+    }
+    if (h.priv == PRV_M) return false;
+    const u64 sdest = pend & deleg;
+    if (((h.mstatus & MST_SIE) || h.priv == PRV_U) && sdest) {
+      const u8 order[11] = { 11, 3, 7, 9, 1, 5, 12, 10, 2, 6, 13 };
+      for (u32 i = 0; i < 11; ++i) if ((sdest >> order[i]) & 1) { cause = order[i]; next = PRV_S; return true; }
+    }
+    return false;
+  }
+  // Hart::initiateInterrupt -> initiateTrap(interrupt = true) (Hart.cpp:3287-3300, 3565-3905)
+  WSP_HD void take_interrupt(u32 cause, u32 next, u64 epc)
+  {
+    const u32 orig = h.priv;
+    h.priv = next;
+    const u64 cv = (1ULL << 63) | cause;
+    u64 tvec, v = h.mstatus;
+    if (next == PRV_M) {
+      m.cold(CI_MEPC) = epc & ~1ULL; m.cold(CI_MCAUSE) = cv; m.cold(CI_MTVAL) = 0;
+      v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)orig << MST_MPP_SH);
+      v = (v & ~MST_MPIE) | ((v & MST_MIE) ? MST_MPIE : 0);
+      v &= ~MST_MIE;
+      s.chg |= CH_MSTATUS | CH_MEPC | CH_MCAUSE | CH_MTVAL;
+      tvec = m.cold(CI_MTVEC);
+    } else {
+      m.cold(CI_SEPC) = epc & ~1ULL; m.cold(CI_SCAUSE) = cv; m.cold(CI_STVAL) = 0;
+      v = (v & ~MST_SPP) | ((u64)(orig & 1) << 8);
+      v = (v & ~MST_SPIE) | ((v & MST_SIE) ? MST_SPIE : 0);
+      v &= ~MST_SIE;
+      s.chg |= CH_SSTATUS | CH_SEPC | CH_SCAUSE | CH_STVAL;
+      tvec = m.cold(CI_STVEC);
+    }
+    h.mstatus = v;
+    const u64 base = tvec & ~3ULL;
+    h.pc = (tvec & 3) == 1 ? base + 4ULL * cause : base;     // vectored mode: interrupts only (Hart.cpp:3849-3853)
+  }
+  // processExternalInterrupt (Hart.cpp:7216-7262): returns true when the step was consumed by an interrupt
+  template <bool TRACE> WSP_HD bool poll_interrupt(u64 cur_pc, u32 priv0)
+  {
+    u32 cause, next;
+    if (!interrupt_possible(cause, next)) return false;
+    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
+    // the interrupted instruction is read for the log only: PMA check, no PMP, no trap (Hart::readInst, Hart.cpp:2997)
+    u32 iw = 0;
+    if (in_mem(cur_pc, 2)) {
+      iw = m.ld16(cur_pc - mem_base);
+      if ((iw & 3) == 3 && in_mem(cur_pc + 2, 2)) iw |= (u32)m.ld16(cur_pc + 2 - mem_base) << 16;
+    }
+    take_interrupt(cause, next, cur_pc);
+    if (!(h.flags & HF_INH_CY)) h.cycle++;                   // Hart.cpp:7255-7256
+    commit<TRACE>(cur_pc, iw, (iw & 3) == 3 ? 4 : 2, priv0, 2);
+    return true;
+  }
+
   // ---- data access checks (determineLoad/StoreException, Hart.cpp:1988-2154, 13786-13935)
   WSP_HD u32 eff_priv() const { return ((h.mstatus & MST_MPRV) && h.priv == PRV_M) ? (u32)((h.mstatus >> MST_MPP_SH) & 3) : h.priv; }   // Hart.hpp:3444
   // PMP with no programmed entry: M allowed, S/U denied (PmpManager.hpp:155-177)
@@ -499,6 +567,12 @@ template <class MEM> struct Lane {
     if (num == 0x747 || (num >= 0x7B0 && num <= 0x7B3)) return -1;
     return 0;
   }
+  // CY/TM/IR of m/scounteren read as zero while cycle/time/instret are not implemented (CsRegs.cpp:1524-1539, 2117-2130)
+  WSP_HD u64 counteren_rmask() const { return ext(ISA_ZICNTR) ? ~0ULL : ~7ULL; }
+  // CsRegs::enableRvc (CsRegs.hpp:2119-2127): xEPC bit 0 reads zero with C, bits 1:0 without; the stored value keeps bit 1
+  WSP_HD u64 epc_rmask() const { return ext(ISA_C) ? ~1ULL : ~3ULL; }
+  // CsRegs::legalizeEnvcfg (CsRegs.cpp:6719): a reserved CBIE (2) keeps the previous field value
+  WSP_HD static u64 legalize_envcfg(u64 prev, u64 next) { return ((next >> 4) & 3) == 2 ? (next & ~0x30ULL) | (prev & 0x30) : next; }
   WSP_HD u64 csr_peek(u32 num)
   {
     switch (num) {
@@ -506,17 +580,17 @@ template <class MEM> struct Lane {
       case C_FRM: return (h.fcsr >> 5) & 7;
       case C_FCSR: return h.fcsr;
       case C_SSTATUS: return h.mstatus & SSTATUS_RMASK;
-      case C_SIE: return m.cold(CI_MIE) & m.cold(CI_MIDELEG) & 0x2222;
-      case C_SIP: return m.cold(CI_MIP) & m.cold(CI_MIDELEG) & 0x2222;
-      case C_STVEC: return m.cold(CI_STVEC); case C_SCOUNTEREN: return m.cold(CI_SCOUNTEREN); case C_SENVCFG: return m.cold(CI_SENVCFG);
-      case C_SSCRATCH: return m.cold(CI_SSCRATCH); case C_SEPC: return m.cold(CI_SEPC); case C_SCAUSE: return m.cold(CI_SCAUSE);
+      case C_SIE: return m.cold(CI_MIE) & m.cold(CI_MIDELEG) & ~0x1444ULL;   // CsRegs::readSie (CsRegs.cpp:195-229)
+      case C_SIP: return m.cold(CI_MIP) & m.cold(CI_MIDELEG) & ~0x1444ULL;
+      case C_STVEC: return m.cold(CI_STVEC); case C_SCOUNTEREN: return m.cold(CI_SCOUNTEREN) & counteren_rmask(); case C_SENVCFG: return m.cold(CI_SENVCFG);
+      case C_SSCRATCH: return m.cold(CI_SSCRATCH); case C_SEPC: return m.cold(CI_SEPC) & epc_rmask(); case C_SCAUSE: return m.cold(CI_SCAUSE);
       case C_STVAL: return m.cold(CI_STVAL); case C_SATP: return m.cold(CI_SATP);
       case C_MSTATUS: return (ext(ISA_F) || ext(ISA_S)) ? h.mstatus : (h.mstatus & ~(3ULL << MST_FS_SH));   // CsRegs.cpp:1977-1987
       case C_MISA: return MISA_RESET;
       case C_MEDELEG: return m.cold(CI_MEDELEG); case C_MIDELEG: return m.cold(CI_MIDELEG); case C_MIE: return m.cold(CI_MIE);
-      case C_MTVEC: return m.cold(CI_MTVEC); case C_MCOUNTEREN: return m.cold(CI_MCOUNTEREN); case C_MENVCFG: return m.cold(CI_MENVCFG);
+      case C_MTVEC: return m.cold(CI_MTVEC); case C_MCOUNTEREN: return m.cold(CI_MCOUNTEREN) & counteren_rmask(); case C_MENVCFG: return m.cold(CI_MENVCFG);
       case C_MCOUNTINHIBIT: return m.cold(CI_MCOUNTINHIBIT);
-      case C_MSCRATCH: return m.cold(CI_MSCRATCH); case C_MEPC: return m.cold(CI_MEPC); case C_MCAUSE: return m.cold(CI_MCAUSE);
+      case C_MSCRATCH: return m.cold(CI_MSCRATCH); case C_MEPC: return m.cold(CI_MEPC) & epc_rmask(); case C_MCAUSE: return m.cold(CI_MCAUSE);
       case C_MTVAL: return m.cold(CI_MTVAL); case C_MIP: return m.cold(CI_MIP);
       case C_MCYCLE: case C_CYCLE: return h.cycle;
       case C_MINSTRET: case C_INSTRET: return h.instret;
@@ -533,20 +607,22 @@ template <class MEM> struct Lane {
       case C_FFLAGS: h.fcsr = (h.fcsr & ~0x1fu) | (u32)(v & 0x1f); break;
       case C_FRM: h.fcsr = (h.fcsr & ~0xe0u) | (u32)((v & 7) << 5); break;
       case C_FCSR: h.fcsr = (u32)(v & 0xff); break;
-      case C_MSTATUS: h.mstatus = legalize_mstatus((h.mstatus & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK)); break;
+      case C_MSTATUS: {   // value &= writeMask & readMask (CsRegs.cpp:3964): FS is read-only zero without F and S
+        const u64 k = (ext(ISA_F) || ext(ISA_S)) ? MSTATUS_WMASK : (MSTATUS_WMASK & ~(3ULL << MST_FS_SH));
+        h.mstatus = legalize_mstatus((h.mstatus & ~MSTATUS_WMASK) | (v & k)); break; }
       case C_SSTATUS: h.mstatus = legalize_mstatus((h.mstatus & ~SSTATUS_WMASK) | (v & SSTATUS_WMASK)); break;
-      case C_MEDELEG: m.cold(CI_MEDELEG) = v & ~((1ULL << 11) | (1ULL << 16) | (1ULL << 14)); break;
-      case C_MIDELEG: m.cold(CI_MIDELEG) = v & 0x222; break;
-      case C_MIE: { u64 k = 0x888 | (sup ? 0x222 : 0); m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
+      case C_MEDELEG: m.cold(CI_MEDELEG) = v & MEDELEG_MASK; break;
+      case C_MIDELEG: m.cold(CI_MIDELEG) = v & ~0x1444ULL; break;   // CsRegs.cpp:4734 all bits; VS/SGEI bits read-only zero without H (1766-1771)
+      case C_MIE: { u64 k = 0x999 | (sup ? 0x222 : 0);   /* CsRegs.cpp:4739 mask 0xfff less the S (CsRegs.cpp:1509) and VS bits: legacy U bits 0,4,8 stay writable */ m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
       case C_MIP: { u64 k = sup ? 0x222 : 0; m.cold(CI_MIP) = (m.cold(CI_MIP) & ~k) | (v & k); break; }
-      case C_SIE: { u64 k = m.cold(CI_MIDELEG) & 0x222; m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
-      case C_SIP: { u64 k = m.cold(CI_MIDELEG) & 0x002; m.cold(CI_MIP) = (m.cold(CI_MIP) & ~k) | (v & k); break; }
+      case C_SIE: { u64 k = m.cold(CI_MIDELEG) & (sup ? 0x222 : 0);   /* CsRegs::writeSie: sie mask & mie mask & mideleg (CsRegs.cpp:2745-2790) */ m.cold(CI_MIE) = (m.cold(CI_MIE) & ~k) | (v & k); break; }
+      case C_SIP: { u64 k = m.cold(CI_MIDELEG) & (sup ? 0x002 : 0);   /* CsRegs::writeSip (CsRegs.cpp:2680-2740) */ m.cold(CI_MIP) = (m.cold(CI_MIP) & ~k) | (v & k); break; }
       case C_MTVEC: m.cold(CI_MTVEC) = v & ~2ULL; break;
       case C_STVEC: m.cold(CI_STVEC) = v & ~2ULL; break;
       case C_MCOUNTEREN: m.cold(CI_MCOUNTEREN) = v & 0xffffffffULL; break;
       case C_SCOUNTEREN: m.cold(CI_SCOUNTEREN) = v; break;
-      case C_MENVCFG: m.cold(CI_MENVCFG) = v & 0xe0000003000000f5ULL; break;
-      case C_SENVCFG: m.cold(CI_SENVCFG) = v & 0x00000003000000f5ULL; break;
+      case C_MENVCFG: m.cold(CI_MENVCFG) = legalize_envcfg(m.cold(CI_MENVCFG), v) & 0xe0000003000000f5ULL; break;
+      case C_SENVCFG: m.cold(CI_SENVCFG) = legalize_envcfg(m.cold(CI_SENVCFG), v) & 0x00000003000000f5ULL; break;
       case C_MCOUNTINHIBIT: {
         u64 nv = v & 0xfffffffdULL; m.cold(CI_MCOUNTINHIBIT) = nv;
         h.flags = (h.flags & ~(HF_INH_CY | HF_INH_IR)) | ((nv & 1) ? (u32)HF_INH_CY : 0) | ((nv & 4) ? (u32)HF_INH_IR : 0);
@@ -755,7 +831,10 @@ template <class MEM> struct Lane {
   // what it accepts.  Register-write / store capture for the commit record only when TRACE.
   WSP_HD void update_hot_flag()
   {
-    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV);
+    // an interrupt that is pending and enabled (whatever its delegation / global enable) keeps the hart on the cold path,
+    // which polls isInterruptPossible every step
+    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
+               (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
     h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
   }
   template <bool TRACE> WSP_HD void wx_fast(u32 rd, u64 v)
@@ -921,7 +1000,7 @@ template <class MEM> struct Lane {
         v |= MST_MPIE;
         if (saved != PRV_M) v &= ~MST_MPRV;
         csr_store(C_MSTATUS, v); s.chg |= CH_MSTATUS;
-        h.pc = m.cold(CI_MEPC) & ~1ULL; h.priv = saved; break; }
+        h.pc = m.cold(CI_MEPC) & epc_rmask(); h.priv = saved; break; }
       case OP_SRET: {                                                                        // Hart.cpp:12428-12560
         if (h.priv < PRV_S || ((h.mstatus & MST_TSR) && h.priv == PRV_S)) { illegal(r, cur_pc); break; }
         u64 v = h.mstatus; u32 saved = (v & MST_SPP) ? PRV_S : PRV_U;
@@ -929,7 +1008,7 @@ template <class MEM> struct Lane {
         v = ext(ISA_U) ? (v & ~MST_SPP) : (v | MST_SPP);
         v |= MST_SPIE; v &= ~MST_MPRV;
         h.mstatus = legalize_mstatus(v); s.chg |= CH_SSTATUS;
-        h.pc = m.cold(CI_SEPC) & ~1ULL; h.priv = saved; break; }
+        h.pc = m.cold(CI_SEPC) & epc_rmask(); h.priv = saved; break; }
       case OP_WFI:                                                                           // Hart.cpp:12618
         if ((h.priv == PRV_U && ext(ISA_S)) || (h.priv != PRV_M && (h.mstatus & MST_TW))) illegal(r, cur_pc);
         break;
@@ -1026,6 +1105,7 @@ template <class MEM> struct Lane {
   {
     u64 cur_pc, a = 0, b = 0; u32 priv0; Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
     cold_begin(cur_pc, priv0);
+    if (poll_interrupt<TRACE>(cur_pc, priv0)) { update_hot_flag(); return; }
     if (fetch_slow_path<TRACE>(rec, a, b, cur_pc, priv0)) { exec(rec.w0 & 0xff, rec, a, b, cur_pc); step_end<TRACE>(rec, cur_pc, priv0); }
     update_hot_flag();
   }
@@ -1045,12 +1125,12 @@ template <class MEM> struct Lane {
     bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
     if (gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
     if (c & CH_SSTATUS) { t = fold(t, (u64)C_SSTATUS ^ K); t = fold(t, csr_peek(C_SSTATUS)); any = true; }
-    if (c & CH_SEPC) { t = fold(t, (u64)C_SEPC ^ K); t = fold(t, m.cold(CI_SEPC)); any = true; }
+    if (c & CH_SEPC) { t = fold(t, (u64)C_SEPC ^ K); t = fold(t, m.cold(CI_SEPC) & epc_rmask()); any = true; }
     if (c & CH_SCAUSE) { t = fold(t, (u64)C_SCAUSE ^ K); t = fold(t, m.cold(CI_SCAUSE)); any = true; }
     if (c & CH_STVAL) { t = fold(t, (u64)C_STVAL ^ K); t = fold(t, m.cold(CI_STVAL)); any = true; }
     if (c & CH_MSTATUS) { t = fold(t, (u64)C_MSTATUS ^ K); t = fold(t, csr_peek(C_MSTATUS)); any = true; }
     if ((c & CH_GEN) && !gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
-    if (c & CH_MEPC) { t = fold(t, (u64)C_MEPC ^ K); t = fold(t, m.cold(CI_MEPC)); any = true; }
+    if (c & CH_MEPC) { t = fold(t, (u64)C_MEPC ^ K); t = fold(t, m.cold(CI_MEPC) & epc_rmask()); any = true; }
     if (c & CH_MCAUSE) { t = fold(t, (u64)C_MCAUSE ^ K); t = fold(t, m.cold(CI_MCAUSE)); any = true; }
     if (c & CH_MTVAL) { t = fold(t, (u64)C_MTVAL ^ K); t = fold(t, m.cold(CI_MTVAL)); any = true; }
     if (!any) { t = fold(t, 1ULL << 60); t = fold(t, 0); }                                   // printTrace.cpp:491-493

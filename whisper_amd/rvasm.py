@@ -211,6 +211,12 @@ class Asm:
     def bnez(self, rs, t):
         self.bne(rs, 0, t)
 
+    def bltz(self, rs, t):
+        self.blt(rs, 0, t)
+
+    def bgez(self, rs, t):
+        self.bge(rs, 0, t)
+
     def csrr(self, rd, csr):
         self.csrrs(rd, csr, 0)
 

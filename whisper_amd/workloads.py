@@ -408,10 +408,12 @@ def compute_kernel(iters: int = 4, fp: bool = True) -> Program:
 
 
 # ------------------------------------------------------------------------------------------ fuzz
-def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = True) -> Program:
+def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = True, interrupts: bool = False) -> Program:
     """Random instruction mix (M-mode, bare): ALU, loads/stores into mapped and unmapped addresses,
     forward branches, M, A, F/D, CSR accesses, ecall/ebreak/illegal words.  A trap handler skips the
-    trapping instruction (length from the low two bits at mepc) and returns."""
+    trapping instruction (length from the low two bits at mepc) and returns.  interrupts=True enables S/U in
+    the ISA, lets the mix write mie/mip/mideleg/sie/sip and set mstatus.MIE so that software-raised
+    supervisor-level interrupts are taken in M mode (direct or vectored mtvec by seed parity)."""
     rng = random.Random(seed)
     data_base = BASE + 0x4000
     a = Asm(BASE)
@@ -436,11 +438,23 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
     a.j("init")
     a.align(4)
     a.label("handler")
+    if interrupts:
+        # vectored layout (used with mtvec.MODE=1 on odd seeds): exceptions enter at base, interrupt cause c at base+4c
+        a.jal(0, "exc")
+        for _ in range(1, 14):
+            a.jal(0, "irq")
+        a.label("irq")           # software-raised supervisor-level interrupt taken in M mode: drop it and resume
+        a.csrw(CSR["mip"], 0); a.mret()
+        a.label("exc")
+        a.csrr(H1, CSR["mcause"]); a.bltz(H1, "irq")
     a.csrr(H1, CSR["mepc"]); a.lhu(H2, 0, H1); a.andi(H2, H2, 3); a.addi(H2, H2, -3)
     a.bnez(H2, "h2"); a.addi(H1, H1, 2)
     a.label("h2"); a.addi(H1, H1, 2); a.csrw(CSR["mepc"], H1); a.mret()
     a.label("init")
-    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    a.la(5, "handler")
+    if interrupts and (seed & 1):
+        a.addi(5, 5, 1)
+    a.csrw(CSR["mtvec"], 5)
     if fp:
         a.li(5, 0x2000); a.csrs(CSR["mstatus"], 5)
         a.li(5, S["fdata"])
@@ -460,6 +474,8 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
     safe_csrs = [CSR["mscratch"], CSR["mepc"], CSR["mcause"], CSR["mtval"], CSR["fflags"], CSR["frm"], CSR["fcsr"],
                  CSR["mcycle"], CSR["minstret"], CSR["mhartid"], CSR["misa"], CSR["mie"], CSR["mip"], CSR["mcounteren"],
                  CSR["cycle"], CSR["sstatus"], CSR["sepc"], 0x7C0, CSR["mvendorid"], CSR["menvcfg"], CSR["mcountinhibit"], CSR["mstatus"]]
+    if interrupts:
+        safe_csrs += [CSR["mie"], CSR["mip"], CSR["mip"], CSR["mideleg"], CSR["medeleg"], CSR["sie"], CSR["sip"], CSR["mstatus"]]
     for i in range(n):
         for p in list(pending):
             p[0] -= 1
@@ -534,8 +550,19 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
         elif k < 0.94:
             csr = rng.choice(safe_csrs)
             op = rng.choice(["csrrw", "csrrs", "csrrc", "csrrwi", "csrrsi", "csrrci"])
+            if interrupts and rng.random() < 0.35:      # raise / enable the supervisor software interrupt, or all three S bits
+                which = rng.random()
+                if which < 0.4:
+                    a.csrrsi(0, CSR["mip"], 2)
+                elif which < 0.8:
+                    a.csrrsi(0, CSR["mie"], 2)
+                else:
+                    a.li(rd if rd else 1, 0x222); a.csrrs(0, CSR["mie"], rd if rd else 1); a.csrrs(0, CSR["mip"], rd if rd else 1)
+                continue
             if csr == CSR["mstatus"]:
                 op = rng.choice(["csrrs", "csrrc", "csrrsi", "csrrci"]); src = rng.choice([0, 3, 5])  # keep FS/MIE sane-ish
+                if interrupts and rng.random() < 0.6:
+                    op, src = "csrrsi", 8                                                             # mstatus.MIE on
                 getattr(a, op)(rd, csr, src if op.endswith("i") else 0)
             else:
                 getattr(a, op)(rd, csr, rng.randrange(32) if op.endswith("i") else rs1)
@@ -559,5 +586,5 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
         a.label(p[1])
     a.align(4)
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
-    return _finish(a, f"fuzz-{seed}", "rv64imafdc_zicsr" if fp else "rv64imac_zicsr", d, mem_size=1 << 16, max_inst=20000,
-                   meta=dict(seed=seed))
+    isa = ("rv64imafdc" if fp else "rv64imac") + ("su_zicsr" if interrupts else "_zicsr")
+    return _finish(a, f"fuzz-{seed}", isa, d, mem_size=1 << 16, max_inst=20000, meta=dict(seed=seed))
