@@ -47,7 +47,7 @@ typedef struct {
   const char* isa;          /* e.g. "rv64imafdc_zicsr" (Hart::configIsa, Hart.cpp:5122; Isa.cpp:561)       */
   uint64_t mem_base;        /* arena base; accesses outside the arena take access faults (PMA no-access)   */
   uint64_t mem_size;        /* bytes per hart, multiple of 4096 (System ctor memSize, System.cpp:50)       */
-  uint32_t lanes_per_wave;  /* 0 = auto; else 8/16/32/64 harts per 64-lane wavefront                      */
+  uint32_t lanes_per_wave;  /* 0 = auto; else a power of two <= 64: harts per 64-lane wavefront           */
   int32_t  device;          /* HIP device ordinal, -1 = current                                            */
   uint32_t hart_id_base;    /* mhartid of hart 0 (core_hart_id_offset)                                     */
   uint32_t reserved;

@@ -291,26 +291,38 @@ __global__ void wsp_poke_each_kernel(DevState d, u32 lo, u32 hi, u32 res, u64 id
   else *(u64*)(d.arena + arena_off(d, hart, idx)) = vals[i];
 }
 
-// Memory digest: sum over 8-byte words of mix(word ^ GOLDEN*(index+1)).  grid = (chunks, waves),
-// block = 64 lanes; lane l of wave w streams words [c*cw, (c+1)*cw) of hart w*lpw+l: each wave
-// instruction reads lpw*8 contiguous bytes (512 B at 64 lanes per wave).
-__global__ void __launch_bounds__(64) wsp_memhash_kernel(DevState d, u64 words_per_chunk, u64* out /*[S]*/)
+// Memory digest: per hart, sum over its 8-byte words of mix(word ^ GOLDEN*(index+1)).  A wave's arena block is
+// lpw*mem_size contiguous bytes in which word j belongs to lane j % lpw, dword j / lpw (arena_off), so the block is
+// streamed linearly - 256 threads x 8 B = 2 KiB per load instruction whatever lpw is - and the partial sums are
+// combined per lane.  grid = (waves, chunks), block = 256; out[] must be zeroed first.
+#define WSP_MH_THREADS 256
+__global__ void __launch_bounds__(WSP_MH_THREADS) wsp_memhash_kernel(DevState d, u64 words_per_chunk, u64* out /*[S]*/)
 {
-  const u32 lane = threadIdx.x, wave = blockIdx.y;
-  const u32 hart = wave * d.lpw + lane;
-  if (lane >= d.lpw || hart >= d.n_harts) return;
-  const u64 nw = d.mem_size >> 3;
-  u64 k0 = (u64)blockIdx.x * words_per_chunk, k1 = k0 + words_per_chunk;
-  if (k1 > nw) k1 = nw;
-  const u64* base = (const u64*)(d.arena + (size_t)wave * d.lpw * d.mem_size) + lane;
+  __shared__ u64 red[WSP_MH_THREADS];
+  const u32 t = threadIdx.x, wave = blockIdx.x;
+  const u64 total = (d.mem_size >> 3) << d.lpw_shift;                 // words in this wave's block
+  u64 j0 = (u64)blockIdx.y * words_per_chunk, j1 = j0 + words_per_chunk;   // words_per_chunk is a multiple of 256
+  if (j1 > total) j1 = total;
+  const u64* base = (const u64*)(d.arena + (size_t)wave * d.lpw * d.mem_size);
+  const u32 sh = d.lpw_shift;
   u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  u64 k = k0;
-  for (; k + 4 <= k1; k += 4) {
-    u64 w0 = base[(k + 0) << d.lpw_shift], w1 = base[(k + 1) << d.lpw_shift], w2 = base[(k + 2) << d.lpw_shift], w3 = base[(k + 3) << d.lpw_shift];
-    s0 += mix(w0 ^ (GOLDEN * (k + 1))); s1 += mix(w1 ^ (GOLDEN * (k + 2))); s2 += mix(w2 ^ (GOLDEN * (k + 3))); s3 += mix(w3 ^ (GOLDEN * (k + 4)));
+  u64 j = j0 + t;
+  for (; j + 3 * WSP_MH_THREADS < j1; j += 4 * WSP_MH_THREADS) {
+    const u64 w0 = base[j], w1 = base[j + WSP_MH_THREADS], w2 = base[j + 2 * WSP_MH_THREADS], w3 = base[j + 3 * WSP_MH_THREADS];
+    s0 += mix(w0 ^ (GOLDEN * ((j >> sh) + 1)));
+    s1 += mix(w1 ^ (GOLDEN * (((j + WSP_MH_THREADS) >> sh) + 1)));
+    s2 += mix(w2 ^ (GOLDEN * (((j + 2 * WSP_MH_THREADS) >> sh) + 1)));
+    s3 += mix(w3 ^ (GOLDEN * (((j + 3 * WSP_MH_THREADS) >> sh) + 1)));
   }
-  for (; k < k1; ++k) s0 += mix(base[k << d.lpw_shift] ^ (GOLDEN * (k + 1)));
-  atomicAdd((unsigned long long*)&out[wave * 64 + lane], (unsigned long long)(s0 + s1 + s2 + s3));
+  for (; j < j1; j += WSP_MH_THREADS) s0 += mix(base[j] ^ (GOLDEN * ((j >> sh) + 1)));
+  red[t] = s0 + s1 + s2 + s3;
+  __syncthreads();
+  // thread t always handled lane t % lpw (chunk starts and the stride are multiples of lpw): fold the halves down to lpw
+  for (u32 k = WSP_MH_THREADS / 2; k >= d.lpw; k >>= 1) {
+    if (t < k) red[t] += red[t + k];
+    __syncthreads();
+  }
+  if (t < d.lpw && wave * d.lpw + t < d.n_harts) atomicAdd((unsigned long long*)&out[wave * 64 + t], (unsigned long long)red[t]);
 }
 
 __global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* out)
@@ -460,10 +472,11 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   HIPOK(hipSetDevice(dev));
   u32 lpw = desc->lanes_per_wave;
   if (lpw == 0) {
-    // Small batches are latency bound per wave: spread harts over more waves (fewer lanes each)
-    // until there is at least one wave per SIMD (256 CUs x 4 SIMDs).
-    lpw = 64;
-    while (lpw > 8 && (desc->n_harts + lpw - 1) / lpw < 1024) lpw >>= 1;
+    // The step kernel is issue/latency bound per wave and runs 2 waves per SIMD (its register budget): the
+    // chip holds 256 CUs x 4 SIMDs x 2 = 2048 resident waves.  Fewest lanes per wave that still fit the
+    // batch in one resident set (measured at 4096 harts: lpw 1/2/4/8/64 -> 2.9/4.2/3.2/2.6/1.8 GIPS).
+    lpw = 1;
+    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 2048) lpw <<= 1;
   }
   if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
   wsp_batch* b = new wsp_batch();
@@ -853,13 +866,14 @@ extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
   HIPOK(hipSetDevice(b->device));
   DevState& d = b->d;
   HIPOK(hipMemsetAsync(b->d_memhash, 0, (size_t)d.S * 8, b->stream));
-  u64 nw = d.mem_size >> 3;
-  // enough chunks that the grid has >= ~8 waves per CU even for small batches
+  const u64 total = (d.mem_size >> 3) * d.lpw;          // words per wave block; mem_size is a multiple of 4096
+  // enough chunks that the grid has >= ~8 workgroups per CU even for small batches; chunk = multiple of 256 words
   u64 chunks = 1;
-  while (chunks * d.n_waves < 4096 && chunks * 2 <= nw / 64) chunks *= 2;
-  u64 wpc = (nw + chunks - 1) / chunks;
+  while (chunks * d.n_waves < 2048 && total / (chunks * 2) >= 4 * WSP_MH_THREADS) chunks *= 2;
+  u64 wpc = (total / chunks + WSP_MH_THREADS - 1) / WSP_MH_THREADS * WSP_MH_THREADS;
+  chunks = (total + wpc - 1) / wpc;
   HIPOK(hipEventRecord(b->ev0, b->stream));
-  hipLaunchKernelGGL(wsp_memhash_kernel, dim3((unsigned)chunks, d.n_waves), dim3(64), 0, b->stream, d, wpc, b->d_memhash);
+  hipLaunchKernelGGL(wsp_memhash_kernel, dim3(d.n_waves, (unsigned)chunks), dim3(WSP_MH_THREADS), 0, b->stream, d, wpc, b->d_memhash);
   HIPOK(hipGetLastError());
   HIPOK(hipEventRecord(b->ev1, b->stream));
   hipLaunchKernelGGL(wsp_results_kernel, dim3((d.n_harts + 127) / 128), dim3(128), 0, b->stream, d, b->d_memhash, b->d_results);
