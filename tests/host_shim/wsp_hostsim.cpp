@@ -43,15 +43,12 @@ template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
       const u64 a = L.m.rx(rec_rs1(rec));
       const u64 b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : L.m.rx(rec_rs2(rec));
       L.h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
-      L.h.exec++; L.h.cycle++;
-      if (L.exec_fast<TRACE>(rec.w0 & 0xff, rec, a, b, cur_pc)) { L.h.instret++; L.h.retired++; L.trace_fast<TRACE>(rec, cur_pc); continue; }
-      L.s.chg = 0;
-      L.exec(rec.w0 & 0xff, rec, a, b, cur_pc);
-      L.step_end<TRACE>(rec, cur_pc, PRV_M);
-      L.update_hot_flag();
-      continue;
+      if (L.exec_fast<TRACE>(rec.w0 & 0xff, rec, a, b, cur_pc)) {
+        L.h.exec++; L.h.cycle++; L.h.instret++; L.h.retired++; L.trace_fast<TRACE>(rec, cur_pc); continue;
+      }
+      L.h.pc = cur_pc;        // not in the inline subset: nothing was changed, take the general step
     }
-    L.cold_step<TRACE>();
+    L.cold_step<TRACE>(s->use_fast && !s->recs.empty() ? s->recs.data() : nullptr);
   }
 }
 

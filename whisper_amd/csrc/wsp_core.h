@@ -60,7 +60,7 @@ struct Rec {
   u32 w0;     // op[7:0] rd[12:8] rs1[17:13] rs2[22:18] rs3[27:23] F_SIZE4[28] F_IMM[29] F_DBL[30]
   i32 imm;
   u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval
-  u32 pad;
+  u32 pad;    // hot-loop operand offsets, filled by finish_rec(): LDS byte offset of x[rs1] | x[rs2] << 16 (x0 -> zero slot 32)
 };
 enum : u32 { F_SIZE4 = 1u << 28, F_IMM = 1u << 29, F_DBL = 1u << 30 };
 WSP_HD u32 rec_op(const Rec& r) { return r.w0 & 0xff; }
@@ -68,6 +68,11 @@ WSP_HD u32 rec_rd(const Rec& r) { return (r.w0 >> 8) & 31; }
 WSP_HD u32 rec_rs1(const Rec& r) { return (r.w0 >> 13) & 31; }
 WSP_HD u32 rec_rs2(const Rec& r) { return (r.w0 >> 18) & 31; }
 WSP_HD u32 rec_rs3(const Rec& r) { return (r.w0 >> 23) & 31; }
+WSP_HD void finish_rec(Rec& r)
+{
+  const u32 s1 = rec_rs1(r), s2 = (r.w0 & F_IMM) ? 0 : rec_rs2(r);
+  r.pad = ((s1 ? s1 : 32u) * 8u) | (((s2 ? s2 : 32u) * 8u) << 16);
+}
 WSP_HD Rec mk(u32 op, u32 rd, u32 rs1, u32 rs2, i32 imm, u32 flags = 0, u32 rs3 = 0)
 { Rec r; r.w0 = op | (rd << 8) | (rs1 << 13) | (rs2 << 18) | (rs3 << 23) | flags; r.imm = imm; r.raw = 0; r.pad = 0; return r; }
 
@@ -1100,13 +1105,23 @@ template <class MEM> struct Lane {
     h.retired++;
     commit<TRACE>(cur_pc, rec.raw, size, priv0, 0);
   }
-  // a complete cold step
-  template <bool TRACE> WSP_HD void cold_step()
+  // a complete cold step.  `recs` (may be null) is the hart's pre-decoded program image: an M-mode hart whose code is
+  // not dirty takes the record from it instead of decoding from RAM (same result: the image is decode() of the same
+  // bytes, and M-mode fetch inside the arena cannot fault).
+  template <bool TRACE> WSP_HD void cold_step(const Rec* recs)
   {
     u64 cur_pc, a = 0, b = 0; u32 priv0; Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
     cold_begin(cur_pc, priv0);
     if (poll_interrupt<TRACE>(cur_pc, priv0)) { update_hot_flag(); return; }
-    if (fetch_slow_path<TRACE>(rec, a, b, cur_pc, priv0)) { exec(rec.w0 & 0xff, rec, a, b, cur_pc); step_end<TRACE>(rec, cur_pc, priv0); }
+    bool have = false;
+    if (recs && h.priv == PRV_M && !(h.flags & HF_CODE_DIRTY) && hot_fetch(recs, rec)) {
+      h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
+      a = m.rx(rec_rs1(rec));
+      b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
+      have = true;
+    } else
+      have = fetch_slow_path<TRACE>(rec, a, b, cur_pc, priv0);
+    if (have) { exec(rec.w0 & 0xff, rec, a, b, cur_pc); step_end<TRACE>(rec, cur_pc, priv0); }
     update_hot_flag();
   }
 

@@ -1,9 +1,9 @@
 // whisper_amd: HIP kernels (gfx950) + host front end + C ABI (include/whisper_amd.h).
 //
 // Execution model: one lane = one hart, one 64-lane wavefront per workgroup steps up
-// to 64 harts in lock step.  Integer and FP register files are staged in LDS as [reg][lane]
-// (bank-conflict free for both converged and diverged register numbers), the per-step state
-// (struct wsp::Hot) stays in VGPRs for the whole slice, cold CSRs / RAM arenas / pre-decoded
+// to 64 harts in lock step.  Integer and FP register files are staged in LDS as [lane][33 slots]
+// (stride 33 dwords-pairs: converged register numbers fall into distinct banks), a handful of
+// per-hart values stay in VGPRs for the whole slice, cold CSRs / RAM arenas / pre-decoded
 // programs live in HBM.  Dispatch picks the op of the first pending lane, makes it wave-uniform
 // with readlane and runs that op for every lane that fetched the same op; converged harts cost
 // one pass per step.
@@ -45,12 +45,16 @@ __host__ __device__ static inline size_t arena_off(const DevState& d, u32 hart, 
 }
 
 // ------------------------------------------------------------------------------------------ device memory policy
+// LDS register block of one lane: WSP_XSLOTS u64 slots.  x1..x31 sit in slots 1..31; slot 0 is a write sink (the hot loop
+// writes rd = x0 results there unconditionally), slot 32 is the constant zero that every read of x0 is redirected to
+// (pre-decoded operand offsets, Rec.pad).  The f block uses slots 0..31.
+#define WSP_XSLOTS 33
 struct DevMem {
   u64* xs; u64* fs; u64* cold_; u8* arena; u32 S, lpw_shift;
-  __device__ __forceinline__ u64 rx(u32 r) const { return xs[r << lpw_shift]; }
-  __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r << lpw_shift] = v; }
-  __device__ __forceinline__ u64 rf(u32 r) const { return fs[r << lpw_shift]; }
-  __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r << lpw_shift] = v; }
+  __device__ __forceinline__ u64 rx(u32 r) const { return xs[r ? r : 32]; }
+  __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r] = v; }
+  __device__ __forceinline__ u64 rf(u32 r) const { return fs[r]; }
+  __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r] = v; }
   __device__ __forceinline__ u64& cold(u32 i) { return cold_[(size_t)i * S]; }
   __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
   __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
@@ -64,8 +68,10 @@ struct DevMem {
 };
 
 // ------------------------------------------------------------------------------------------ step kernel
+// Occupancy target: 4 waves per SIMD (128 VGPRs).  The hot loop needs < 64; the out-of-line general path spills a
+// little at this cap, which is cheap at its call frequency (measured: 2 -> 4.8, 4 -> 8.1, 8 -> 6.3 GIPS at 4096 harts).
 #ifndef WSP_WAVES_PER_EU
-#define WSP_WAVES_PER_EU 2
+#define WSP_WAVES_PER_EU 4
 #endif
 extern __shared__ __align__(16) u64 wsp_lds[];
 
@@ -74,8 +80,8 @@ __device__ __forceinline__ u32 ln_of(const DevState& d)
 
 __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
 {
-  L.m.xs = wsp_lds + ln;
-  L.m.fs = wsp_lds + 32 * d.lpw + ln;
+  L.m.xs = wsp_lds + ln * WSP_XSLOTS;
+  L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot;
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
@@ -114,35 +120,36 @@ __device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevSt
 // from the difference between the register exec counter and the stored one.
 struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status; };
 
-// The general path, out of line: rebuilds the full lane from HBM, runs either one complete cold
-// step (mode 0) or the full exec()+retire of an instruction the hot prologue already fetched and
-// counted (mode 1), stores the lane back.
+// The general path, out of line: rebuilds the full lane from HBM, runs one complete general step
+// (interrupt poll, fetch, full exec(), retire, commit record) and stores the lane back.
 template <bool TRACE>
-__device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, u32 mode, u32 op_in, u32 w0, i32 imm, u32 raw,
-                                         u64 a, u64 b, u64 cur_pc, HotRegs hr)
+__device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, HotRegs hr)
 {
   const DevState& d = *dp;
   const u32 slot = wave * 64 + ln;
   Lane<DevMem> L; const Rec* recs;
   wsp_lane_setup(L, d, wave, ln, slot, recs);
   wsp_load_hot(L, d, slot);
-  const u64 dlt = hr.exec - L.h.exec;
-  const u64 done = mode ? dlt - 1 : dlt;          // mode 1: the current instruction is counted in exec/cycle only
-  L.h.cycle += dlt; L.h.instret += done; L.h.retired += done;
+  const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
+  L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
   L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
   L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
-  if (mode) {
-    const u32 op = (u32)__builtin_amdgcn_readfirstlane((int)op_in);   // wave-uniform by construction of the dispatch loop
-    Rec rec; rec.w0 = w0; rec.imm = imm; rec.raw = raw; rec.pad = 0;
-    L.exec(op, rec, a, b, cur_pc);
-    L.template step_end<TRACE>(rec, cur_pc, PRV_M);
-    L.update_hot_flag();
-  } else
-    L.template cold_step<TRACE>();
+  L.template cold_step<TRACE>(recs);
   wsp_store_hot(L, d, slot);
   HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status;
   return r;
 }
+
+// Wave-wide minimum of a u32 (all 64 lanes participate).
+__device__ __forceinline__ u32 wave_min_u32(u32 v)
+{
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const u32 t = (u32)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+
+typedef u32 wsp_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) wsp_u32x4* wsp_gq;  // record image is plain global memory
 
 template <bool TRACE, bool FP>
 __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState d, const DevState* dp, u64 max_steps)
@@ -159,67 +166,188 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   L.h.pc = d.hot64[H64_PC * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.thash = d.hot64[H64_THASH * S + slot];
   L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot];
-  L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / flags
-  L.s.chg = 0; L.s.ireg = 0; L.s.ival = 0; L.s.maddr = 0; L.s.mval = 0;
+  L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / mip / mie / flags
   u64 stop_at;
   {
     const u64 max_exec = d.max_exec[slot], exec0 = L.h.exec;
     stop_at = exec0 >= max_exec ? exec0 : ((max_exec - exec0 < max_steps) ? max_exec : exec0 + max_steps);
   }
-  // A cold call is a context switch: every per-lane value of the hot loop is either passed through
-  // HotRegs or rebuilt from the kernel arguments afterwards, so nothing but SGPR kernel arguments is
-  // live across the call and the hot loop's register allocation is not shaped by the call ABI.
-#define WSP_COLD_CALL(MODE, OP, W0, IMM, RAW, A, B, PC)                                                        \
-  do {                                                                                                          \
-    HotRegs hr_; hr_.pc = L.h.pc; hr_.exec = L.h.exec; hr_.thash = L.h.thash; hr_.stop_at = stop_at;           \
-    hr_.flags = L.h.flags; hr_.status = L.h.status;                                                             \
-    hr_ = wsp_cold<TRACE>(dp, blockIdx.x, ln_of(d), MODE, OP, W0, IMM, RAW, A, B, PC, hr_);                    \
-    const u32 ln2_ = ln_of(d);                                                                                  \
-    wsp_lane_setup(L, d, blockIdx.x, ln2_, blockIdx.x * 64 + ln2_, recs);                                       \
-    L.h.pc = hr_.pc; L.h.exec = hr_.exec; L.h.thash = hr_.thash; stop_at = hr_.stop_at;                         \
-    L.h.flags = hr_.flags; L.h.status = hr_.status;                                                             \
-  } while (0)
 
   if (active) {
-    for (u32 r = 0; r < 32; ++r) L.m.wx(r, d.x[(size_t)r * S + slot]);
-    if (FP) for (u32 r = 0; r < 32; ++r) L.m.wf(r, d.f[(size_t)r * S + slot]);
+    L.m.xs[0] = 0; L.m.xs[32] = 0;
+#pragma unroll 4
+    for (u32 r = 1; r < 32; ++r) L.m.wx(r, d.x[(size_t)r * S + slot]);
+    if (FP) {
+#pragma unroll 4
+      for (u32 r = 0; r < 32; ++r) L.m.wf(r, d.f[(size_t)r * S + slot]);
+    }
   }
   __syncthreads();
 
+  const bool zca = (d.isa & ISA_C) != 0;                 // without C, taken control transfers can trap: general path
+
+  // Outer loop: { hot inner loop (no calls) ; one general step for the lanes that asked for it }.
+  //
+  // Hot inner loop.  Entered only when every running lane of the wave is hot (HF_HOT) with its pc inside its pre-decoded
+  // text; runs under an exec mask of exactly those lanes for n = min remaining budget iterations (wave-uniform trip
+  // count: nothing in the loop can stop a hart, so "running" does not change inside).  The pc is kept as a 32-bit offset
+  // into the text.  Per iteration: load the 16-byte record, read both source registers from LDS through the
+  // pre-computed byte offsets in Rec.pad, then run each distinct op present once (wave-uniform switch).  A lane that
+  // meets anything outside the inline subset (an op that is not inlined, a misaligned / out-of-arena / tohost / text
+  // access, a control transfer leaving the text) changes nothing, raises `nc` and the loop is left after that iteration;
+  // the general step then executes that same instruction in full.
   while (true) {
     const bool run = L.h.status == ST_RUNNING && L.h.exec < stop_at;
     if (!__any(run)) break;                              // every lane of the wave has stopped or used its budget
+    const u64 off64 = L.h.pc - L.text_lo;
+    const u32 text_len = (u32)(L.text_hi - L.text_lo);   // loader keeps every text image below 1 GiB
+    const bool can = run && (L.h.flags & HF_HOT) && off64 < (u64)text_len;
+    bool need_cold = run && !can;
 
-    // ---- fetch: pre-decoded record for hot harts, everything else takes a complete cold step
-    Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
-    bool todo = run && (L.h.flags & HF_HOT) && L.hot_fetch(recs, rec);
-    if (run && !todo) WSP_COLD_CALL(0, 0, 0, 0, 0, 0, 0, 0);
-    const u64 cur_pc = L.h.pc;
-    const u64 a = L.m.rx(rec_rs1(rec));
-    const u64 b2 = L.m.rx(rec_rs2(rec));
-    const u64 b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : b2;
-    if (todo) { L.h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2); L.h.exec++; }
+    if (!__any(need_cold)) {
+      const u64 left = stop_at - L.h.exec;
+      const u32 n = wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu);
+      if (can) {
+        u32 pco = (u32)off64, it = 0;
+        u32 ncv = 0;                                      // "needs the general step", as a VGPR flag (no lane-mask algebra)
+        const u32 xb = (u32)(size_t)((char*)L.m.xs - (char*)wsp_lds);      // byte offset of this lane's x block
+        const char* const ldsb = (const char*)wsp_lds;
+        const u64 tlo = L.text_lo, thi = L.text_hi, tohost = L.tohost, mbase = L.mem_base, msize = L.mem_size;
+        u64* const sinkx = (u64*)(ldsb + xb);                                  // LDS slot 0 of this lane: register write sink
+        u8* const gsink = (u8*)(d.cold + (size_t)CI_COUNT * S + (blockIdx.x * 64 + ln_of(d)));   // 8-byte global store sink
+        do {
+          // ---- fetch.  pco <= text_len always holds here (control transfers are range-checked, sequential flow stops
+          // at the sentinel records behind the image), so the load needs no guard.
+          const wsp_u32x4 q = *(wsp_gq)((const char*)recs + ((u64)pco << 3));
+          const u32 w0 = q.x; const i32 imm = (i32)q.y;
+          const u32 op = w0 & 0xff;
+          const u64 a = *(const u64*)(ldsb + (xb + (q.w & 0xffffu)));
+          const u64 b2 = *(const u64*)(ldsb + (xb + (q.w >> 16)));         // x[rs2]; the zero slot for immediate forms
+          u64* const rdp = (u64*)(ldsb + (xb + ((w0 >> 5) & 0xf8u)));      // rd * 8 (slot 0 = sink)
+          const u64 simm = (u64)(i64)imm;
+          const u64 bi = b2 + simm;                       // ALU second operand: register forms carry imm = 0
+          const u32 size = 2u + ((w0 >> 27) & 2u);        // F_SIZE4 is bit 28
+          u32 npc = pco + size;
+          u64 tr_k = 1ULL << 60, tr_v = 0;                // trace: the change this instruction made (default: none)
+          const u64 rd_key = (w0 & 0x1f00u) ? ((u64)((w0 >> 8) & 31) ^ (1ULL << 60)) : (1ULL << 60);   // x0: "no change"
 
-    // ---- dispatch: wave-uniform op, executed for every lane that fetched it
-    const u32 op = rec.w0 & 0xff;
-    unsigned long long pend = __ballot(todo);
-    while (pend) {
-      const int leader = __ffsll((long long)pend) - 1;
-      const u32 lop = (u32)__builtin_amdgcn_readlane((int)op, leader);
-      const bool mine = todo && op == lop;
-      if (mine) {
-        // Launder the uniform op and the operands: without this the compiler (a) proves lop == op
-        // inside this branch and switches on the per-lane VGPR copy (a divergent, exec-masked
-        // switch), and (b) hoists every case body out of the dispatch loop because a and b are
-        // loop invariant, computing all ~40 results per step and spilling them.
-        u32 uop = lop; u64 aa = a, bb = b;
-        asm volatile("" : "+v"(uop), "+v"(aa), "+v"(bb));
-        uop = (u32)__builtin_amdgcn_readfirstlane((int)uop);
-        if (L.template exec_fast<TRACE>(uop, rec, aa, bb, cur_pc)) L.template trace_fast<TRACE>(rec, cur_pc);
-        else WSP_COLD_CALL(1, uop, rec.w0, rec.imm, rec.raw, aa, bb, cur_pc);
-        todo = false;
+          // One op for the lanes in EXEC.  Every case is straight-line (selects, no divergent branch and no short-circuit
+          // evaluation); the most frequent ops sit at the top of the compare chain.
+#define WSP_WX(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? v_ : 0; } } while (0)
+#define WSP_HOT_OP(uop, aa, bb, cc)                                                                                        \
+          if (uop == OP_ADD) WSP_WX(aa + cc);                                                                              \
+          else if (uop >= OP_LB && uop <= OP_LWU) {                                                                        \
+            const u32 k = uop - OP_LB, sz = 1u << (k & 3);                                                                 \
+            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);                                 \
+            const u8* p = L.m.p(ok ? off : 0);            /* rejected lanes read their own dword 0 and discard it */     \
+            u64 v;                                                                                                         \
+            if (k == 2) v = (u64)(i64)*(const i32*)p; else if (k == 3) v = *(const u64*)p;                                 \
+            else if (k == 6) v = *(const u32*)p; else if (k == 4) v = *p; else if (k == 0) v = (u64)(i64)*(const int8_t*)p; \
+            else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;                                    \
+            *(ok ? rdp : sinkx) = v;                                                                                       \
+            ncv |= ok ? 0u : 1u;                                                                                           \
+            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? v : 0; }                                                   \
+          } else if (uop >= OP_BEQ && uop <= OP_BGEU) {                                                                    \
+            const u32 m = uop - OP_BEQ;                                                                                    \
+            const bool c = m < 2 ? aa == bb : m < 4 ? (i64)aa < (i64)bb : aa < bb;                                         \
+            const bool take = c != (bool)(m & 1);                                                                          \
+            const u32 t = pco + (u32)imm;                                                                                  \
+            const bool ok = zca & (t < text_len);                                                                          \
+            npc = (take & ok) ? (t & ~1u) : npc;                                                                           \
+            ncv |= (take & !ok) ? 1u : 0u;                                                                                 \
+          } else if (uop == OP_ADDW) WSP_WX((u64)(i64)(i32)((u32)aa + (u32)cc));                                           \
+          else if (uop == OP_MULW) WSP_WX((u64)(i64)(i32)((u32)aa * (u32)cc));                                             \
+          else if (uop == OP_SLL) WSP_WX(aa << (cc & 63));                                                                 \
+          else if (uop == OP_SRL) WSP_WX(aa >> (cc & 63));                                                                 \
+          else if (uop >= OP_SB && uop <= OP_SD) {                                                                         \
+            const u32 k = uop - OP_SB, sz = 1u << k;                                                                       \
+            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost) & (va != tohost + 4) &           \
+                            !((va + sz > tlo) & (va < thi));                                                               \
+            u8* p = ok ? L.m.p(off) : gsink;              /* rejected lanes store into their private sink */              \
+            const u64 sv = k == 3 ? bb : (bb & ((1ULL << (8 * sz)) - 1));                                                  \
+            if (k == 2) *(u32*)p = (u32)sv; else if (k == 3) *(u64*)p = sv; else if (k == 0) *p = (u8)sv; else *(u16*)p = (u16)sv; \
+            ncv |= ok ? 0u : 1u;                                                                                           \
+            if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }                                                            \
+          } else if (uop == OP_AND) WSP_WX(aa & cc);                                                                       \
+          else if (uop == OP_MUL) WSP_WX(aa * cc);                                                                         \
+          else if (uop == OP_JAL || uop == OP_JALR) {                                                                      \
+            const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((aa + simm) & ~1ULL) - tlo);                           \
+            const bool ok = zca & (t < (u64)text_len);                                                                     \
+            const u64 link = tlo + pco + size;                                                                             \
+            *(ok ? rdp : sinkx) = link;                                                                                    \
+            npc = ok ? ((u32)t & ~1u) : npc;                                                                               \
+            ncv |= ok ? 0u : 1u;                                                                                           \
+            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? link : 0; }                                                \
+          } else switch (uop) {                                                                                            \
+            case OP_SUB: WSP_WX(aa - cc); break;                                                                           \
+            case OP_SLT: WSP_WX((u64)((i64)aa < (i64)cc)); break;                                                          \
+            case OP_SLTU: WSP_WX((u64)(aa < cc)); break;                                                                   \
+            case OP_XOR: WSP_WX(aa ^ cc); break;                                                                           \
+            case OP_SRA: WSP_WX((u64)((i64)aa >> (cc & 63))); break;                                                       \
+            case OP_OR: WSP_WX(aa | cc); break;                                                                            \
+            case OP_SUBW: WSP_WX((u64)(i64)(i32)((u32)aa - (u32)cc)); break;                                               \
+            case OP_SLLW: WSP_WX((u64)(i64)(i32)((u32)aa << (cc & 31))); break;                                            \
+            case OP_SRLW: WSP_WX((u64)(i64)(i32)((u32)aa >> (cc & 31))); break;                                            \
+            case OP_SRAW: WSP_WX((u64)(i64)((i32)aa >> (cc & 31))); break;                                                 \
+            case OP_AUIPC: WSP_WX(tlo + pco + simm); break;                                                                \
+            case OP_NOP: break;                                                                                            \
+            default: ncv = 1u; break;                     /* not in the inline subset */                                  \
+          }
+
+          // ---- dispatch.  Converged wave (one op in all lanes, always so with one hart per wave): a single pass with the
+          // op in an SGPR.  Otherwise loop over the distinct ops present.
+          const u32 op0 = (u32)__builtin_amdgcn_readfirstlane((int)op);
+          if (__all(op == op0)) {
+            WSP_HOT_OP(op0, a, b2, bi)
+          } else {
+            bool todo = true;
+            unsigned long long pend = __ballot(true);
+            while (pend) {
+              const int leader = __ffsll((long long)pend) - 1;
+              const u32 lop = (u32)__builtin_amdgcn_readlane((int)op, leader);
+              const bool mine = todo && op == lop;
+              if (mine) {
+                // Launder the uniform op and the operands: without this the compiler (a) proves lop == op inside this
+                // branch and switches on the per-lane VGPR copy (a divergent, exec-masked switch), and (b) hoists every
+                // case body out of the loop because the operands are invariant in it.
+                u32 uop = lop; u64 aa = a, bb = b2, cc = bi;
+                asm volatile("" : "+v"(uop), "+v"(aa), "+v"(bb), "+v"(cc));
+                uop = (u32)__builtin_amdgcn_readfirstlane((int)uop);
+                WSP_HOT_OP(uop, aa, bb, cc)
+                todo = false;
+              }
+              pend &= ~__ballot(mine);
+            }
+          }
+#undef WSP_HOT_OP
+#undef WSP_WX
+          if (TRACE && !ncv) {                            // commit record of an M-mode instruction without trap or CSR change
+            u64 t = L.h.thash;
+            t = fold(t, tlo + pco);
+            t = fold(t, (u64)q.z | ((u64)PRV_M << 32) | ((u64)size << 48));
+            t = fold(t, tr_k); t = fold(t, tr_v);
+            L.h.thash = t;
+          }
+          pco = ncv ? pco : npc;
+          ++it;
+        } while (!__any(ncv != 0) && it < n);
+        L.h.exec += ncv ? it - 1 : it;                    // the lane that raised the flag did not execute in the last iteration
+        L.h.pc = tlo + pco;
+        need_cold = ncv != 0;
       }
-      pend &= ~__ballot(mine);
+    }
+    if (need_cold) {
+      // A cold call is a context switch: every per-lane value of the hot loop is either passed through HotRegs or
+      // rebuilt from the kernel arguments afterwards.
+      HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.stop_at = stop_at;
+      hr.flags = L.h.flags; hr.status = L.h.status;
+      hr = wsp_cold<TRACE>(dp, blockIdx.x, ln_of(d), hr);
+      const u32 ln2 = ln_of(d);
+      wsp_lane_setup(L, d, blockIdx.x, ln2, blockIdx.x * 64 + ln2, recs);
+      L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; stop_at = hr.stop_at;
+      L.h.flags = hr.flags; L.h.status = hr.status;
     }
   }
 
@@ -244,12 +372,17 @@ __global__ void wsp_predecode_kernel(const u8* img, u64 n_bytes, u32 isa, Rec* o
 {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 off = i * 2;
-  if (off + 2 > n_bytes) return;
+  if (off + 2 > n_bytes) {
+    // two sentinel records behind the image: a hart that runs off the end of its text fetches "not pre-decoded"
+    if (off < n_bytes + 4) { Rec r = mk(OP_SLOWFETCH, 0, 0, 0, 0); finish_rec(r); out[i] = r; }
+    return;
+  }
   u32 lo = img[off] | ((u32)img[off + 1] << 8);
   Rec r;
   if ((lo & 3) != 3) r = decode16(lo, isa);
   else if (off + 4 <= n_bytes) r = decode32(lo | ((u32)img[off + 2] << 16) | ((u32)img[off + 3] << 24), isa);
   else { r = mk(OP_SLOWFETCH, 0, 0, 0, 0); r.raw = lo; }   // upper half lies outside the decoded range
+  finish_rec(r);
   out[i] = r;
 }
 
@@ -472,11 +605,11 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   HIPOK(hipSetDevice(dev));
   u32 lpw = desc->lanes_per_wave;
   if (lpw == 0) {
-    // The step kernel is issue/latency bound per wave and runs 2 waves per SIMD (its register budget): the
-    // chip holds 256 CUs x 4 SIMDs x 2 = 2048 resident waves.  Fewest lanes per wave that still fit the
-    // batch in one resident set (measured at 4096 harts: lpw 1/2/4/8/64 -> 2.9/4.2/3.2/2.6/1.8 GIPS).
+    // The step kernel is issue/latency bound per wave and runs 4 waves per SIMD: the chip holds 256 CUs x 4 SIMDs x 4 =
+    // 4096 resident waves.  Harts of one wave only share work while they execute the same op, so the fewest lanes per
+    // wave that still fit the batch in one resident set are the fastest (4096 harts: lpw 1/2/4/8 -> 8.1/4.8/3.6/3.1 GIPS).
     lpw = 1;
-    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 2048) lpw <<= 1;
+    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 4096) lpw <<= 1;
   }
   if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
   wsp_batch* b = new wsp_batch();
@@ -493,7 +626,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m_ = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); wsp_batch_destroy(b); return fail(WSP_ENOMEM, m_); } \
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
   ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
-  ALLOC(d.cold, CI_COUNT * S * 8); ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
+  ALLOC(d.cold, (CI_COUNT + 1) * S * 8);   /* + one row: per-slot store sink of the hot loop */ ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
   ALLOC(d.arena, arena_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
 #undef ALLOC
   // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
@@ -587,8 +720,9 @@ static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vec
     u8* dimg = nullptr;
     HIPOK(hipMalloc(&dimg, text.size()));
     HIPOK(hipMemcpy(dimg, text.data(), text.size(), hipMemcpyHostToDevice));
-    HIPOK(hipMalloc(&p.d_recs, nslots * sizeof(Rec)));
-    hipLaunchKernelGGL(wsp_predecode_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, b->stream, dimg, (u64)(p.text_hi - p.text_lo), d.isa, p.d_recs);
+    if (nslots >= (1u << 29)) return fail(WSP_ERANGE, "code image of 1 GiB or more");
+    HIPOK(hipMalloc(&p.d_recs, (nslots + 2) * sizeof(Rec)));
+    hipLaunchKernelGGL(wsp_predecode_kernel, dim3((unsigned)((nslots + 2 + 255) / 256)), dim3(256), 0, b->stream, dimg, (u64)(p.text_hi - p.text_lo), d.isa, p.d_recs);
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(b->stream));
     HIPOK(hipFree(dimg));
@@ -825,7 +959,7 @@ extern "C" int wsp_batch_poke_each(wsp_batch* b, uint32_t lo, uint32_t hi, uint3
 template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 steps)
 {
   DevState& d = b->d;
-  size_t lds = (size_t)d.lpw * 32 * 8 * (FP ? 2 : 1);
+  size_t lds = (size_t)d.lpw * WSP_XSLOTS * 8 * (FP ? 2 : 1);
   hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps);
