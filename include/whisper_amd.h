@@ -66,7 +66,7 @@ typedef struct {
 } wsp_result;
 
 /* One pre-decoded instruction as produced by the device decoder (test/diagnostic surface). */
-typedef struct { uint32_t w0; int32_t imm; uint32_t raw; uint32_t pad; } wsp_decoded;
+typedef struct { uint32_t w0; int32_t imm; uint32_t pad; uint32_t raw; } wsp_decoded;
 
 /* System ctor + HartConfig::configHarts/configMemory + Hart::configIsa + Hart::reset
  * (System.cpp:50, HartConfig.cpp:3282/3414, Hart.cpp:5122, 942). */

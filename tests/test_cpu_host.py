@@ -35,7 +35,7 @@ fcvt.s.l c.nop c.ebreak c.fldsp c.fsdsp c.addi16sp ecall ebreak sret sfence.vma 
 
 
 class Dec(C.Structure):
-    _fields_ = [("w0", C.c_uint32), ("imm", C.c_int32), ("raw", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("w0", C.c_uint32), ("imm", C.c_int32), ("pad", C.c_uint32), ("raw", C.c_uint32)]
 
 
 def _host_decode(isa, words):

@@ -45,7 +45,7 @@ class Result(C.Structure):
 
 
 class Decoded(C.Structure):
-    _fields_ = [("w0", C.c_uint32), ("imm", C.c_int32), ("raw", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("w0", C.c_uint32), ("imm", C.c_int32), ("pad", C.c_uint32), ("raw", C.c_uint32)]
 
 
 def build(force=False):

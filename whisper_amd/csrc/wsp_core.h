@@ -59,8 +59,9 @@ enum Op : u32 {
 struct Rec {
   u32 w0;     // op[7:0] rd[12:8] rs1[17:13] rs2[22:18] rs3[27:23] F_SIZE4[28] F_IMM[29] F_DBL[30]
   i32 imm;
-  u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval
   u32 pad;    // hot-loop operand offsets, filled by finish_rec(): LDS byte offset of x[rs1] | x[rs2] << 16 (x0 -> zero slot 32)
+  u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval.  Last: the untraced hot loop
+              // loads only the first three words
 };
 enum : u32 { F_SIZE4 = 1u << 28, F_IMM = 1u << 29, F_DBL = 1u << 30 };
 WSP_HD u32 rec_op(const Rec& r) { return r.w0 & 0xff; }
@@ -854,7 +855,7 @@ template <class MEM> struct Lane {
     if (idx >= text_hi - text_lo) return false;
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (idx << 3));
-    rec.w0 = q.x; rec.imm = (i32)q.y; rec.raw = q.z; rec.pad = 0;
+    rec.w0 = q.x; rec.imm = (i32)q.y; rec.pad = q.z; rec.raw = q.w;
 #else
     rec = recs[idx >> 1];
 #endif

@@ -148,8 +148,12 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v)
   return v;
 }
 
+// Record image is plain global memory.  Untraced runs load {w0, imm, pad}; traced runs also the raw instruction bits.
 typedef u32 wsp_u32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) wsp_u32x4* wsp_gq;  // record image is plain global memory
+typedef u32 wsp_u32x3 __attribute__((ext_vector_type(3)));
+template <bool TRACE> struct RecQ;
+template <> struct RecQ<true> { typedef wsp_u32x4 T; static __device__ __forceinline__ u32 raw(const T& q) { return q.w; } };
+template <> struct RecQ<false> { typedef wsp_u32x3 T; static __device__ __forceinline__ u32 raw(const T&) { return 0; } };
 
 template <bool TRACE, bool FP>
 __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState d, const DevState* dp, u64 max_steps)
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 
     if (!__any(need_cold)) {
       const u64 left = stop_at - L.h.exec;
-      const u32 n = wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu);
+      const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu));
       if (can) {
         u32 pco = (u32)off64, it = 0;
         u32 ncv = 0;                                      // "needs the general step", as a VGPR flag (no lane-mask algebra)
@@ -215,19 +219,25 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         const u64 tlo = L.text_lo, thi = L.text_hi, tohost = L.tohost, mbase = L.mem_base, msize = L.mem_size;
         u64* const sinkx = (u64*)(ldsb + xb);                                  // LDS slot 0 of this lane: register write sink
         u8* const gsink = (u8*)(d.cold + (size_t)CI_COUNT * S + (blockIdx.x * 64 + ln_of(d)));   // 8-byte global store sink
+        // ---- fetch.  pco <= text_len always holds (control transfers are range-checked, sequential flow stops at the two
+        // sentinel records behind the image), so record loads need no guard.  The record of the sequentially next
+        // instruction is requested as soon as the size of the current one is known and is in flight while the current
+        // instruction executes; only a taken control transfer pays the load latency.
+        typedef typename RecQ<TRACE>::T QT;
+        typedef const __attribute__((address_space(1))) QT* QP;
+        QT q = *(QP)((const char*)recs + ((u64)pco << 3));
         do {
-          // ---- fetch.  pco <= text_len always holds here (control transfers are range-checked, sequential flow stops
-          // at the sentinel records behind the image), so the load needs no guard.
-          const wsp_u32x4 q = *(wsp_gq)((const char*)recs + ((u64)pco << 3));
-          const u32 w0 = q.x; const i32 imm = (i32)q.y;
+          const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 ofs = q.z; const u32 raw = RecQ<TRACE>::raw(q);
           const u32 op = w0 & 0xff;
-          const u64 a = *(const u64*)(ldsb + (xb + (q.w & 0xffffu)));
-          const u64 b2 = *(const u64*)(ldsb + (xb + (q.w >> 16)));         // x[rs2]; the zero slot for immediate forms
+          const u64 a = *(const u64*)(ldsb + (xb + (ofs & 0xffffu)));
+          const u64 b2 = *(const u64*)(ldsb + (xb + (ofs >> 16)));         // x[rs2]; the zero slot for immediate forms
           u64* const rdp = (u64*)(ldsb + (xb + ((w0 >> 5) & 0xf8u)));      // rd * 8 (slot 0 = sink)
           const u64 simm = (u64)(i64)imm;
           const u64 bi = b2 + simm;                       // ALU second operand: register forms carry imm = 0
           const u32 size = 2u + ((w0 >> 27) & 2u);        // F_SIZE4 is bit 28
-          u32 npc = pco + size;
+          const u32 spc = pco + size;
+          const QT qn = *(QP)((const char*)recs + ((u64)spc << 3));
+          u32 npc = spc;
           u64 tr_k = 1ULL << 60, tr_v = 0;                // trace: the change this instruction made (default: none)
           const u64 rd_key = (w0 & 0x1f00u) ? ((u64)((w0 >> 8) & 31) ^ (1ULL << 60)) : (1ULL << 60);   // x0: "no change"
 
@@ -326,11 +336,13 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
           if (TRACE && !ncv) {                            // commit record of an M-mode instruction without trap or CSR change
             u64 t = L.h.thash;
             t = fold(t, tlo + pco);
-            t = fold(t, (u64)q.z | ((u64)PRV_M << 32) | ((u64)size << 48));
+            t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
             t = fold(t, tr_k); t = fold(t, tr_v);
             L.h.thash = t;
           }
           pco = ncv ? pco : npc;
+          q = qn;
+          if (pco != spc) q = *(QP)((const char*)recs + ((u64)pco << 3));
           ++it;
         } while (!__any(ncv != 0) && it < n);
         L.h.exec += ncv ? it - 1 : it;                    // the lane that raised the flag did not execute in the last iteration
