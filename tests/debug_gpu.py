@@ -24,7 +24,7 @@ def orc_run(p, k):
     return ro, h
 
 
-for seed in [int(a) for a in sys.argv[1:]]:
+for seed in ([int(a) for a in sys.argv[1:]] if __name__ == "__main__" else []):
     p = WL.fuzz_program(seed, n=300)
     full, h = orc_run(p, p.max_inst)
     lo, hi = 0, full["exec"]

@@ -103,6 +103,18 @@ def test_compute_kernel_no_trace_and_slices():
     _check([p] * n, res, seeds=seeds, trace=False)
 
 
+def test_compute_kernel_4096_one_hart_per_wave():
+    """The bench configuration: 4096 instances, one hart per wave, vector hot loop (above the scalar-mode limit);
+    every hart checked against the oracle."""
+    p = WL.compute_kernel(iters=1)
+    n = 4096
+    seeds = [(WL.compute_seed(i), i) for i in range(n)]
+    b, left, res = _run_batch([p] * n, seeds=seeds, lanes=1, same_elf=True, trace=True)
+    b.close()
+    assert left == 0
+    _check([p] * n, res, seeds=seeds, trace=True)
+
+
 def test_fuzz_programs():
     progs = [WL.fuzz_program(s, n=300) for s in range(200)]
     b, left, res = _run_batch(progs)

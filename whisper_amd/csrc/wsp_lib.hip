@@ -73,6 +73,9 @@ struct DevMem {
 #ifndef WSP_WAVES_PER_EU
 #define WSP_WAVES_PER_EU 4
 #endif
+#ifndef WSP_SCALAR_MAX_WAVES
+#define WSP_SCALAR_MAX_WAVES 1024u
+#endif
 extern __shared__ __align__(16) u64 wsp_lds[];
 
 __device__ __forceinline__ u32 ln_of(const DevState& d)
@@ -140,6 +143,10 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, H
   return r;
 }
 
+// v_writelane_b32 (this clang has no __builtin for it): the LLVM intrinsic, bound by name.
+extern "C" __device__ int wsp_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+#define WSP_WRITELANE(v, l, o) wsp_writelane_i32((v), (l), (o))
+
 // Wave-wide minimum of a u32 (all 64 lanes participate).
 __device__ __forceinline__ u32 wave_min_u32(u32 v)
 {
@@ -190,6 +197,158 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 
   const bool zca = (d.isa & ISA_C) != 0;                 // without C, taken control transfers can trap: general path
 
+  // ================================================================================================================
+  // One hart per wave (lanes_per_wave == 1, the layout picked for batches that fit the chip with one hart per wave):
+  // the interpreter runs on the scalar unit.  Everything about the hart is wave-uniform, so pc, operands and results
+  // live in SGPRs, the integer register file sits across the lanes of two VGPRs (lane r = x[r]; lane 0 is the write
+  // sink for rd = x0, lane 32 the constant zero, exactly like the LDS slots) and is accessed with v_readlane /
+  // v_writelane, and records come through the scalar cache (the image is read-only while the kernel runs).  Arena
+  // data is read and written with vector instructions only: the scalar cache is never used for anything the kernel
+  // writes.  The CU has one scalar unit for its four SIMDs, so this mode pays only while few waves share a CU: measured
+  // +20 % at 1024 harts (one wave per SIMD), level at 2048, -10 % at 4096 (four waves per SIMD) against the vector loop
+  // below; it is used up to WSP_SCALAR_MAX_WAVES waves.
+  if (d.lpw == 1 && d.n_waves <= WSP_SCALAR_MAX_WAVES) {
+#define RFL(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+#define RFL64(x) ((u64)RFL((u32)(x)) | ((u64)RFL((u32)((x) >> 32)) << 32))
+    u64 u_pc = RFL64(L.h.pc), u_exec = RFL64(L.h.exec), u_thash = RFL64(L.h.thash), u_stop = RFL64(stop_at);
+    u32 u_flags = RFL(L.h.flags), u_status = RFL(d.hot32[H32_STATUS * S + slot]);
+    if (wave >= d.n_harts) u_status = ST_STOP_LIMIT;   // lpw == 1: hart index = wave (uniform; `hart` itself differs per lane)
+    u64 tlo = RFL64(L.text_lo), thi = RFL64(L.text_hi), tohost = RFL64(L.tohost);
+    const u64 mbase = d.mem_base, msize = d.mem_size;
+    const char* recs_u = (const char*)(size_t)RFL64((u64)(size_t)recs);
+    u8* const arena_u = d.arena + (size_t)wave * d.mem_size;
+    // register file: LDS slots -> lanes
+    u32 xlo = 0, xhi = 0;
+    if (lane <= 32) { const u64 v = L.m.xs[lane]; xlo = (u32)v; xhi = (u32)(v >> 32); }
+#define XR(l) ((u64)(u32)__builtin_amdgcn_readlane((int)xlo, (int)(l)) | ((u64)(u32)__builtin_amdgcn_readlane((int)xhi, (int)(l)) << 32))
+#define XW(l, val) do { const u64 v_ = (val); xlo = (u32)WSP_WRITELANE((int)(u32)v_, (int)(l), (int)xlo); \
+                        xhi = (u32)WSP_WRITELANE((int)(u32)(v_ >> 32), (int)(l), (int)xhi); } while (0)
+    typedef wsp_u32x4 QT;                                            // scalar loads come in 1/2/4/8 dwords
+    typedef const __attribute__((address_space(4))) QT* CQ;          // constant address space: scalar loads
+
+    while (u_status == ST_RUNNING && u_exec < u_stop) {
+      const u64 off64 = u_pc - tlo;
+      const u32 text_len = (u32)(thi - tlo);
+      if ((u_flags & HF_HOT) && off64 < (u64)text_len) {
+        u32 pco = (u32)off64;
+        const u64 left = u_stop - u_exec;
+        const u32 n = left > 0x40000000ULL ? 0x40000000u : (u32)left;
+        u32 it = 0; bool nc = false;
+        QT q = *(CQ)(recs_u + ((u64)pco << 3));
+        do {
+          const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 ofs = q.z; const u32 raw = q.w;
+          const u32 uop = w0 & 0xff, ld = (w0 >> 8) & 31;
+          const u32 size = 2u + ((w0 >> 27) & 2u);
+          const u32 spc = pco + size;
+          const QT qn = *(CQ)(recs_u + ((u64)spc << 3));              // next sequential record: in flight during this step
+          const u64 a = XR((ofs >> 3) & 63), b2 = XR((ofs >> 19) & 63);
+          const u64 simm = (u64)(i64)imm, bi = b2 + simm;
+          u32 npc = spc;
+          u64 tr_k = 1ULL << 60, tr_v = 0;
+          // every case leaves its result in (wl, wv): one register-file write site after the chain (wl = 0: the sink lane)
+          u32 wl = 0; u64 wv = 0;
+#define SWX(val) do { wv = (val); wl = ld; } while (0)
+          if (uop == OP_ADD) SWX(a + bi);
+          else if (uop >= OP_LB && uop <= OP_LWU) {
+            const u32 k = uop - OP_LB, sz = 1u << (k & 3);
+            const u64 va = a + simm, off = va - mbase;
+            if ((va & (sz - 1)) || off > msize - sz || va == tohost) nc = true;
+            else {
+              const u8* p = arena_u + off;
+              u64 v;
+              if (k == 2) v = (u64)(i64)*(const i32*)p; else if (k == 3) v = *(const u64*)p;
+              else if (k == 6) v = *(const u32*)p; else if (k == 4) v = *p; else if (k == 0) v = (u64)(i64)*(const int8_t*)p;
+              else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;
+              SWX(RFL64(v));
+            }
+          } else if (uop >= OP_BEQ && uop <= OP_BGEU) {
+            const u32 m = uop - OP_BEQ;
+            const bool c = m < 2 ? a == b2 : m < 4 ? (i64)a < (i64)b2 : a < b2;
+            if (c != (bool)(m & 1)) {
+              const u32 t = pco + (u32)imm;
+              if (!zca || t >= text_len) nc = true; else npc = t & ~1u;
+            }
+          } else if (uop == OP_ADDW) SWX((u64)(i64)(i32)((u32)a + (u32)bi));
+          else if (uop == OP_MULW) SWX((u64)(i64)(i32)((u32)a * (u32)bi));
+          else if (uop == OP_SLL) SWX(a << (bi & 63));
+          else if (uop == OP_SRL) SWX(a >> (bi & 63));
+          else if (uop >= OP_SB && uop <= OP_SD) {
+            const u32 k = uop - OP_SB, sz = 1u << k;
+            const u64 va = a + simm, off = va - mbase;
+            if ((va & (sz - 1)) || off > msize - sz || va == tohost || va == tohost + 4 || (va + sz > tlo && va < thi)) nc = true;
+            else {
+              u8* p = arena_u + off;
+              const u64 sv = k == 3 ? b2 : (b2 & ((1ULL << (8 * sz)) - 1));
+              if (k == 2) *(u32*)p = (u32)sv; else if (k == 3) *(u64*)p = sv; else if (k == 0) *p = (u8)sv; else *(u16*)p = (u16)sv;
+              if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }
+            }
+          } else if (uop == OP_AND) SWX(a & bi);
+          else if (uop == OP_MUL) SWX(a * bi);
+          else if (uop == OP_JAL || uop == OP_JALR) {
+            const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((a + simm) & ~1ULL) - tlo);
+            if (!zca || t >= (u64)text_len) nc = true;
+            else { SWX(tlo + pco + size); npc = (u32)t & ~1u; }
+          } else switch (uop) {
+            case OP_SUB: SWX(a - bi); break;
+            case OP_SLT: SWX((u64)((i64)a < (i64)bi)); break;
+            case OP_SLTU: SWX((u64)(a < bi)); break;
+            case OP_XOR: SWX(a ^ bi); break;
+            case OP_SRA: SWX((u64)((i64)a >> (bi & 63))); break;
+            case OP_OR: SWX(a | bi); break;
+            case OP_SUBW: SWX((u64)(i64)(i32)((u32)a - (u32)bi)); break;
+            case OP_SLLW: SWX((u64)(i64)(i32)((u32)a << (bi & 31))); break;
+            case OP_SRLW: SWX((u64)(i64)(i32)((u32)a >> (bi & 31))); break;
+            case OP_SRAW: SWX((u64)(i64)((i32)a >> (bi & 31))); break;
+            case OP_AUIPC: SWX(tlo + pco + simm); break;
+            case OP_NOP: break;
+            default: nc = true; break;                    // not in the inline subset
+          }
+#undef SWX
+          XW(wl, wv);
+          if (TRACE && wl) { tr_k = (u64)wl ^ (1ULL << 60); tr_v = wv; }
+          // keep all four destination registers of the in-flight record load reserved until here: a register of the
+          // tuple that is reused early forces a wait for the whole load right after it was issued
+          asm volatile("" :: "s"(qn.x), "s"(qn.y), "s"(qn.z), "s"(qn.w));
+          if (nc) break;
+          if (TRACE) {
+            u64 t = u_thash;
+            t = fold(t, tlo + pco);
+            t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
+            t = fold(t, tr_k); t = fold(t, tr_v);
+            u_thash = t;
+          }
+          q = qn;
+          if (npc != spc) q = *(CQ)(recs_u + ((u64)npc << 3));
+          pco = npc;
+          ++it;
+        } while (it < n);
+        u_exec += it;
+        u_pc = tlo + pco;
+        if (!nc) continue;
+      }
+      // ---- one general step: registers to LDS, lane 0 runs the out-of-line path, registers back
+      // (the register file crosses lanes through LDS: workgroup barriers order the accesses; one wave per workgroup)
+      if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
+      __syncthreads();
+      HotRegs hr; hr.pc = u_pc; hr.exec = u_exec; hr.thash = u_thash; hr.stop_at = u_stop; hr.flags = u_flags; hr.status = u_status;
+      if (lane == 0) hr = wsp_cold<TRACE>(dp, blockIdx.x, 0, hr);
+      u_pc = RFL64(hr.pc); u_exec = RFL64(hr.exec); u_thash = RFL64(hr.thash); u_flags = RFL(hr.flags); u_status = RFL(hr.status);
+      __syncthreads();
+      if (lane <= 32) { const u64 v = L.m.xs[lane]; xlo = (u32)v; xhi = (u32)(v >> 32); }
+      {                                                    // the general step may have changed nothing else that the loop caches
+        const u32 pg = d.prog[blockIdx.x * 64];
+        if (pg != ~0u) { const ProgDev pd = d.progs[pg]; tlo = RFL64(pd.text_lo); thi = RFL64(pd.text_hi); }
+        tohost = RFL64(d.tohost[blockIdx.x * 64]);
+      }
+    }
+    if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
+    __syncthreads();
+    L.h.pc = u_pc; L.h.exec = u_exec; L.h.thash = u_thash; L.h.flags = u_flags; L.h.status = active ? u_status : (u32)ST_STOP_LIMIT;
+#undef XR
+#undef XW
+#undef RFL64
+#undef RFL
+  } else
   // Outer loop: { hot inner loop (no calls) ; one general step for the lanes that asked for it }.
   //
   // Hot inner loop.  Entered only when every running lane of the wave is hot (HF_HOT) with its pc inside its pre-decoded
