@@ -300,7 +300,8 @@ enum ColdIx {
 // HF_HOT: the hart may use the pre-decoded fetch and the trap-free inline subset: M-mode, MPRV clear,
 // code not self-modified, no counter inhibited (so every hot step advances exec, cycle, instret and
 // retired by exactly one).  Recomputed by update_hot_flag() after anything that can change it.
-enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16 };
+enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16,
+             HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -842,6 +843,7 @@ template <class MEM> struct Lane {
     bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
                (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
     h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
+    h.flags = (((h.mstatus >> MST_FS_SH) & 3) == 3) ? (h.flags | HF_FS_DIRTY) : (h.flags & ~(u32)HF_FS_DIRTY);
   }
   template <bool TRACE> WSP_HD void wx_fast(u32 rd, u64 v)
   {

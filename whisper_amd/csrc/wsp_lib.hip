@@ -121,7 +121,7 @@ __device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevSt
 // cold steps; exec/cycle/instret/retired are synchronised lazily: a hot step advances all four by
 // exactly one (HF_HOT guarantees no inhibit, no trap), so the HBM copies are brought up to date
 // from the difference between the register exec counter and the stored one.
-struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status; };
+struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status, fcsr; };
 
 // The general path, out of line: rebuilds the full lane from HBM, runs one complete general step
 // (interrupt poll, fetch, full exec(), retire, commit record) and stores the lane back.
@@ -135,11 +135,39 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, H
   wsp_load_hot(L, d, slot);
   const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
   L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
-  L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status;
+  L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
   L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
   L.template cold_step<TRACE>(recs);
   wsp_store_hot(L, d, slot);
-  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status;
+  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
+  return r;
+}
+
+// The "warm" path: one F/D computational instruction (arithmetic, convert, compare, move, classify) of a hart that is
+// hot and whose mstatus.FS is already Dirty.  Such an instruction reads and writes only the LDS register files and
+// fflags, cannot trap once its rounding mode is known to be legal, and advances all counters by one like any hot step:
+// no HBM state is touched, and the function is small enough to need no callee-saved registers.  handled = 0 sends the
+// instruction to the general path (reserved rounding mode: illegal-instruction trap).
+struct WarmRet { u64 thash; u32 fcsr, handled; };
+template <bool TRACE>
+__device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr)
+{
+  Lane<DevMem> L;
+  L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
+  L.m.cold_ = nullptr; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
+  L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
+  L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
+  const u32 op = w0 & 0xff;
+  WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0;
+  const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
+  int rm = 0;
+  if (uses_rm && !L.fp_rm((u32)imm & 7, rm)) return r;
+  L.exec_fp(rec, L.m.rx(rec_rs1(rec)), pc);
+  L.template commit<TRACE>(pc, raw, (w0 & F_SIZE4) ? 4 : 2, PRV_M, 0);
+  r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = 1;
   return r;
 }
 
@@ -176,7 +204,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   wsp_lane_setup(L, d, wave, ln, slot, recs);
   L.h.pc = d.hot64[H64_PC * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.thash = d.hot64[H64_THASH * S + slot];
   L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
-  L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot];
+  L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.fcsr = d.hot32[H32_FCSR * S + slot];
   L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / mip / mie / flags
   u64 stop_at;
   {
@@ -211,7 +239,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 #define RFL(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
 #define RFL64(x) ((u64)RFL((u32)(x)) | ((u64)RFL((u32)((x) >> 32)) << 32))
     u64 u_pc = RFL64(L.h.pc), u_exec = RFL64(L.h.exec), u_thash = RFL64(L.h.thash), u_stop = RFL64(stop_at);
-    u32 u_flags = RFL(L.h.flags), u_status = RFL(d.hot32[H32_STATUS * S + slot]);
+    u32 u_flags = RFL(L.h.flags), u_status = RFL(d.hot32[H32_STATUS * S + slot]), u_fcsr = RFL(L.h.fcsr);
     if (wave >= d.n_harts) u_status = ST_STOP_LIMIT;   // lpw == 1: hart index = wave (uniform; `hart` itself differs per lane)
     u64 tlo = RFL64(L.text_lo), thi = RFL64(L.text_hi), tohost = RFL64(L.tohost);
     const u64 mbase = d.mem_base, msize = d.mem_size;
@@ -326,13 +354,24 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         u_pc = tlo + pco;
         if (!nc) continue;
       }
-      // ---- one general step: registers to LDS, lane 0 runs the out-of-line path, registers back
+      // ---- one general (or warm) step: registers to LDS, lane 0 runs the out-of-line path, registers back
       // (the register file crosses lanes through LDS: workgroup barriers order the accesses; one wave per workgroup)
       if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
       __syncthreads();
-      HotRegs hr; hr.pc = u_pc; hr.exec = u_exec; hr.thash = u_thash; hr.stop_at = u_stop; hr.flags = u_flags; hr.status = u_status;
-      if (lane == 0) hr = wsp_cold<TRACE>(dp, blockIdx.x, 0, hr);
-      u_pc = RFL64(hr.pc); u_exec = RFL64(hr.exec); u_thash = RFL64(hr.thash); u_flags = RFL(hr.flags); u_status = RFL(hr.status);
+      HotRegs hr; hr.pc = u_pc; hr.exec = u_exec; hr.thash = u_thash; hr.stop_at = u_stop; hr.flags = u_flags; hr.status = u_status; hr.fcsr = u_fcsr;
+      if (lane == 0) {
+        bool done = false;
+        if (FP && (u_flags & (HF_HOT | HF_FS_DIRTY)) == (HF_HOT | HF_FS_DIRTY) && u_pc - tlo < thi - tlo) {
+          const wsp_u32x4 q = *(const wsp_u32x4*)(recs_u + (((u_pc - tlo) >> 1) << 4));
+          const u32 op = q.x & 0xff;
+          if (op >= OP_FADD && op <= OP_FMV_X2F) {
+            const WarmRet w = wsp_warm<TRACE>(d.isa, 0, WSP_XSLOTS * 8, q.x, (i32)q.y, q.w, u_pc, u_thash, u_fcsr);
+            if (w.handled) { hr.pc = u_pc + ((q.x & F_SIZE4) ? 4 : 2); hr.exec = u_exec + 1; hr.thash = w.thash; hr.fcsr = w.fcsr; done = true; }
+          }
+        }
+        if (!done) hr = wsp_cold<TRACE>(dp, blockIdx.x, 0, hr);
+      }
+      u_pc = RFL64(hr.pc); u_exec = RFL64(hr.exec); u_thash = RFL64(hr.thash); u_flags = RFL(hr.flags); u_status = RFL(hr.status); u_fcsr = RFL(hr.fcsr);
       __syncthreads();
       if (lane <= 32) { const u64 v = L.m.xs[lane]; xlo = (u32)v; xhi = (u32)(v >> 32); }
       {                                                    // the general step may have changed nothing else that the loop caches
@@ -343,7 +382,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     }
     if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
     __syncthreads();
-    L.h.pc = u_pc; L.h.exec = u_exec; L.h.thash = u_thash; L.h.flags = u_flags; L.h.status = active ? u_status : (u32)ST_STOP_LIMIT;
+    L.h.pc = u_pc; L.h.exec = u_exec; L.h.thash = u_thash; L.h.flags = u_flags; L.h.fcsr = u_fcsr; L.h.status = active ? u_status : (u32)ST_STOP_LIMIT;
 #undef XR
 #undef XW
 #undef RFL64
@@ -377,6 +416,8 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         const char* const ldsb = (const char*)wsp_lds;
         const u64 tlo = L.text_lo, thi = L.text_hi, tohost = L.tohost, mbase = L.mem_base, msize = L.mem_size;
         u64* const sinkx = (u64*)(ldsb + xb);                                  // LDS slot 0 of this lane: register write sink
+        const u32 foff = d.lpw * (WSP_XSLOTS * 8);                              // x block -> f block of the same lane
+        const bool fsd = (L.h.flags & HF_FS_DIRTY) != 0, boxd = (d.isa & ISA_D) != 0;
         u8* const gsink = (u8*)(d.cold + (size_t)CI_COUNT * S + (blockIdx.x * 64 + ln_of(d)));   // 8-byte global store sink
         // ---- fetch.  pco <= text_len always holds (control transfers are range-checked, sequential flow stops at the two
         // sentinel records behind the image), so record loads need no guard.  The record of the sequentially next
@@ -441,7 +482,28 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }                                                            \
           } else if (uop == OP_AND) WSP_WX(aa & cc);                                                                       \
           else if (uop == OP_MUL) WSP_WX(aa * cc);                                                                         \
-          else if (uop == OP_JAL || uop == OP_JALR) {                                                                      \
+          else if (FP && uop >= OP_FLW && uop <= OP_FSD) {                                                                 \
+            /* flw fld fsw fsd with FS already Dirty (float.cpp:281-321, 1019-1057): f registers in LDS, no CSR change */  \
+            const bool st = uop >= OP_FSW, dw = (uop & 1u) == (OP_FLD & 1u);                                               \
+            const u32 sz = dw ? 8u : 4u;                                                                                   \
+            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            bool ok = fsd & ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);                                 \
+            if (st) {                                                                                                      \
+              ok = ok & (va != tohost + 4) & !((va + sz > tlo) & (va < thi));                                              \
+              const u64 fv = *(const u64*)(ldsb + (xb + foff + ((w0 >> 15) & 0xf8u)));     /* f[rs2], raw bits */         \
+              u8* p = ok ? L.m.p(off) : gsink;                                                                             \
+              const u64 sv = dw ? fv : (fv & 0xffffffffULL);                                                               \
+              if (dw) *(u64*)p = sv; else *(u32*)p = (u32)sv;                                                              \
+              if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }                                                          \
+            } else {                                                                                                       \
+              const u8* p = L.m.p(ok ? off : 0);                                                                           \
+              u64 v;                                                                                                       \
+              if (dw) v = *(const u64*)p; else v = (u64)*(const u32*)p | (boxd ? 0xffffffff00000000ULL : 0);               \
+              *(u64*)(ldsb + (ok ? (xb + foff + ((w0 >> 5) & 0xf8u)) : xb)) = v;                                          \
+              if (TRACE) { tr_k = (u64)((w0 >> 8) & 31) ^ (2ULL << 60); tr_v = v; }                                        \
+            }                                                                                                              \
+            ncv |= ok ? 0u : 1u;                                                                                           \
+          } else if (uop == OP_JAL || uop == OP_JALR) {                                                                      \
             const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((aa + simm) & ~1ULL) - tlo);                           \
             const bool ok = zca & (t < (u64)text_len);                                                                     \
             const u64 link = tlo + pco + size;                                                                             \
@@ -509,16 +571,29 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         need_cold = ncv != 0;
       }
     }
+    if (FP && need_cold && (L.h.flags & (HF_HOT | HF_FS_DIRTY)) == (HF_HOT | HF_FS_DIRTY)) {
+      // F/D computational instruction of a hot hart with FS already Dirty: the warm path (LDS + fflags only)
+      Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+      if (L.hot_fetch(recs, rec) && (rec.w0 & 0xff) >= OP_FADD && (rec.w0 & 0xff) <= OP_FMV_X2F) {
+        const u32 ln2 = ln_of(d);
+        const WarmRet w = wsp_warm<TRACE>(d.isa, ln2 * (WSP_XSLOTS * 8), (d.lpw + ln2) * (WSP_XSLOTS * 8), rec.w0, rec.imm, rec.raw,
+                                          L.h.pc, L.h.thash, L.h.fcsr);
+        if (w.handled) {
+          L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
+          need_cold = false;
+        }
+      }
+    }
     if (need_cold) {
       // A cold call is a context switch: every per-lane value of the hot loop is either passed through HotRegs or
       // rebuilt from the kernel arguments afterwards.
       HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.stop_at = stop_at;
-      hr.flags = L.h.flags; hr.status = L.h.status;
+      hr.flags = L.h.flags; hr.status = L.h.status; hr.fcsr = L.h.fcsr;
       hr = wsp_cold<TRACE>(dp, blockIdx.x, ln_of(d), hr);
       const u32 ln2 = ln_of(d);
       wsp_lane_setup(L, d, blockIdx.x, ln2, blockIdx.x * 64 + ln2, recs);
       L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; stop_at = hr.stop_at;
-      L.h.flags = hr.flags; L.h.status = hr.status;
+      L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
     }
   }
 
@@ -531,7 +606,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     const u64 dlt = L.h.exec - d.hot64[H64_EXEC * S + slot];
     d.hot64[H64_CYCLE * S + slot] += dlt; d.hot64[H64_INSTRET * S + slot] += dlt; d.hot64[H64_RETIRED * S + slot] += dlt;
     d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_THASH * S + slot] = L.h.thash;
-    d.hot32[H32_FLAGS * S + slot] = L.h.flags; d.hot32[H32_STATUS * S + slot] = L.h.status;
+    d.hot32[H32_FLAGS * S + slot] = L.h.flags; d.hot32[H32_STATUS * S + slot] = L.h.status; d.hot32[H32_FCSR * S + slot] = L.h.fcsr;
   }
   const unsigned long long still = __ballot(active && L.h.status == ST_RUNNING);
   if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
