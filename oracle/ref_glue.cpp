@@ -135,3 +135,28 @@ int ref_csr_name(unsigned num, char* buf, int n)
 }
 
 }
+
+// ---------------------------------------------------------------------------------------------
+// The reference's PmpManager (PmpManager.hpp, header only) driven the way Hart::updateMemoryProtection does
+// (Hart.cpp:842-899): 8 pmpcfg values (pmpcfg0,2,..14) and 64 pmpaddr values in, permission bits out.
+extern "C" {
+void* ref_pmp_new(const uint64_t* cfg8, const uint64_t* addr64)
+{
+  auto* m = new PmpManager();
+  for (unsigned ix = 0; ix < 64; ++ix) {
+    unsigned config = unsigned(cfg8[ix >> 3] >> (8 * (ix & 7))) & 0xff;
+    Pmp pmp; uint64_t low = 0, high = 0;
+    if (m->unpackMemoryProtection(config, addr64[ix], ix ? addr64[ix - 1] : 0, false, pmp, low, high) and pmp.type() != Pmp::Type::Off)
+      m->defineRegion(low, high, pmp, ix);
+  }
+  m->enable(true);
+  return m;
+}
+void ref_pmp_free(void* p) { delete static_cast<PmpManager*>(p); }
+unsigned ref_pmp_perm(void* p, unsigned priv, uint64_t addr)
+{
+  auto pmp = static_cast<PmpManager*>(p)->accessPmp(PrivilegeMode(priv), addr);
+  return unsigned(pmp.isRead()) | (unsigned(pmp.isWrite()) << 1) | (unsigned(pmp.isExec()) << 2);
+}
+uint64_t ref_pmp_legalize_cfg(uint64_t prev, uint64_t next) { PmpManager m; return m.legalizePmpcfg<uint64_t>(prev, next); }
+}

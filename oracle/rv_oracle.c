@@ -134,6 +134,8 @@ struct rvo_hart {
   u32 htif_dev;
   /* reservation (Memory.hpp:450-543) */
   int lr_valid; u64 lr_addr; unsigned lr_size;
+  u64 pmpcfg[8];            /* pmpcfg0,2,..,14 (RV64: even numbered only, CsRegs.cpp:4777-4784) */
+  u64 pmpaddr[64];
   /* per-instruction trace capture */
   int has_exc;
   int ch_ireg; int ch_freg;
@@ -244,7 +246,7 @@ static int csr_class(const rvo_hart* h, unsigned num)
     default: break;
   }
   /* Implemented in the reference's default configuration but not modelled here. */
-  if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : -1;  /* pmpcfg (even only on rv64), pmpaddr */
+  if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   /* pmpcfg (even only on rv64), pmpaddr0..63 */
   if (num >= 0xB03 && num <= 0xB1F) return -1;      /* mhpmcounter3..31 */
   if (num >= 0x323 && num <= 0x33F) return -1;      /* mhpmevent3..31 */
   if (num == 0x747) return -1;                      /* mseccfg */
@@ -275,12 +277,81 @@ static u64 csr_peek(const rvo_hart* h, unsigned num)
     case C_MINSTRET: case C_INSTRET: return h->instret;
     case C_TIME: return h->time_;
     case C_MHARTID: return h->cfg.hart_id;
-    default: return 0;
+    default:
+      if (num >= 0x3A0 && num <= 0x3AF) return h->pmpcfg[(num - 0x3A0) >> 1];
+      if (num >= 0x3B0 && num <= 0x3EF) return h->pmpaddr[num - 0x3B0];    /* grain G = 0: read value = stored value */
+      return 0;
   }
 }
 
 int rvo_peek_csr(const rvo_hart* h, unsigned num, u64* v)
 { if (csr_class(h, num) != 1) return -1; *v = csr_peek(h, num); return 0; }
+
+
+/* ------------------------------------------------------------------ PMP (PmpManager.hpp, Hart.cpp:842-899) */
+static unsigned pmp_cfg_byte(const rvo_hart* h, unsigned ix) { return (unsigned)(h->pmpcfg[ix >> 3] >> (8 * (ix & 7))) & 0xff; }
+
+/* PmpManager::legalizePmpcfg (PmpManager.hpp:480-551) without Smepmp, grain G = 0, TOR and NA4 enabled */
+static u64 legalize_pmpcfg(u64 prev, u64 next)
+{
+  u64 legal = 0;
+  for (unsigned i = 0; i < 8; ++i) {
+    unsigned pb = (unsigned)(prev >> (8 * i)) & 0xff, nb = (unsigned)(next >> (8 * i)) & 0xff;
+    if (pb >> 7) nb = pb;                                   /* locked: keep */
+    else if ((nb & 3) == 2) nb = (pb & 7) | (nb & ~7u);     /* w=1 r=0 reserved: keep old xwr */
+    legal |= (u64)nb << (8 * i);
+  }
+  return legal;
+}
+
+/* CsRegs::isPmpaddrLocked (CsRegs.cpp:6773-6793) */
+static int pmpaddr_locked(const rvo_hart* h, unsigned ix)
+{
+  if (pmp_cfg_byte(h, ix) & 0x80) return 1;
+  if (ix >= 63) return 0;
+  unsigned nb = pmp_cfg_byte(h, ix + 1);
+  return (nb & 0x80) && ((nb >> 3) & 3) == 1;
+}
+
+/* Region of entry ix: PmpManager::unpackMemoryProtection (PmpManager.hpp:417-468) + defineRegion word alignment (:233-236).
+ * Returns 0 when the entry is off. */
+static int pmp_region(const rvo_hart* h, unsigned ix, u64* a0, u64* a1)
+{
+  unsigned cfg = pmp_cfg_byte(h, ix), type = (cfg >> 3) & 3;
+  if (!type) return 0;
+  u64 v = h->pmpaddr[ix], lo, hi;
+  if (type == 1) {                                          /* TOR */
+    lo = (ix ? h->pmpaddr[ix - 1] : 0) << 2;
+    hi = v << 2; if (hi > 0) hi -= 1;
+  } else {
+    u64 size_m1 = 3, napot = v;
+    if (type == 3) {
+      unsigned rzi;
+      if (v == ~0ULL) { napot = 0; rzi = 64; }
+      else { rzi = (unsigned)__builtin_ctzll(~v); napot = (napot >> rzi) << rzi; }
+      size_m1 = rzi + 3 >= 64 ? ~0ULL : ((1ULL << (rzi + 3)) - 1);
+    }
+    lo = napot << 2; hi = lo + size_m1;
+  }
+  *a0 = (lo >> 2) << 2; *a1 = ((hi >> 2) << 2) + 3;
+  return 1;
+}
+
+/* PmpManager::getPmp (PmpManager.hpp:155-177): r=1 w=2 x=4 for privilege pm at addr.  First matching entry in index
+ * order; M mode ignores entries that are not locked; no match: M everything, S/U nothing. */
+unsigned rvo_pmp_perm(const rvo_hart* h, unsigned pm, u64 addr)
+{
+  for (unsigned ix = 0; ix < 64; ++ix) {
+    u64 a0, a1;
+    if (!pmp_region(h, ix, &a0, &a1)) continue;
+    if (addr >= a0 && addr <= a1) {
+      unsigned cfg = pmp_cfg_byte(h, ix);
+      if (pm == PRV_M && !(cfg & 0x80)) return 7;
+      return cfg & 7;
+    }
+  }
+  return pm == PRV_M ? 7 : 0;
+}
 
 /* Poke = host-side write with the write mask applied, no side effects on counters. */
 static void csr_store(rvo_hart* h, unsigned num, u64 v, int record);
@@ -333,7 +404,10 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
     case C_SATP: h->satp = v; break;
     case C_MCYCLE: h->cycle = v; break;
     case C_MINSTRET: h->instret = v; break;
-    default: break;
+    default:
+      if (num >= 0x3A0 && num <= 0x3AF) { unsigned k = (num - 0x3A0) >> 1; h->pmpcfg[k] = legalize_pmpcfg(h->pmpcfg[k], v) & 0x9f9f9f9f9f9f9f9fULL; }
+      else if (num >= 0x3B0 && num <= 0x3EF) { if (!pmpaddr_locked(h, num - 0x3B0)) h->pmpaddr[num - 0x3B0] = v & 0x003fffffffffffffULL; }
+      break;
   }
   if (record) record_csr(h, num);
 }
@@ -488,7 +562,7 @@ static void illegal(rvo_hart* h, u32 inst) { take_exception(h, 2, h->curr_pc, in
 
 /* ------------------------------------------------------------------ memory access checks */
 /* PMP with no programmed entries: M-mode allowed, S/U denied (PmpManager.hpp:155-177). */
-static inline int pmp_ok(const rvo_hart* h, unsigned priv) { (void)h; return priv == PRV_M; }
+static inline int pmp_ok(const rvo_hart* h, unsigned priv, u64 addr, unsigned need) { return (rvo_pmp_perm(h, priv, addr) & need) != 0; }
 
 static unsigned eff_ldst_priv(const rvo_hart* h)
 {
@@ -498,18 +572,18 @@ static unsigned eff_ldst_priv(const rvo_hart* h)
 
 /* determineLoadException / determineStoreException (Hart.cpp:1988-2154, 13786-13935), bare
  * translation only. Returns 0 if OK, else sets *tval and returns 1. */
-static int check_access(const rvo_hart* h, u64 va, unsigned size, u64* tval)
+static int check_access(const rvo_hart* h, u64 va, unsigned size, unsigned need /* 1 load, 2 store/amo */, u64* tval)
 {
   unsigned pm = eff_ldst_priv(h);
   u64 mask = size - 1;
   if (!(va & mask)) {
-    if (!pmp_ok(h, pm) || !in_mem(h, va, size)) { *tval = va; return 1; }
+    if (!pmp_ok(h, pm, va, need) || !in_mem(h, va, size)) { *tval = va; return 1; }
     return 0;
   }
   u64 va2 = (va + size - 1) & ~mask;
   unsigned n1 = (unsigned)(va2 - va);
-  if (!pmp_ok(h, pm) || !in_mem(h, va, n1)) { *tval = va; return 1; }
-  if (!in_mem(h, va2, size)) { *tval = va2; return 1; }
+  if (!pmp_ok(h, pm, va, need) || !in_mem(h, va, n1)) { *tval = va; return 1; }
+  if (!pmp_ok(h, pm, va2, need) || !in_mem(h, va2, size)) { *tval = va2; return 1; }
   return 0;
 }
 
@@ -525,7 +599,7 @@ static int do_load(rvo_hart* h, u64 va, unsigned size, u64* out)
 {
   u64 tval;
   if (ldst_translate_unsupported(h)) return 0;
-  if (check_access(h, va, size, &tval)) { ldst_exception(h, 5, tval); return 0; }
+  if (check_access(h, va, size, 1, &tval)) { ldst_exception(h, 5, tval); return 0; }
   if (h->cfg.tohost_valid && va == h->cfg.tohost) { *out = 0; return 1; }   /* Hart.cpp:2509-2513 */
   *out = ld_le(h->mem + (va - h->cfg.mem_base), size);
   return 1;
@@ -551,7 +625,7 @@ static int do_store(rvo_hart* h, u64 va, unsigned size, u64 val)
 {
   u64 tval;
   if (ldst_translate_unsupported(h)) return 0;
-  if (check_access(h, va, size, &tval)) { ldst_exception(h, 7, tval); return 0; }
+  if (check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, tval); return 0; }
   u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
   h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;
   if (h->cfg.tohost_valid && (va == h->cfg.tohost || va == h->cfg.tohost + 4)) { store_tohost(h, va, sv, size); return 1; }
@@ -679,6 +753,14 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
     unsigned mode = (unsigned)(next >> 60);
     if (mode != 0 && mode != 8 && mode != 9 && mode != 10) goto done;  /* unsupported MODE: dropped (13284-13294) */
     if (mode != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return; }
+  }
+  if (num >= 0x3B0 && num < 0x3EF && !pmpaddr_locked(h, num - 0x3B0)) {
+    /* postCsrUpdate (Hart.cpp:4672-4679) refreshes the region table only when the written entry itself is on: a
+     * pmpaddr write under an Off entry whose successor is an active TOR entry leaves the reference with a stale lower
+     * bound.  Not modelled: stop instead of diverging. */
+    unsigned ix = num - 0x3B0;
+    if (((pmp_cfg_byte(h, ix) >> 3) & 3) == 0 && ((pmp_cfg_byte(h, ix + 1) >> 3) & 3) == 1 && (next & 0x003fffffffffffffULL) != h->pmpaddr[ix])
+    { stop(h, RVO_STOP_UNSUPPORTED, 0x181); return; }
   }
   csr_store(h, num, next, 1);
   if ((num == C_FFLAGS || num == C_FRM || num == C_FCSR)) mark_fs_dirty(h);  /* postCsrUpdate: FS dirty on fp csr write */
@@ -962,7 +1044,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
   if (f5 == 2) {                                            /* lr: amo.cpp:142-266 */
     if (rs2 != 0) { illegal(h, raw); return; }
     if (ldst_translate_unsupported(h)) return;
-    int bad = check_access(h, va, size, &tval) || (va & (size - 1));
+    int bad = check_access(h, va, size, 1, &tval) || (va & (size - 1));
     if (bad) { ldst_exception(h, 5, va); return; }
     u64 v = ld_le(h->mem + (va - h->cfg.mem_base), size);
     if (size == 4) v = (u64)(i64)(i32)v;
@@ -974,7 +1056,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
     if (ldst_translate_unsupported(h)) return;
     int exc = 0;
     if (va & (size - 1)) { ldst_exception(h, 7, va); exc = 1; }
-    else if (check_access(h, va, size, &tval)) { ldst_exception(h, 7, va); exc = 1; }
+    else if (check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, va); exc = 1; }
     int had = h->lr_valid && h->lr_addr <= va && va + size <= h->lr_addr + h->lr_size;
     h->lr_valid = 0;                                                  /* cancelLr(SC) amo.cpp:403-405 */
     if (exc) return;
@@ -988,7 +1070,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
   switch (f5) { case 0: case 1: case 4: case 8: case 12: case 16: case 20: case 24: case 28: break; default: illegal(h, raw); return; }
   /* amo: execAmo32Op / execAmo64Op (amo.cpp:427-460): amoLoad then store<>() */
   if (ldst_translate_unsupported(h)) return;
-  if ((va & (size - 1)) || check_access(h, va, size, &tval)) { ldst_exception(h, 7, va); return; }
+  if ((va & (size - 1)) || check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, va); return; }   /* amoLoad validates with the store check only (amo.cpp:28-56) */
   u64 ld = ld_le(h->mem + (va - h->cfg.mem_base), size);
   if (size == 4) ld = (u64)(i64)(i32)ld;
   u64 b = h->x[rs2], r;
@@ -1167,7 +1249,7 @@ ill:
 static int fetch(rvo_hart* h, u64 pc, u32* inst, u64* tval)
 {
   if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return 2; }
-  if (!pmp_ok(h, h->priv)) { *tval = pc; return 1; }
+  if (!pmp_ok(h, h->priv, pc, 4)) { *tval = pc; return 1; }                       /* Hart.cpp:3079-3084 */
   if (!(pc & 3)) {
     if (!in_mem(h, pc, 4)) { *tval = pc; return 1; }
     u32 w = (u32)ld_le(h->mem + (pc - h->cfg.mem_base), 4);
@@ -1177,6 +1259,7 @@ static int fetch(rvo_hart* h, u64 pc, u32* inst, u64* tval)
   if (!in_mem(h, pc, 2)) { *tval = pc; return 1; }
   u32 lo = (u32)ld_le(h->mem + (pc - h->cfg.mem_base), 2);
   if ((lo & 3) != 3) { *inst = lo; return 0; }
+  if (!pmp_ok(h, h->priv, pc + 2, 4)) { *tval = pc + 2; return 1; }               /* Hart.cpp:3158-3162 */
   if (!in_mem(h, pc + 2, 2)) { *tval = pc + 2; return 1; }
   *inst = lo | ((u32)ld_le(h->mem + (pc + 2 - h->cfg.mem_base), 2) << 16);
   return 0;

@@ -105,6 +105,8 @@ uint64_t  rvo_state_hash(const rvo_hart* h);
 uint64_t  rvo_mem_hash(const rvo_hart* h);
 
 /* The hash primitives the device kernels must reproduce bit-for-bit. */
+/* PMP permission bits (r=1 w=2 x=4) of privilege pm at addr: test hook for pinning against the reference PmpManager */
+unsigned  rvo_pmp_perm(const rvo_hart* h, unsigned pm, uint64_t addr);
 uint64_t  rvo_fold(uint64_t h, uint64_t w);
 uint64_t  rvo_mix(uint64_t x);
 

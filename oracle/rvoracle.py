@@ -243,3 +243,11 @@ def format_commit(c, hart_ix=0, disasm=None) -> str:
         res = {CH_R: "r", CH_F: "f", CH_M: "m", CH_C: "c", CH_V: "v"}[kind]
         lines.append(f"#{c.tag} {hart_ix} {PRIV_STR[c.priv]:>2s} {c.pc:016x} {op:>8s} {res} {key:016x} {val:016x} {txt}")
     return "  +\n".join(lines)
+
+
+def pmp_perm(hart: "Hart", priv: int, addr: int) -> int:
+    """PMP permission bits (r=1 w=2 x=4) the oracle grants privilege `priv` at `addr`."""
+    L = lib()
+    L.rvo_pmp_perm.restype = C.c_uint
+    L.rvo_pmp_perm.argtypes = [C.c_void_p, C.c_uint, C.c_uint64]
+    return L.rvo_pmp_perm(hart.h, priv, addr)
