@@ -1354,6 +1354,8 @@ u64 rvo_state_hash(const rvo_hart* h)
     s = rvo_fold(s, v);
   }
   s = rvo_fold(s, h->time_);
+  for (int i = 0; i < 8; ++i) s = rvo_fold(s, h->pmpcfg[i]);
+  for (int i = 0; i < 64; ++i) s = rvo_fold(s, h->pmpaddr[i]);
   return s;
 }
 

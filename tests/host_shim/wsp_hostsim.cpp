@@ -117,6 +117,7 @@ u64 hs_state_hash(Sim* s)
   const int c2[] = { CI_MEDELEG, CI_MIDELEG, CI_MIE, CI_MTVEC, CI_MCOUNTEREN, CI_MENVCFG, CI_MCOUNTINHIBIT, CI_MSCRATCH, CI_MEPC, CI_MCAUSE, CI_MTVAL, CI_MIP };
   for (int c : c2) h = fold(h, L.m.cold_[c]);
   h = fold(h, L.h.cycle); h = fold(h, L.h.instret); h = fold(h, L.h.exec);
+  for (int i = 0; i < 72; ++i) h = fold(h, L.m.cold_[CI_PMPCFG0 + i]);
   return h;
 }
 u64 hs_mem_hash(Sim* s)

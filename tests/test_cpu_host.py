@@ -172,6 +172,82 @@ def test_hostsim_fuzz_interrupts():
     assert taken > 20
 
 
+def test_hostsim_pmp_programs():
+    """Row a7p: TOR/NA4/NAPOT entries, locks, MPRV, fetch / load / store / AMO access faults from U, S and M, the
+    4-byte fetch that straddles a region end, pmpcfg / pmpaddr rewrites -- device core (host build) == oracle, with
+    pre-decoded fetch and with decode from RAM."""
+    faults = stale = 0
+    for s in range(120):
+        p = WL.pmp_program(s)
+        _same(p)
+        if s < 30:
+            a, _, _ = S.run_hostsim(p, predecode=False)
+            b, _, log = S.run_oracle(p, log_cap=40000)
+            assert a == b
+            faults += sum(1 for c in log if c.trap == 1)
+            stale += b["status"] == 4 and b["value"] == 0x181
+    assert faults > 1000 and stale >= 1
+
+
+def test_pmp_semantics_directed():
+    """PmpManager.hpp:155-177 + Hart.cpp:3079/3158/1988: no entry -> U store faults (cause 7, tval = address); a NAPOT rw-
+    entry admits it; a locked r-- entry makes the same store fault in M mode; a misaligned access that runs into a
+    denied word reports the address of the second part."""
+    base = 0x80000000
+    a = Asm(base)
+    a.la(5, "h"); a.csrw(0x305, 5)
+    a.li(6, 0x80002000); a.li(7, 0x1234)
+    a.li(5, ((0x80002000 >> 2) | 7)); a.csrw(0x3B0, 5)          # entry 0: NAPOT 64 bytes at 0x80002000
+    a.li(5, 0x003FFFFFFFFFFFFF); a.csrw(0x3B1, 5)               # entry 1: background
+    a.li(5, (0x1F << 8) | 0x1B); a.csrw(0x3A0, 5)               # entry 0 NAPOT rw-, entry 1 NAPOT rwx
+    a.li(5, 3 << 11); a.csrc(0x300, 5); a.la(5, "u"); a.csrw(0x341, 5); a.mret()
+    a.label("u")
+    a.sd(7, 0, 6)                                               # allowed (rw-)
+    a.ld(8, 0, 6)
+    a.li(9, 0x80002000 + 62); a.sw(7, 0, 9)                     # bytes 62..65: second part (0x80002040) is background rwx: allowed
+    a.ecall()                                                   # -> M: lock entry 0 as r--
+    a.sd(7, 8, 6)                                               # U store now faults
+    a.ecall()                                                   # -> M tries the same store: faults too (locked)
+    a.li(9, 0x80002000 - 2); a.sw(7, 0, 9)                      # first part allowed (background), second part denied: tval = 0x80002000
+    a.li(17, 1); a.ecall()
+    a.align(4)
+    a.label("h")
+    a.csrr(28, 0x342); a.csrr(29, 0x343)
+    a.addi(30, 28, -8); a.bnez(30, "skip")
+    a.bnez(17, "exit")
+    a.addi(20, 20, 1); a.addi(30, 20, -1); a.bnez(30, "second")
+    a.li(5, 0x99); a.csrrw(0, 0x3A0, 5)                         # first ecall: entry 0 := L | NAPOT | r--  (entry 1 byte -> Off!)
+    a.li(5, (0x1F << 8) | 0x99); a.csrw(0x3A0, 5)               # locked byte stays, entry 1 back on
+    a.j("skip")
+    a.label("second")
+    a.csrr(24, 0x341); a.csrr(25, 0x300)
+    a.sd(7, 16, 6); a.csrr(22, 0x342); a.csrr(23, 0x343)                 # M store into the locked r-- region: nested trap
+    a.csrw(0x341, 24); a.csrw(0x300, 25)
+    a.label("skip")
+    a.csrr(30, 0x341); a.addi(30, 30, 4); a.csrw(0x341, 30); a.mret()
+    a.label("exit")
+    a.li(30, 0x80001000); a.li(31, 1); a.sd(31, 0, 30)
+    a.label("hang"); a.j("hang")
+    img = a.assemble()
+    h = rvoracle.Hart(isa="rv64imacsu_zicsr", mem_base=base, mem_size=1 << 16, tohost=0x80001000, reset_pc=base)
+    h.write_mem(base, img)
+    st, log = h.run(5000, log_cap=5000)
+    assert st == 1
+    traps = [(c.pc, [(key, val) for kind, key, val in c.changes() if kind == 5]) for c in log if c.trap == 1]
+    causes = [dict(t[1]) for t in traps]
+    seq = [(c[0x342], c[0x343]) for c in causes]
+    # ecall(8), U store fault, ecall(8), nested M store fault, U misaligned store fault at the second part, final ecall
+    assert seq[0][0] == 8
+    assert seq[1] == (7, 0x80002008)
+    assert seq[2][0] == 8
+    assert seq[3] == (7, 0x80002010)
+    assert seq[4] == (7, 0x80002000)
+    assert seq[5][0] == 8 and len(seq) == 6
+    assert (h.x(22), h.x(23)) == (7, 0x80002010)
+    assert h.x(8) == 0x1234 and h.read_mem(0x80002000 + 62, 4) == (0x1234).to_bytes(4, "little")
+    assert h.csr(0x3A0) == (0x1F << 8) | 0x99
+
+
 def test_hostsim_decode_from_ram_equals_predecoded():
     p = WL.fuzz_program(3, 300)
     a, _, _ = S.run_hostsim(p, predecode=True)

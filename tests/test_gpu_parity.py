@@ -4,6 +4,7 @@ digest for every hart."""
 import pytest
 
 import simutil as S
+from simutil import rvoracle
 import whisper_amd as W
 from whisper_amd import workloads as WL
 
@@ -131,6 +132,35 @@ def test_fuzz_programs_with_interrupts():
     b.close()
     assert left == 0
     _check(progs, res)
+
+
+def test_pmp_programs():
+    """Row a7p: PMP entries (TOR / NA4 / NAPOT, locked and not), MPRV, access faults on fetch / load / store / AMO from
+    U, S and M, pmpcfg / pmpaddr rewrites; includes harts that end on the stale-TOR-bound UNSUPPORTED stop."""
+    progs = [WL.pmp_program(s) for s in range(160)]
+    for lanes in (0, 16):         # one hart per wave, and 16 harts sharing a wave (divergent cold paths)
+        b, left, res = _run_batch(progs, lanes=lanes)
+        b.close()
+        assert left == 0
+        _check(progs, res)
+    assert any(r["status"] == W.ST_STOP_UNSUPPORTED and r["value"] == 0x181 for r in res)
+
+
+def test_pmp_csr_peek_poke():
+    """pmpcfg / pmpaddr through the C-ABI poke/peek: masks, per-byte legalisation and locks as CsRegs / PmpManager."""
+    p = WL.readme_program()
+    b = W.Batch(2, isa="rv64imacsu_zicsr", mem_base=p.mem_base, mem_size=p.mem_size)
+    try:
+        h = rvoracle.Hart(isa="rv64imacsu_zicsr")
+        ops = [(0x3B0, 0x20000400), (0x3B1, (1 << 64) - 1), (0x3A0, 0x0000_0000_0000_9A0F), (0x3B0, 0x1111), (0x3B1, 0x2222),
+               (0x3A0, 0x1F1F), (0x3A2, 0xFFFF_FFFF_FFFF_FFFF), (0x3EF, 0x55), (0x3BF, 0x77), (0x3AE, 0x0A0B)]
+        for num, v in ops:
+            b.poke(1, W.RES_CSR, num, v); h.set_csr(num, v)
+        for num in (0x3A0, 0x3A2, 0x3AE, 0x3B0, 0x3B1, 0x3BF, 0x3EF):
+            assert b.peek(1, W.RES_CSR, num) == h.csr(num), hex(num)
+            assert b.peek(0, W.RES_CSR, num) == 0
+    finally:
+        b.close()
 
 
 def test_instruction_limit_and_peek_poke():

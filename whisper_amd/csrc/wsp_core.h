@@ -31,7 +31,7 @@ enum { ST_RUNNING = 0, ST_STOP_TOHOST = 1, ST_STOP_ILLEGAL = 2, ST_STOP_LIMIT = 
 enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
 
 // Unsupported-reason codes reported in wsp_result.stop_value when status == ST_STOP_UNSUPPORTED
-enum { UNS_PAGING = 0x180, UNS_CSR_BASE = 0x10000, UNS_VECTOR = 0x20000 };
+enum { UNS_PAGING = 0x180, UNS_PMP_STALE = 0x181, UNS_CSR_BASE = 0x10000, UNS_VECTOR = 0x20000 };
 
 enum Op : u32 {
   OP_ILLEGAL = 0,
@@ -294,14 +294,18 @@ WSP_HD Rec decode(u32 inst, u32 isa) { return (inst & 3) == 3 ? decode32(inst, i
 enum ColdIx {
   CI_MEDELEG, CI_MIDELEG, CI_MIE, CI_MIP, CI_MTVEC, CI_MCOUNTEREN, CI_MENVCFG, CI_MCOUNTINHIBIT,
   CI_MSCRATCH, CI_MEPC, CI_MCAUSE, CI_MTVAL, CI_STVEC, CI_SCOUNTEREN, CI_SENVCFG, CI_SSCRATCH,
-  CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP, CI_COUNT
+  CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP,
+  CI_PMPCFG0,                        // pmpcfg0,2,..,14 (RV64: even numbered only, CsRegs.cpp:4777-4784)
+  CI_PMPADDR0 = CI_PMPCFG0 + 8,      // pmpaddr0..63
+  CI_COUNT = CI_PMPADDR0 + 64
 };
 
 // HF_HOT: the hart may use the pre-decoded fetch and the trap-free inline subset: M-mode, MPRV clear,
 // code not self-modified, no counter inhibited (so every hot step advances exec, cycle, instret and
 // retired by exactly one).  Recomputed by update_hot_flag() after anything that can change it.
 enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16,
-             HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */ };
+             HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */,
+             HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -318,6 +322,7 @@ enum {
   C_MSTATUS = 0x300, C_MISA = 0x301, C_MEDELEG = 0x302, C_MIDELEG = 0x303, C_MIE = 0x304, C_MTVEC = 0x305,
   C_MCOUNTEREN = 0x306, C_MENVCFG = 0x30A, C_MCOUNTINHIBIT = 0x320,
   C_MSCRATCH = 0x340, C_MEPC = 0x341, C_MCAUSE = 0x342, C_MTVAL = 0x343, C_MIP = 0x344,
+  C_PMPCFG0 = 0x3A0, C_PMPADDR0 = 0x3B0,
   C_MCYCLE = 0xB00, C_MINSTRET = 0xB02, C_CYCLE = 0xC00, C_TIME = 0xC01, C_INSTRET = 0xC02,
   C_MVENDORID = 0xF11, C_MARCHID = 0xF12, C_MIMPID = 0xF13, C_MHARTID = 0xF14, C_MCONFIGPTR = 0xF15
 };
@@ -489,15 +494,80 @@ template <class MEM> struct Lane {
 
   // ---- data access checks (determineLoad/StoreException, Hart.cpp:1988-2154, 13786-13935)
   WSP_HD u32 eff_priv() const { return ((h.mstatus & MST_MPRV) && h.priv == PRV_M) ? (u32)((h.mstatus >> MST_MPP_SH) & 3) : h.priv; }   // Hart.hpp:3444
-  // PMP with no programmed entry: M allowed, S/U denied (PmpManager.hpp:155-177)
-  WSP_HD bool check_access(u64 va, u32 size, u64& tval) const
+  // ---- PMP (PmpManager.hpp, Hart::updateMemoryProtection Hart.cpp:842-899), grain G = 0, no Smepmp
+  WSP_HD u32 pmp_cfg_byte(u32 ix) { return (u32)(m.cold(CI_PMPCFG0 + (ix >> 3)) >> (8 * (ix & 7))) & 0xff; }
+  // PmpManager::legalizePmpcfg (PmpManager.hpp:480-551): a locked byte keeps its value, the reserved w=1 r=0 keeps the old xwr
+  WSP_HD static u64 legalize_pmpcfg(u64 prev, u64 next)
   {
-    bool pmp_ok = eff_priv() == PRV_M;
+    u64 legal = 0;
+    for (u32 i = 0; i < 8; ++i) {
+      u32 pb = (u32)(prev >> (8 * i)) & 0xff, nb = (u32)(next >> (8 * i)) & 0xff;
+      if (pb >> 7) nb = pb;
+      else if ((nb & 3) == 2) nb = (pb & 7) | (nb & ~7u);
+      legal |= (u64)nb << (8 * i);
+    }
+    return legal;
+  }
+  // CsRegs::isPmpaddrLocked (CsRegs.cpp:6773-6793): own entry locked, or the next one is a locked TOR
+  WSP_HD bool pmpaddr_locked(u32 ix)
+  {
+    if (pmp_cfg_byte(ix) & 0x80) return true;
+    if (ix >= 63) return false;
+    u32 nb = pmp_cfg_byte(ix + 1);
+    return (nb & 0x80) && ((nb >> 3) & 3) == 1;
+  }
+  WSP_HD void update_pmp_flags()
+  {
+    u32 f = 0;
+    for (u32 k = 0; k < 8; ++k) {
+      u64 w = m.cold(CI_PMPCFG0 + k), on = (w | (w >> 1)) & 0x0808080808080808ULL;      // A != Off, per byte at bit 3
+      if (on) f |= HF_PMP_ON;
+      if ((on << 4) & w) f |= HF_PMP_MLOCK;                                               // ... and L (bit 7)
+    }
+    h.flags = (h.flags & ~(u32)(HF_PMP_ON | HF_PMP_MLOCK)) | f;
+  }
+  // PmpManager::getPmp / accessPmp (PmpManager.hpp:155-177) over regions unpacked as unpackMemoryProtection (:417-468) and
+  // word-aligned as defineRegion (:233-236): r=1 w=2 x=4.  First match in index order; M mode ignores entries that are not
+  // locked; no match: M everything, S/U nothing.
+  WSP_HD u32 pmp_perm(u32 pm, u64 addr)
+  {
+    const u32 dflt = pm == PRV_M ? 7u : 0u;
+    if (!(h.flags & HF_PMP_ON) || (pm == PRV_M && !(h.flags & HF_PMP_MLOCK))) return dflt;
+    for (u32 k = 0; k < 8; ++k) {
+      const u64 w = m.cold(CI_PMPCFG0 + k);
+      if (!(w & 0x1818181818181818ULL)) continue;
+      for (u32 j = 0; j < 8; ++j) {
+        const u32 cfg = (u32)(w >> (8 * j)) & 0xff, type = (cfg >> 3) & 3, ix = 8 * k + j;
+        if (!type) continue;
+        const u64 v = m.cold(CI_PMPADDR0 + ix);
+        u64 lo, hi;
+        if (type == 1) {                                      // TOR
+          lo = (ix ? m.cold(CI_PMPADDR0 + ix - 1) : 0) << 2;
+          hi = v << 2; if (hi > 0) hi -= 1;
+        } else {
+          u64 size_m1 = 3, napot = v;
+          if (type == 3) {                                    // NAPOT (pmpaddr is 54 bits: never all ones)
+            u32 rzi = 0; while (rzi < 64 && ((v >> rzi) & 1)) ++rzi;
+            napot = rzi >= 64 ? 0 : ((v >> rzi) << rzi);
+            size_m1 = rzi + 3 >= 64 ? ~0ULL : ((1ULL << (rzi + 3)) - 1);
+          }
+          lo = napot << 2; hi = lo + size_m1;
+        }
+        const u64 a0 = (lo >> 2) << 2, a1 = ((hi >> 2) << 2) + 3;
+        if (addr >= a0 && addr <= a1) return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u);
+      }
+    }
+    return dflt;
+  }
+  // need: 1 load / LR, 2 store / SC / AMO (validateAmoAddr checks write permission only, amo.cpp:28-56)
+  WSP_HD bool check_access(u64 va, u32 size, u32 need, u64& tval)
+  {
+    const u32 pm = eff_priv();
     u64 mask = size - 1;
-    if (!(va & mask)) { if (!pmp_ok || !in_mem(va, size)) { tval = va; return false; } return true; }
+    if (!(va & mask)) { if (!(pmp_perm(pm, va) & need) || !in_mem(va, size)) { tval = va; return false; } return true; }
     u64 va2 = (va + size - 1) & ~mask;
-    if (!pmp_ok || !in_mem(va, va2 - va)) { tval = va; return false; }
-    if (!in_mem(va2, size)) { tval = va2; return false; }
+    if (!(pmp_perm(pm, va) & need) || !in_mem(va, va2 - va)) { tval = va; return false; }
+    if (!(pmp_perm(pm, va2) & need) || !in_mem(va2, size)) { tval = va2; return false; }
     return true;
   }
   WSP_HD bool paging_unsupported()
@@ -529,7 +599,7 @@ template <class MEM> struct Lane {
   {
     u64 tval;
     if (paging_unsupported()) return false;
-    if (!check_access(va, size, tval)) { take_exception(5, cur_pc, tval, false); return false; }
+    if (!check_access(va, size, 1, tval)) { take_exception(5, cur_pc, tval, false); return false; }
     if (va == tohost) { out = 0; return true; }                           // Hart.cpp:2509-2513
     out = mem_read(va - mem_base, size);
     return true;
@@ -539,7 +609,7 @@ template <class MEM> struct Lane {
   {
     u64 tval;
     if (paging_unsupported()) return false;
-    if (!check_access(va, size, tval)) { take_exception(7, cur_pc, tval, false); return false; }
+    if (!check_access(va, size, 2, tval)) { take_exception(7, cur_pc, tval, false); return false; }
     u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
     s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
     mem_write(va - mem_base, size, sv);
@@ -568,7 +638,7 @@ template <class MEM> struct Lane {
       case C_CYCLE: case C_TIME: case C_INSTRET: return ext(ISA_ZICNTR) ? 1 : 0;
       default: break;
     }
-    if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : -1;
+    if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   // pmpcfg (even only on rv64), pmpaddr0..63
     if (num >= 0xB03 && num <= 0xB1F) return -1;
     if (num >= 0x323 && num <= 0x33F) return -1;
     if (num == 0x747 || (num >= 0x7B0 && num <= 0x7B3)) return -1;
@@ -603,7 +673,10 @@ template <class MEM> struct Lane {
       case C_MINSTRET: case C_INSTRET: return h.instret;
       case C_TIME: return h.exec;               // time_ ticks once per loop iteration (Hart.hpp:3101, 1 hart, downsample 0)
       case C_MHARTID: return hart_id;
-      default: return 0;
+      default:
+        if (num >= 0x3A0 && num <= 0x3AF) return m.cold(CI_PMPCFG0 + ((num - 0x3A0) >> 1));
+        if (num >= 0x3B0 && num <= 0x3EF) return m.cold(CI_PMPADDR0 + (num - 0x3B0));    // grain G = 0: read value = stored value
+        return 0;
     }
   }
   // value update of CsRegs::write (CsRegs.cpp:3908-4165) for the modelled subset
@@ -645,7 +718,15 @@ template <class MEM> struct Lane {
       case C_SATP: m.cold(CI_SATP) = v; break;
       case C_MCYCLE: h.cycle = v; break;
       case C_MINSTRET: h.instret = v; break;
-      default: break;
+      default:
+        if (num >= 0x3A0 && num <= 0x3AF) {                    // CsRegs.cpp:4777-4784 mask, legalised per byte
+          const u32 k = CI_PMPCFG0 + ((num - 0x3A0) >> 1);
+          m.cold(k) = legalize_pmpcfg(m.cold(k), v) & 0x9f9f9f9f9f9f9f9fULL;
+          update_pmp_flags();
+        } else if (num >= 0x3B0 && num <= 0x3EF) {
+          if (!pmpaddr_locked(num - 0x3B0)) m.cold(CI_PMPADDR0 + (num - 0x3B0)) = v & 0x003fffffffffffffULL;
+        }
+        break;
     }
   }
   WSP_HD bool csr_readable(u32 num)
@@ -682,6 +763,14 @@ template <class MEM> struct Lane {
       u32 mode = (u32)(next >> 60);
       if (mode != 0 && mode != 8 && mode != 9 && mode != 10) return;                      // unsupported MODE: write dropped (13284-13294)
       if (mode != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return; }
+    }
+    if (num >= 0x3B0 && num < 0x3EF && !pmpaddr_locked(num - 0x3B0)) {
+      // postCsrUpdate (Hart.cpp:4672-4679) refreshes the region table only when the written entry itself is on: a pmpaddr
+      // write under an Off entry whose successor is an active TOR entry leaves the reference with a stale lower bound.
+      // Not modelled: stop instead of diverging.
+      const u32 ix = num - 0x3B0;
+      if (((pmp_cfg_byte(ix) >> 3) & 3) == 0 && ((pmp_cfg_byte(ix + 1) >> 3) & 3) == 1 &&
+          (next & 0x003fffffffffffffULL) != m.cold(CI_PMPADDR0 + ix)) { stop(ST_STOP_UNSUPPORTED, UNS_PMP_STALE); return; }
     }
     csr_store(num, next);
     if (num == C_MSTATUS) s.chg |= CH_MSTATUS; else if (num == C_SSTATUS) s.chg |= CH_SSTATUS;
@@ -798,7 +887,7 @@ template <class MEM> struct Lane {
     u64 tval;
     if (paging_unsupported()) return;
     if (op == OP_LR) {                                                                     // amo.cpp:142-266
-      if ((va & (size - 1)) || !check_access(va, size, tval)) { take_exception(5, cur_pc, va, false); return; }
+      if ((va & (size - 1)) || !check_access(va, size, 1, tval)) { take_exception(5, cur_pc, va, false); return; }
       u64 v = mem_read(va - mem_base, size);
       if (size == 4) v = (u64)(i64)(i32)v;
       wx(rd, v);
@@ -806,7 +895,7 @@ template <class MEM> struct Lane {
       return;
     }
     if (op == OP_SC) {                                                                     // amo.cpp:273-420
-      bool exc = (va & (size - 1)) || !check_access(va, size, tval);
+      bool exc = (va & (size - 1)) || !check_access(va, size, 2, tval);
       bool had = (h.flags & HF_LR_VALID) && h.lr_addr <= va && va + size <= h.lr_addr + 8;
       h.flags &= ~HF_LR_VALID;                                                             // cancelLr(SC): amo.cpp:403-405
       if (exc) { take_exception(7, cur_pc, va, false); return; }
@@ -818,7 +907,7 @@ template <class MEM> struct Lane {
       wx(rd, 0);
       return;
     }
-    if ((va & (size - 1)) || !check_access(va, size, tval)) { take_exception(7, cur_pc, va, false); return; }   // amo.cpp:28-56
+    if ((va & (size - 1)) || !check_access(va, size, 2, tval)) { take_exception(7, cur_pc, va, false); return; }   // amo.cpp:28-56
     u64 ld = mem_read(va - mem_base, size), res;
     if (size == 4) ld = (u64)(i64)(i32)ld;
     switch ((u32)r.imm) {
@@ -840,7 +929,7 @@ template <class MEM> struct Lane {
   {
     // an interrupt that is pending and enabled (whatever its delegation / global enable) keeps the hart on the cold path,
     // which polls isInterruptPossible every step
-    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
+    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR | HF_PMP_MLOCK)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
                (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
     h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
     h.flags = (((h.mstatus >> MST_FS_SH) & 3) == 3) ? (h.flags | HF_FS_DIRTY) : (h.flags & ~(u32)HF_FS_DIRTY);
@@ -1048,7 +1137,7 @@ template <class MEM> struct Lane {
   WSP_HD int fetch_slow(u64 pc, Rec& r, u64& tval)
   {
     if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return 2; }
-    if (h.priv != PRV_M) { tval = pc; return 1; }       // PMP: no entry matches, S/U denied
+    if (!(pmp_perm(h.priv, pc) & 4)) { tval = pc; return 1; }                      // Hart.cpp:3079-3084
     u32 inst;
     if (!(pc & 3)) {
       if (!in_mem(pc, 4)) { tval = pc; return 1; }
@@ -1058,6 +1147,7 @@ template <class MEM> struct Lane {
       if (!in_mem(pc, 2)) { tval = pc; return 1; }
       inst = m.ld16(pc - mem_base);
       if ((inst & 3) == 3) {
+        if (!(pmp_perm(h.priv, pc + 2) & 4)) { tval = pc + 2; return 1; }            // Hart.cpp:3158-3162
         if (!in_mem(pc + 2, 2)) { tval = pc + 2; return 1; }
         inst |= (u32)m.ld16(pc + 2 - mem_base) << 16;
       }
@@ -1110,14 +1200,14 @@ template <class MEM> struct Lane {
   }
   // a complete cold step.  `recs` (may be null) is the hart's pre-decoded program image: an M-mode hart whose code is
   // not dirty takes the record from it instead of decoding from RAM (same result: the image is decode() of the same
-  // bytes, and M-mode fetch inside the arena cannot fault).
+  // bytes, and M-mode fetch inside the arena cannot fault while no locked PMP entry is on).
   template <bool TRACE> WSP_HD void cold_step(const Rec* recs)
   {
     u64 cur_pc, a = 0, b = 0; u32 priv0; Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
     cold_begin(cur_pc, priv0);
     if (poll_interrupt<TRACE>(cur_pc, priv0)) { update_hot_flag(); return; }
     bool have = false;
-    if (recs && h.priv == PRV_M && !(h.flags & HF_CODE_DIRTY) && hot_fetch(recs, rec)) {
+    if (recs && h.priv == PRV_M && !(h.flags & (HF_CODE_DIRTY | HF_PMP_MLOCK)) && hot_fetch(recs, rec)) {
       h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
       a = m.rx(rec_rs1(rec));
       b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));

@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   L.h.pc = d.hot64[H64_PC * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.thash = d.hot64[H64_THASH * S + slot];
   L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.fcsr = d.hot32[H32_FCSR * S + slot];
-  L.update_hot_flag();                                   // host pokes may have changed priv / mstatus / mip / mie / flags
+  L.update_pmp_flags();                                  // host pokes may have changed priv / mstatus / mip / mie / pmpcfg / flags
+  L.update_hot_flag();
   u64 stop_at;
   {
     const u64 max_exec = d.max_exec[slot], exec0 = L.h.exec;
@@ -723,6 +724,7 @@ __global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* o
   s = fold(s, d.hot64[H64_CYCLE * S + slot]);
   s = fold(s, d.hot64[H64_INSTRET * S + slot]);
   s = fold(s, d.hot64[H64_EXEC * S + slot]);          // time CSR == loop iterations (Hart.hpp:3101)
+  for (u32 i = 0; i < 72; ++i) s = fold(s, d.cold[(size_t)(CI_PMPCFG0 + i) * S + slot]);   // pmpcfg0,2,..14 then pmpaddr0..63
   wsp_result r;
   r.status = d.hot32[H32_STATUS * S + slot]; r.priv = d.hot32[H32_PRIV * S + slot];
   r.stop_value = d.hot64[H64_STOP_VALUE * S + slot]; r.pc = d.hot64[H64_PC * S + slot];
@@ -1116,7 +1118,10 @@ static int csr_loc(u32 num, u32* ix)
     case C_STVEC: *ix = CI_STVEC; return 2; case C_SCOUNTEREN: *ix = CI_SCOUNTEREN; return 2; case C_SENVCFG: *ix = CI_SENVCFG; return 2;
     case C_SSCRATCH: *ix = CI_SSCRATCH; return 2; case C_SEPC: *ix = CI_SEPC; return 2; case C_SCAUSE: *ix = CI_SCAUSE; return 2;
     case C_STVAL: *ix = CI_STVAL; return 2; case C_SATP: *ix = CI_SATP; return 2;
-    default: return -1;
+    default:
+      if (num >= 0x3A0 && num <= 0x3AF && !(num & 1)) { *ix = CI_PMPCFG0 + ((num - 0x3A0) >> 1); return 2; }
+      if (num >= 0x3B0 && num <= 0x3EF) { *ix = CI_PMPADDR0 + (num - 0x3B0); return 2; }
+      return -1;
   }
 }
 
@@ -1173,6 +1178,16 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
       if (loc == 0) HIPOK(hipMemcpy(d.hot64 + ix * S + s, &v, 8, hipMemcpyHostToDevice));
       else if (loc == 1) { u32 f = (u32)v & 0xff; HIPOK(hipMemcpy(d.hot32 + ix * S + s, &f, 4, hipMemcpyHostToDevice)); }
       else if (loc == 2) {
+        if (ix >= CI_PMPCFG0) {   // pmpcfg / pmpaddr pokes are legalised and honour locks like CSR writes (PmpManager.hpp:480-551, CsRegs.cpp:6773)
+          u64 cfg[8]; for (u32 k = 0; k < 8; ++k) HIPOK(hipMemcpy(&cfg[k], d.cold + (size_t)(CI_PMPCFG0 + k) * S + s, 8, hipMemcpyDeviceToHost));
+          auto cb = [&](u32 e) { return (u32)(cfg[e >> 3] >> (8 * (e & 7))) & 0xff; };
+          if (ix < CI_PMPADDR0) v = Lane<DevMem>::legalize_pmpcfg(cfg[ix - CI_PMPCFG0], v) & 0x9f9f9f9f9f9f9f9fULL;
+          else {
+            const u32 e = ix - CI_PMPADDR0;
+            if ((cb(e) & 0x80) || (e < 63 && (cb(e + 1) & 0x80) && ((cb(e + 1) >> 3) & 3) == 1)) break;
+            v &= 0x003fffffffffffffULL;
+          }
+        }
         HIPOK(hipMemcpy(d.cold + ix * S + s, &v, 8, hipMemcpyHostToDevice));
         if (n == C_MCOUNTINHIBIT) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + H32_FLAGS * S + s, 4, hipMemcpyDeviceToHost)); f = (f & ~(HF_INH_CY | HF_INH_IR)) | ((v & 1) ? (u32)HF_INH_CY : 0) | ((v & 4) ? (u32)HF_INH_IR : 0); HIPOK(hipMemcpy(d.hot32 + H32_FLAGS * S + s, &f, 4, hipMemcpyHostToDevice)); }
       } else return fail(WSP_EUNSUPPORTED, "CSR not modelled");

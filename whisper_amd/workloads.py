@@ -588,3 +588,206 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     isa = ("rv64imafdc" if fp else "rv64imac") + ("su_zicsr" if interrupts else "_zicsr")
     return _finish(a, f"fuzz-{seed}", isa, d, mem_size=1 << 16, max_inst=20000, meta=dict(seed=seed))
+
+
+# ------------------------------------------------------------------------------------------ PMP
+def _napot(base: int, size: int) -> int:
+    """pmpaddr value of the naturally aligned power-of-two region [base, base + size), size >= 8."""
+    return ((base >> 2) | (size // 8 - 1)) & 0x003FFFFFFFFFFFFF
+
+
+def pmp_program(seed: int, n: int = 300) -> Program:
+    """Physical memory protection: M mode programs TOR / NA4 / NAPOT entries (some locked) over a data arena, a small
+    code island and a background entry, drops to U (even seeds) or S (odd seeds) and runs a random mix of loads, stores,
+    AMOs, LR/SC and FP accesses at region edges (aligned and not), jumps into executable and non-executable islands and
+    a 4-byte instruction that straddles the end of an executable region.  `ecall` with a7 != 0 asks M mode to access
+    memory itself (locked entries apply), under MPRV (U/S permissions apply), or to rewrite pmpcfg2 / pmpaddr9 (which may
+    hit the reference's stale-TOR-bound quirk: an UNSUPPORTED stop on every implementation).  Every trap goes to one M
+    handler that skips the faulting instruction (fetch faults: resumes at ra).  a7 == 0 exits through tohost."""
+    rng = random.Random(0x706D70 ^ seed)
+    data_base = BASE + 0x4000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.org(data_base + 0x100)
+    d.label("arena")
+    d.data(bytes(rng.getrandbits(8) for _ in range(0x700)))
+    d.org(data_base + 0x1000)
+    isl = Asm(data_base + 0x1000)
+    ISL = data_base + 0x1000
+    # island 1 at ISL: executable [ISL, ISL+8); the 4-byte instruction at ISL+6 crosses into non-executable memory
+    isl.c_nop(); isl.addi(6, 6, 1); isl.addi(6, 6, 2); isl.c_nop(); isl.ret()
+    isl.org(ISL + 0x40)
+    isl.addi(6, 6, 3); isl.ret()                    # island 2 at ISL+0x40: fully executable (16 bytes NAPOT)
+    isl.org(ISL + 0x80)
+    isl.addi(6, 6, 4); isl.ret()                    # island 3 at ISL+0x80: executable only if the background entry says so
+    d.data(isl.assemble())
+    S = d.symbols
+    ARENA = S["arena"]
+    perms = [0, 1, 3, 4, 5, 7]
+    cfg = [0] * 64
+    addr = [0] * 64
+    edges = []
+
+    def region(ix, kind, lo, size, p, lock=False):
+        c = p | (0x80 if lock else 0)
+        if kind == "tor":
+            addr[ix - 1] = lo >> 2; addr[ix] = (lo + size) >> 2; cfg[ix] = c | (1 << 3)
+        elif kind == "na4":
+            addr[ix] = lo >> 2; cfg[ix] = c | (2 << 3); size = 4
+        else:
+            addr[ix] = _napot(lo, size); cfg[ix] = c | (3 << 3)
+        edges.extend([lo, lo + size])
+
+    region(0, "napot", BASE, 0x4000, 5)                                  # program text: r-x
+    region(1, "napot", S["tohost"], 16, 0)                               # tohost / fromhost: nothing below M
+    edges.clear()                                                        # (M-mode service stores stay away from text and tohost)
+    ix = 2
+    while ix < 16:                                                       # entries 2..7 over arena A, 8..15 over arena B
+        lo_area = ARENA + (0x000 if ix < 8 else 0x400)
+        kind = rng.choice(["tor", "na4", "napot", "napot", "off"])
+        lock = rng.random() < 0.2
+        p = rng.choice(perms)
+        if kind == "tor" and ix + 1 < (8 if ix < 8 else 16):
+            lo = lo_area + 4 * rng.randrange(0, 0x80); region(ix + 1, "tor", lo, 4 * rng.randrange(1, 0x40), p, lock); ix += 2
+        elif kind == "na4":
+            region(ix, "na4", lo_area + 4 * rng.randrange(0, 0xF0), 4, p, lock); ix += 1
+        elif kind == "napot":
+            size = rng.choice([8, 16, 32, 64, 128, 256]); region(ix, "napot", lo_area + size * rng.randrange(0, 0x300 // size), size, p, lock); ix += 1
+        else:
+            addr[ix] = (lo_area + 4 * rng.randrange(0, 0xF0)) >> 2; ix += 1
+    region(17, "tor", ISL, 8, 5)                                         # island 1
+    region(18, "napot", ISL + 0x40, 16, rng.choice([5, 4, 7]))           # island 2
+    region(40, "na4", ARENA + 0x3F0, 4, rng.choice(perms), rng.random() < 0.3)
+    region(63, "napot", 0, 1 << 57, rng.choice([3, 3, 7, 1, 0]))         # background
+    edges = sorted(set(edges) - {0, 1 << 57})
+
+    N1, H0, H3, H1, H2 = 27, 28, 29, 30, 31     # reserved for the handler
+    MPRV = 1 << 17
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    # a fault of M mode itself (locked entries, MPRV) can only come from a load / store of this handler, all 4 bytes long:
+    # step over it with registers of its own so that the interrupted path carries on
+    a.csrr(N1, CSR["mstatus"]); a.srli(N1, N1, 11); a.andi(N1, N1, 3); a.addi(N1, N1, -3); a.bnez(N1, "from_below")
+    a.csrr(N1, CSR["mepc"]); a.addi(N1, N1, 4); a.csrw(CSR["mepc"], N1); a.mret()
+    a.label("from_below")
+    a.csrr(H1, CSR["mcause"])
+    a.addi(H2, H1, -1); a.beqz(H2, "fetch_fault")
+    a.addi(H2, H1, -8); a.sltiu(H2, H2, 4); a.bnez(H2, "is_ecall")
+    a.label("skip")
+    a.csrr(H1, CSR["mepc"]); a.lhu(H2, 0, H1); a.andi(H2, H2, 3); a.addi(H2, H2, -3)
+    a.bnez(H2, "h2"); a.addi(H1, H1, 2)
+    a.label("h2"); a.addi(H1, H1, 2); a.csrw(CSR["mepc"], H1); a.mret()
+    a.label("fetch_fault")
+    a.csrr(H1, CSR["mepc"]); a.beq(H1, 1, "exit")                        # ra itself is not executable (clobbered by arena code): give up
+    a.csrw(CSR["mepc"], 1); a.mret()
+    a.label("is_ecall")
+    a.beqz(17, "exit")
+    a.csrr(H0, CSR["mepc"]); a.csrr(H3, CSR["mstatus"])                  # the service may fault and nest
+    for k, lbl in ((1, "svc_store"), (2, "svc_mprv"), (3, "svc_load"), (4, "svc_cfg"), (5, "svc_addr")):
+        a.li(H2, k); a.beq(17, H2, lbl)
+    a.j("svc_done")
+    a.label("svc_load"); a.ld(H2, 0, 10); a.lbu(H2, 3, 10); a.j("svc_done")
+    a.label("svc_store"); a.sd(11, 0, 10); a.sb(11, 5, 10); a.amoadd_w(H2, 11, 10); a.j("svc_done")
+    a.label("svc_mprv")
+    a.li(H2, MPRV); a.csrs(CSR["mstatus"], H2); a.lw(H2, 0, 10); a.sw(11, 4, 10)
+    a.li(H2, MPRV); a.csrc(CSR["mstatus"], H2); a.j("svc_done")
+    a.label("svc_cfg"); a.csrrw(H2, 0x3A2, 11); a.j("svc_done")
+    a.label("svc_addr"); a.csrrw(H2, 0x3B9, 11)
+    a.label("svc_done")
+    a.csrw(CSR["mstatus"], H3); a.addi(H0, H0, 4); a.csrw(CSR["mepc"], H0); a.mret()
+    a.label("exit")
+    _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
+
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    a.li(5, 0x2000); a.csrs(CSR["mstatus"], 5)                           # FS on
+    for i in range(64):
+        if addr[i]:
+            a.li(5, addr[i]); a.csrw(0x3B0 + i, 5)
+    for k in range(8):
+        v = 0
+        for j in range(8):
+            v |= cfg[8 * k + j] << (8 * j)
+        if v:
+            a.li(5, v); a.csrw(0x3A0 + 2 * k, 5)
+    for k in (0, 2, 4, 10, 14):                                          # read everything back into the trace
+        a.csrr(5, 0x3A0 + k)
+    for i in (0, 1, 2, 9, 17, 63):
+        a.csrr(5, 0x3B0 + i)
+    a.li(5, 0x3A2); a.csrrw(6, 0x3A1, 5)                                 # odd pmpcfg: not implemented on RV64 (illegal)
+    for r in range(1, 28):
+        a.li(r, rng.choice([rng.getrandbits(64), rng.getrandbits(12), ARENA + 8 * rng.randrange(0xE0), 0]))
+    a.li(5, 3 << 11); a.csrc(CSR["mstatus"], 5)
+    if seed & 1:
+        a.li(5, 1 << 11); a.csrs(CSR["mstatus"], 5)                      # MPP = S
+    a.la(5, "user"); a.csrw(CSR["mepc"], 5); a.mret()
+    a.align(4)
+    a.label("user")
+
+    def pick_addr(m_mode=False):
+        r = rng.random()
+        if r < 0.65 and edges:
+            return rng.choice(edges) + rng.randrange(-9, 9)
+        if r < 0.9 or m_mode:
+            return ARENA + rng.randrange(0, 0x700)
+        return rng.choice([S["tohost"], S["tohost"] + 8, S["tohost"] + 13, BASE + 0x100, BASE + 0x3FFC, BASE - 8, BASE + 0x10000 - 4, ISL + 0x104, 0x1000])
+
+    P = 9            # address register
+    amo = ["amoswap", "amoadd", "amoxor", "amoand", "amoor", "amomin", "amomax", "amominu", "amomaxu"]
+    regs = [r for r in range(2, 27) if r not in (P, 10, 11, 17)]
+    for i in range(n):
+        k = rng.random()
+        rd = rng.choice(regs); rs2 = rng.choice(regs)
+        if k < 0.45:
+            m, sz = rng.choice(_LD + _ST)
+            t = pick_addr()
+            if rng.random() < 0.6:
+                t -= t % sz
+            off = rng.randrange(-64, 64)
+            a.li(P, (t - off) & MASK64)
+            getattr(a, m)(rd if m.startswith("l") else rs2, off, P)
+        elif k < 0.57:
+            sfx = rng.choice(["w", "d"]); t = pick_addr()
+            if rng.random() < 0.85:
+                t -= t % (4 if sfx == "w" else 8)
+            a.li(P, t & MASK64)
+            r = rng.random()
+            if r < 0.25:
+                getattr(a, f"lr_{sfx}")(rd, P)
+            elif r < 0.5:
+                getattr(a, f"lr_{sfx}")(rd, P); getattr(a, f"sc_{sfx}")(rd, rs2, P)
+            else:
+                getattr(a, f"{rng.choice(amo)}_{sfx}")(rd, rs2, P)
+        elif k < 0.65:
+            t = pick_addr(); t -= t % rng.choice([1, 4, 8])
+            a.li(P, t & MASK64)
+            rng.choice([a.flw, a.fld, a.fsw, a.fsd])(rng.randrange(32), 0, P)
+        elif k < 0.75:
+            t = rng.choice([ISL, ISL, ISL + 0x40, ISL + 0x80, ISL + 2, ISL + 8, ARENA + 4 * rng.randrange(0x100), BASE + 0x20000])
+            a.li(P, t); a.jalr(1, P, 0)
+        elif k < 0.88:
+            svc = rng.choice([1, 1, 2, 2, 3, 3, 4, 5])
+            a.li(17, svc)
+            if svc == 4:
+                v = 0
+                for j in range(8):
+                    v |= (rng.choice(perms) | (rng.choice([0, 1, 2, 3]) << 3) | (0x80 if rng.random() < 0.1 else 0)) << (8 * j)
+                a.li(11, v)
+            elif svc == 5:
+                a.li(11, (ARENA + 0x400 + 4 * rng.randrange(0xF0)) >> 2)
+            else:
+                t = pick_addr(True); t -= t % rng.choice([1, 8]); a.li(10, t & MASK64); a.li(11, rng.getrandbits(64))
+            a.ecall()
+        elif k < 0.92:
+            rng.choice([lambda: a.csrr(rd, 0x3A0), lambda: a.csrw(0x3B3, rs2), lambda: a.csrr(rd, CSR["mstatus"]),
+                        lambda: a.csrr(rd, CSR["sstatus"]), a.ebreak, a.wfi, a.fence_i])()
+        else:
+            getattr(a, rng.choice(_RR))(rd, rng.choice(regs), rs2)
+    a.li(17, 0); a.ecall()
+    a.label("hang"); a.j("hang")
+    assert a.here() < BASE + 0x4000, "text outgrew its PMP region"
+    return _finish(a, f"pmp-{seed}", "rv64imafdcsu_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed))
