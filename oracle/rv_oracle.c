@@ -136,6 +136,7 @@ struct rvo_hart {
   int lr_valid; u64 lr_addr; unsigned lr_size;
   u64 pmpcfg[8];            /* pmpcfg0,2,..,14 (RV64: even numbered only, CsRegs.cpp:4777-4784) */
   u64 pmpaddr[64];
+  int pmp_on;               /* some entry is not Off (cache over pmpcfg, kept by csr_store) */
   /* per-instruction trace capture */
   int has_exc;
   int ch_ireg; int ch_freg;
@@ -341,6 +342,7 @@ static int pmp_region(const rvo_hart* h, unsigned ix, u64* a0, u64* a1)
  * order; M mode ignores entries that are not locked; no match: M everything, S/U nothing. */
 unsigned rvo_pmp_perm(const rvo_hart* h, unsigned pm, u64 addr)
 {
+  if (!h->pmp_on) return pm == PRV_M ? 7 : 0;
   for (unsigned ix = 0; ix < 64; ++ix) {
     u64 a0, a1;
     if (!pmp_region(h, ix, &a0, &a1)) continue;
@@ -405,7 +407,8 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
     case C_MCYCLE: h->cycle = v; break;
     case C_MINSTRET: h->instret = v; break;
     default:
-      if (num >= 0x3A0 && num <= 0x3AF) { unsigned k = (num - 0x3A0) >> 1; h->pmpcfg[k] = legalize_pmpcfg(h->pmpcfg[k], v) & 0x9f9f9f9f9f9f9f9fULL; }
+      if (num >= 0x3A0 && num <= 0x3AF) { unsigned k = (num - 0x3A0) >> 1; h->pmpcfg[k] = legalize_pmpcfg(h->pmpcfg[k], v) & 0x9f9f9f9f9f9f9f9fULL;
+        h->pmp_on = 0; for (unsigned i = 0; i < 8; ++i) if (h->pmpcfg[i] & 0x1818181818181818ULL) h->pmp_on = 1; }
       else if (num >= 0x3B0 && num <= 0x3EF) { if (!pmpaddr_locked(h, num - 0x3B0)) h->pmpaddr[num - 0x3B0] = v & 0x003fffffffffffffULL; }
       break;
   }
