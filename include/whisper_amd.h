@@ -50,7 +50,7 @@ typedef struct {
   uint32_t lanes_per_wave;  /* 0 = auto; else a power of two <= 64: harts per 64-lane wavefront           */
   int32_t  device;          /* HIP device ordinal, -1 = current                                            */
   uint32_t hart_id_base;    /* mhartid of hart 0 (core_hart_id_offset)                                     */
-  uint32_t reserved;
+  uint32_t tlb_entries;     /* TLB entries per hart, a power of two; 0 = 2048 (Hart.cpp:106; config tag tlb_entries) */
 } wsp_batch_desc;
 
 typedef struct {

@@ -160,3 +160,67 @@ unsigned ref_pmp_perm(void* p, unsigned priv, uint64_t addr)
 }
 uint64_t ref_pmp_legalize_cfg(uint64_t prev, uint64_t next) { PmpManager m; return m.legalizePmpcfg<uint64_t>(prev, next); }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The reference's VirtMem + Tlb (virtual_memory/VirtMem.cpp, Tlb.cpp) standing alone over a flat RAM buffer, configured the
+// way Hart does it (Hart.cpp:326-468 callbacks, 904-919 satp, 1167-1174 SUM/MXR, 12135-12173 sfence.vma).  Hart reaches the
+// TLB and the setters as a friend; this test TU opens them the blunt way, for itself only.
+#define private public
+#define protected public
+#include "virtual_memory/VirtMem.hpp"
+#undef private
+#undef protected
+
+namespace {
+struct VmBox {
+  VirtMem vm;
+  uint8_t* mem; uint64_t base, size;
+  VmBox(unsigned tlbSize, uint8_t* m, uint64_t b, uint64_t s) : vm(0, 4096, tlbSize), mem(m), base(b), size(s)
+  {
+    auto inside = [this](uint64_t a, unsigned n) { return a >= base && a - base <= size - n; };
+    vm.setMemReadCallback([this, inside](uint64_t a, bool, unsigned n, uint64_t& d) { if (!inside(a, n)) return false; d = 0; memcpy(&d, mem + (a - base), n); return true; });
+    vm.setMemWriteCallback([this, inside](uint64_t a, bool, unsigned n, uint64_t d) { if (!inside(a, n)) return false; memcpy(mem + (a - base), &d, n); return true; });
+    vm.setIsReadableCallback([](uint64_t) { return true; });
+    vm.setIsWritableCallback([](uint64_t) { return true; });
+    vm.setFaultOnFirstAccess(true);      // no Svadu (Hart.hpp:539-549)
+  }
+};
+}
+
+extern "C" {
+void* ref_vm_new(unsigned tlbSize, uint8_t* mem, uint64_t base, uint64_t size) { return new VmBox(tlbSize, mem, base, size); }
+void ref_vm_free(void* p) { delete static_cast<VmBox*>(p); }
+void ref_vm_config(void* p, uint64_t satp, int sum, int mxr)
+{
+  auto& vm = static_cast<VmBox*>(p)->vm;
+  vm.configTranslation(VirtMem::Mode(satp >> 60), uint32_t((satp >> 44) & 0xffff), satp & 0xfffffffffffULL);
+  vm.setSum(sum); vm.setExecReadable(mxr);
+}
+// acc: 1 read, 2 write, 4 exec.  Returns the ExceptionCause number (0 = none).
+unsigned ref_vm_translate(void* p, uint64_t va, unsigned priv, unsigned acc, uint64_t* pa)
+{
+  auto& vm = static_cast<VmBox*>(p)->vm;
+  uint64_t gpa = va;
+  auto c = vm.translate(va, PrivilegeMode(priv), false, acc == 1, acc == 2, acc == 4, gpa, *pa);
+  return c == ExceptionCause::NONE ? 0 : unsigned(c);
+}
+unsigned ref_vm_translate_noupdate(void* p, uint64_t va, unsigned priv, unsigned acc, uint64_t* pa)
+{
+  auto& vm = static_cast<VmBox*>(p)->vm;
+  auto c = vm.transAddrNoUpdate(va, PrivilegeMode(priv), false, acc == 1, acc == 2, acc == 4, *pa);
+  return c == ExceptionCause::NONE ? 0 : unsigned(c);
+}
+// Hart installs a Memory write observer that drops cached PTEs overlapped by a store (Memory.hpp:148,395-398)
+void ref_vm_ram_written(void* p, uint64_t addr, unsigned size) { static_cast<VmBox*>(p)->vm.invalidatePteCache(addr, size); }
+void ref_vm_sfence(void* p, int hasAddr, uint64_t addr, int hasAsid, uint64_t asid)
+{
+  auto& vm = static_cast<VmBox*>(p)->vm;
+  auto& tlb = vm.tlb_;
+  uint64_t vpn = vm.pageNumber(addr);
+  if (!hasAddr && !hasAsid) tlb.invalidate();
+  else if (!hasAddr) tlb.invalidateAsid(uint32_t(asid), 0);
+  else if (!hasAsid) tlb.invalidateVirtualPage(vpn, 0);
+  else tlb.invalidateVirtualPageAsid(vpn, uint32_t(asid), 0);
+  vm.flushPteCache();
+}
+}

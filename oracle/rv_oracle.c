@@ -115,6 +115,9 @@ enum {
 #define SSTATUS_WMASK 0x000DE722ULL
 #define SSTATUS_RMASK 0x80000003000DE762ULL
 
+/* TlbEntry (Tlb.hpp:28-46) without the STEE world id and VMID */
+struct rvo_tlbe { u64 vpn, ppn; u32 asid; uint8_t counter, valid, global, user, read, write, exec, accessed, dirty, level; };
+
 struct rvo_hart {
   rvo_config cfg;
   uint8_t* mem;
@@ -137,6 +140,8 @@ struct rvo_hart {
   u64 pmpcfg[8];            /* pmpcfg0,2,..,14 (RV64: even numbered only, CsRegs.cpp:4777-4784) */
   u64 pmpaddr[64];
   int pmp_on;               /* some entry is not Off (cache over pmpcfg, kept by csr_store) */
+  /* TLB (Tlb.hpp:28-46), direct mapped, tlb_n entries (Hart.cpp:106: 2048 by default) */
+  struct rvo_tlbe* tlb; unsigned tlb_n;
   /* per-instruction trace capture */
   int has_exc;
   int ch_ireg; int ch_freg;
@@ -157,10 +162,13 @@ rvo_hart* rvo_create(const rvo_config* cfg)
   /* reset mstatus: MPP=M, SXL=UXL=2 (CsRegs.cpp:4705-4710); FS/VS Off */
   h->mstatus = (3ULL << MST_MPP_SH) | (0xAULL << 32);
   h->pc = cfg->reset_pc;
+  h->tlb_n = cfg->tlb_entries ? cfg->tlb_entries : 2048;
+  if (h->tlb_n & (h->tlb_n - 1)) { free(h->mem); free(h); return NULL; }   /* Tlb.cpp:11 */
+  h->tlb = (struct rvo_tlbe*)calloc(h->tlb_n, sizeof(struct rvo_tlbe));
   return h;
 }
 
-void rvo_destroy(rvo_hart* h) { if (h) { free(h->mem); free(h); } }
+void rvo_destroy(rvo_hart* h) { if (h) { free(h->mem); free(h->tlb); free(h); } }
 
 static inline int in_mem(const rvo_hart* h, u64 a, u64 n)
 { return a >= h->cfg.mem_base && a - h->cfg.mem_base <= h->cfg.mem_size - n && n <= h->cfg.mem_size; }
@@ -403,7 +411,9 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
     case C_SCAUSE: h->scause = v; break;
     case C_MTVAL: h->mtval = v; break;
     case C_STVAL: h->stval = v; break;
-    case C_SATP: h->satp = v; break;
+    case C_SATP: {                                                              /* Hart::updateAddressTranslation (Hart.cpp:904-919) -> VirtMem::configTranslation -> Tlb::setMode (Tlb.hpp:378-383) */
+      if ((h->satp >> 60) != (v >> 60)) for (unsigned i = 0; i < h->tlb_n; ++i) { h->tlb[i].valid = 0; h->tlb[i].counter = 0; }
+      h->satp = v; break; }
     case C_MCYCLE: h->cycle = v; break;
     case C_MINSTRET: h->instret = v; break;
     default:
@@ -573,38 +583,228 @@ static unsigned eff_ldst_priv(const rvo_hart* h)
   return h->priv;
 }
 
-/* determineLoadException / determineStoreException (Hart.cpp:1988-2154, 13786-13935), bare
- * translation only. Returns 0 if OK, else sets *tval and returns 1. */
-static int check_access(const rvo_hart* h, u64 va, unsigned size, unsigned need /* 1 load, 2 store/amo */, u64* tval)
+/* ------------------------------------------------------------------ Sv39 + TLB (virtual_memory/VirtMem.cpp, Tlb.hpp, Tlb.cpp)
+ * Single-stage Sv39 as the reference runs it by default: no Svadu (faultOnFirstAccess_ = true, VirtMem.hpp:1159),
+ * no Svpbmt, no Svnapot, no shadow stack.  The 8192-entry PTE cache (VirtMem.hpp:769-832) is coherent with stores
+ * and flushed on sfence/satp/PMP changes, so it is not modelled.  Sv48/Sv57 stop the hart as unsupported. */
+static inline int paging_on(const rvo_hart* h, unsigned pm) { return ext(h, RVO_ISA_S) && pm != PRV_M && (h->satp >> 60) == 8; }
+static inline unsigned pf_cause(unsigned acc) { return acc == 4 ? 12 : acc == 1 ? 13 : 15; }   /* stage1PageFaultType (VirtMem.cpp:31-40) */
+static inline unsigned af_cause(unsigned acc) { return acc == 4 ? 1 : acc == 1 ? 5 : 7; }      /* accessFaultType (VirtMem.cpp:57-66) */
+
+/* VirtMem::pageTableWalk<Pte39, Va39> (VirtMem.cpp:694-892) behind translateNoTlb's canonical-address check (:393-397).
+ * ad_check = accessDirtyCheck_.  Fills *e on success. */
+static unsigned page_walk(rvo_hart* h, u64 va, unsigned pm, unsigned acc, int ad_check, u64* pa, struct rvo_tlbe* e)
 {
-  unsigned pm = eff_ldst_priv(h);
-  u64 mask = size - 1;
-  if (!(va & mask)) {
-    if (!pmp_ok(h, pm, va, need) || !in_mem(h, va, size)) { *tval = va; return 1; }
-    return 0;
+  const unsigned pf = pf_cause(acc);
+  if ((u64)(((i64)va << 25) >> 25) != va) return pf;
+  const int sum = (h->mstatus & MST_SUM) != 0, mxr = (h->mstatus & MST_MXR) != 0;
+  u64 root = (h->satp & 0xfffffffffffULL) << 12, pte;
+  int ii = 2, global = 0;
+  for (;;) {
+    u64 pte_addr = root + ((va >> (12 + 9 * ii)) & 0x1ff) * 8;
+    /* isAddrReadable: PMP as Supervisor (Hart.cpp:424-441), then memRead: PMA read (Hart.cpp:337-339) */
+    if (!pmp_ok(h, PRV_S, pte_addr, 1) || !in_mem(h, pte_addr, 8)) return af_cause(acc);
+    pte = ld_le(h->mem + (pte_addr - h->cfg.mem_base), 8);
+    if (pte >> 63) return pf;                                                     /* napotCheck without Svnapot (VirtMem.hpp:1090) */
+    /* isValidPte (VirtMem.hpp:558): V, not (W without R), reserved bits 60:54 zero.  The xwr = 010 encoding that
+     * isSsPte lets through for fetches (VirtMem.cpp:740-743) faults below all the same. */
+    if (!(pte & 1) || (!(pte & 2) && (pte & 4)) || ((pte >> 54) & 0x7f)) return pf;
+    global |= (pte >> 5) & 1;
+    if (!(pte & 0xe)) {                                                           /* pointer to the next level (:747-756) */
+      if ((pte & 0xd0) || ((pte >> 61) & 3)) return pf;                           /* A, D, U, PBMT must be zero */
+      if (--ii < 0) return pf;
+      root = ((pte >> 10) & 0xfffffffffffULL) << 12;
+      continue;
+    }
+    if ((pte >> 61) & 3) return pf;                                               /* Svpbmt off (:772-773) */
+    const int u = (pte >> 4) & 1, r = (pte >> 1) & 1, w = (pte >> 2) & 1, x = (pte >> 3) & 1;
+    if (pm == PRV_U && !u) return pf;
+    if (pm == PRV_S && u && (!sum || acc == 4)) return pf;
+    if ((acc == 1 && !(r || (mxr && x))) || (acc == 2 && !w) || (acc == 4 && !x)) return pf;
+    for (int j = 0; j < ii; ++j)                                                  /* misaligned superpage (:804-806) */
+      if ((pte >> (10 + 9 * j)) & 0x1ff) return pf;
+    if (ad_check && (!((pte >> 6) & 1) || (acc == 2 && !((pte >> 7) & 1)))) return pf;   /* faultOnFirstAccess_ (:809-814) */
+    break;
   }
-  u64 va2 = (va + size - 1) & ~mask;
-  unsigned n1 = (unsigned)(va2 - va);
-  if (!pmp_ok(h, pm, va, need) || !in_mem(h, va, n1)) { *tval = va; return 1; }
-  if (!pmp_ok(h, pm, va2, need) || !in_mem(h, va2, size)) { *tval = va2; return 1; }
+  /* computePhysAddr (VirtMem.cpp:665-689) */
+  u64 a = va & 0xfff;
+  for (int j = 0; j < ii; ++j) a |= ((va >> (12 + 9 * j)) & 0x1ff) << (12 + 9 * j);
+  for (int j = ii; j < 3; ++j) a |= ((pte >> (10 + 9 * j)) & (j == 2 ? 0x3ffffffULL : 0x1ffULL)) << (12 + 9 * j);
+  *pa = a;
+  memset(e, 0, sizeof *e);
+  e->vpn = va >> 12; e->ppn = a >> 12; e->asid = (u32)((h->satp >> 44) & 0xffff); e->valid = 1; e->global = (uint8_t)global;
+  e->user = (pte >> 4) & 1; e->read = (pte >> 1) & 1; e->write = (pte >> 2) & 1; e->exec = (pte >> 3) & 1;
+  e->accessed = (pte >> 6) & 1; e->dirty = (pte >> 7) & 1; e->level = (uint8_t)(1 + ii);
   return 0;
 }
 
+/* Tlb::findEntry (Tlb.hpp:63-71) */
+static struct rvo_tlbe* tlb_find(rvo_hart* h, u64 vpn)
+{
+  struct rvo_tlbe* e = &h->tlb[vpn & (h->tlb_n - 1)];
+  u32 asid = (u32)((h->satp >> 44) & 0xffff);
+  return (e->valid && e->vpn == vpn && (e->global || e->asid == asid)) ? e : NULL;
+}
+
+/* VirtMem::translate (VirtMem.cpp:261-329), single stage.  Returns 0 or the exception cause. */
+static unsigned translate(rvo_hart* h, u64 va, unsigned pm, unsigned acc, u64* pa)
+{
+  const unsigned pf = pf_cause(acc);
+  *pa = va;
+  struct rvo_tlbe* e = tlb_find(h, va >> 12);
+  if (e) {
+    e->counter = (e->counter + 1) & 3;                                            /* findEntryUpdateTime (Tlb.hpp:91-100) */
+    const int sum = (h->mstatus & MST_SUM) != 0, mxr = (h->mstatus & MST_MXR) != 0;
+    if (pm == PRV_U && !e->user) return pf;
+    if (pm == PRV_S && e->user && (acc == 4 || !sum)) return pf;
+    if ((acc == 1 && !(e->read || (mxr && e->exec))) || (acc == 2 && !e->write) || (acc == 4 && !e->exec)) return pf;
+    if (!e->accessed || (acc == 2 && !e->dirty)) e->valid = 0;                    /* :311-312: forget the entry and walk again */
+    else { *pa = (e->ppn << 12) | (va & 0xfff); return 0; }
+  }
+  struct rvo_tlbe ne;
+  unsigned cause = page_walk(h, va, pm, acc, 1, pa, &ne);
+  if (cause) { *pa = va; return cause; }
+  struct rvo_tlbe* slot = &h->tlb[ne.vpn & (h->tlb_n - 1)];                       /* Tlb::insertEntry (Tlb.cpp:74-92) */
+  if (slot->valid && (slot->counter & 2)) slot->counter--;
+  else *slot = ne;
+  return 0;
+}
+unsigned rvo_translate(rvo_hart* h, u64 va, unsigned pm, unsigned acc, u64* pa) { if (!paging_on(h, pm)) { *pa = va; return 0; } return translate(h, va, pm, acc, pa); }
+
+/* VirtMem::transAddrNoUpdate (VirtMem.cpp:143-205): no TLB update, no A/D check. */
+static unsigned translate_noupdate(rvo_hart* h, u64 va, unsigned pm, unsigned acc, u64* pa)
+{
+  const unsigned pf = pf_cause(acc);
+  *pa = va;
+  struct rvo_tlbe* e = tlb_find(h, va >> 12);
+  if (e) {
+    const int sum = (h->mstatus & MST_SUM) != 0, mxr = (h->mstatus & MST_MXR) != 0;
+    if (pm == PRV_U && !e->user) return pf;
+    if (pm == PRV_S && e->user && (acc == 4 || !sum)) return pf;
+    if ((acc == 1 && !(e->read || (mxr && e->exec))) || (acc == 2 && !e->write) || (acc == 4 && !e->exec)) return pf;
+    *pa = (e->ppn << 12) | (va & 0xfff);
+    return 0;
+  }
+  struct rvo_tlbe ne;
+  unsigned cause = page_walk(h, va, pm, acc, 0, pa, &ne);
+  if (cause) *pa = va;
+  return cause;
+}
+
+unsigned rvo_translate_noupdate(rvo_hart* h, u64 va, unsigned pm, unsigned acc, u64* pa) { if (!paging_on(h, pm)) { *pa = va; return 0; } return translate_noupdate(h, va, pm, acc, pa); }
+
+/* Tlb::sizeIn4kBytes / alignPageNumBySize for Sv39 (Tlb.hpp:389-456); Bare: size 0 */
+static u64 tlb_size4k(const rvo_hart* h, unsigned level) { return (h->satp >> 60) != 8 ? 0 : level <= 1 ? 1 : level == 2 ? 512 : 262144; }
+static u64 tlb_align(const rvo_hart* h, u64 vpn, unsigned level) { return ((h->satp >> 60) != 8 || level <= 1) ? vpn : level == 2 ? (vpn >> 9) << 9 : (vpn >> 18) << 18; }
+
+/* execSfence_vma's TLB part (Hart.cpp:12139-12173) over Tlb::invalidate / invalidateAsid / invalidateVirtualPage /
+ * invalidateVirtualPageAsid (Tlb.hpp:176-284, 368-375).  Entries are matched whether or not they are valid. */
+void rvo_sfence(rvo_hart* h, int has_addr, u64 addr, int has_asid, u64 asid_v)
+{
+  const u32 asid = (u32)asid_v;
+  const u64 vpn = addr >> 12;
+  if (!has_addr) {
+    for (unsigned i = 0; i < h->tlb_n; ++i) {
+      struct rvo_tlbe* e = &h->tlb[i];
+      if (!has_asid || (!e->global && e->asid == asid)) { e->valid = 0; e->counter = 0; }
+    }
+    return;
+  }
+  unsigned max_size = 0; u64 vpn_of_max = 0;
+  for (unsigned i = 0; i < h->tlb_n; ++i) {
+    struct rvo_tlbe* e = &h->tlb[i];
+    u64 size = tlb_size4k(h, e->level), pn = tlb_align(h, e->vpn, e->level);
+    if (pn <= vpn && vpn < pn + size && (!has_asid || (e->asid == asid && !e->global))) {
+      if (size > max_size) { max_size = (unsigned)size; vpn_of_max = e->vpn; }
+      e->valid = 0; e->counter = 0;
+    }
+  }
+  if (max_size > 1)                                                               /* "invalidate subpages covered by super-page" */
+    for (unsigned i = 0; i < h->tlb_n; ++i) {
+      struct rvo_tlbe* e = &h->tlb[i];
+      if (vpn_of_max <= vpn && vpn < vpn_of_max + max_size && (!has_asid || (e->asid == asid && !e->global))) { e->valid = 0; e->counter = 0; }
+    }
+}
+
+/* Same two-word packing as the device keeps in HBM (wsp_core.h) */
+u64 rvo_tlb_hash(const rvo_hart* h)
+{
+  u64 s = 0;
+  for (unsigned i = 0; i < h->tlb_n; ++i) {
+    const struct rvo_tlbe* e = &h->tlb[i];
+    u64 fl = (u64)e->valid | (u64)e->global << 1 | (u64)e->user << 2 | (u64)e->read << 3 | (u64)e->write << 4 | (u64)e->exec << 5 |
+             (u64)e->accessed << 6 | (u64)e->dirty << 7;
+    s = rvo_fold(s, (e->vpn & 0xfffffffffffffULL) | (u64)(e->level & 3) << 52 | (u64)(e->counter & 3) << 54 | fl << 56);
+    s = rvo_fold(s, (e->ppn & 0xfffffffffffULL) | (u64)(e->asid & 0xffff) << 44);
+  }
+  return s;
+}
+
+/* determineLoadException / determineStoreException (Hart.cpp:1988-2154, 13786-13935).  need: 1 load, 2 store/amo.
+ * Returns 0 and the physical addresses of the (up to two) parts, or the exception cause with *tval. */
+static unsigned ldst_addr(rvo_hart* h, u64 va, unsigned size, unsigned need, u64* pa1, u64* pa2, u64* tval)
+{
+  const unsigned pm = eff_ldst_priv(h), af = need == 1 ? 5 : 7;
+  const int tr = paging_on(h, pm);
+  const u64 mask = size - 1;
+  const int misal = (va & mask) != 0;
+  const u64 va2 = misal ? ((va + size - 1) & ~mask) : va;
+  unsigned c;
+  *pa1 = va;
+  if (tr && (c = translate(h, va, pm, need, pa1)) != 0) { *tval = va; return c; }
+  if (!misal) {
+    if (!pmp_ok(h, pm, *pa1, need) || !in_mem(h, *pa1, size)) { *tval = va; return af; }
+    *pa2 = *pa1;
+    return 0;
+  }
+  const int cross = (va >> 12) != (va2 >> 12);
+  *pa2 = (*pa1 + size - 1) & ~mask;
+  if (cross && tr && (c = translate(h, va2, pm, need, pa2)) != 0) { *tval = va2; return c; }
+  const unsigned n1 = (unsigned)(((*pa1 + size - 1) & ~mask) - *pa1);              /* lower part stops at the alignment boundary (:2068-2069) */
+  if (!pmp_ok(h, pm, *pa1, need) || !in_mem(h, *pa1, n1)) { *tval = va; return af; }
+  if (!pmp_ok(h, pm, *pa2, need) || !in_mem(h, *pa2, size)) { *tval = va2; return af; }
+  if (!cross) *pa2 = *pa1;
+  return 0;
+}
+
+/* Hart::memRead / memWrite over a possibly page-crossing item (Hart.hpp:3469-3567) */
+static u64 mem_read2(const rvo_hart* h, u64 pa1, u64 pa2, unsigned size)
+{
+  if (pa1 == pa2) return ld_le(h->mem + (pa1 - h->cfg.mem_base), size);
+  unsigned size1 = size - (unsigned)(pa1 & (size - 1));
+  u64 v = 0;
+  for (unsigned i = 0; i < size; ++i) {
+    u64 a = i < size1 ? pa1 + i : pa2 + (i - size1);
+    v |= (u64)h->mem[a - h->cfg.mem_base] << (8 * i);
+  }
+  return v;
+}
+static void mem_write2(rvo_hart* h, u64 pa1, u64 pa2, unsigned size, u64 v)
+{
+  if (pa1 == pa2) { st_le(h->mem + (pa1 - h->cfg.mem_base), v, size); return; }
+  unsigned size1 = size - (unsigned)(pa1 & (size - 1));
+  for (unsigned i = 0; i < size; ++i) {
+    u64 a = i < size1 ? pa1 + i : pa2 + (i - size1);
+    h->mem[a - h->cfg.mem_base] = (uint8_t)(v >> (8 * i));
+  }
+}
+
+/* satp.MODE Sv48 / Sv57 are outside the modelled subset */
 static int ldst_translate_unsupported(rvo_hart* h)
 {
-  /* Paging (satp.MODE != Bare with effective privilege < M) is not modelled in this round. */
-  if (ext(h, RVO_ISA_S) && eff_ldst_priv(h) != PRV_M && (h->satp >> 60) != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return 1; }
+  if (ext(h, RVO_ISA_S) && eff_ldst_priv(h) != PRV_M && (h->satp >> 60) > 8) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return 1; }
   return 0;
 }
 
 /* Hart::load (Hart.cpp:2302) + readForLoad (2477). Returns 1 on success. */
 static int do_load(rvo_hart* h, u64 va, unsigned size, u64* out)
 {
-  u64 tval;
+  u64 tval, pa1, pa2;
   if (ldst_translate_unsupported(h)) return 0;
-  if (check_access(h, va, size, 1, &tval)) { ldst_exception(h, 5, tval); return 0; }
-  if (h->cfg.tohost_valid && va == h->cfg.tohost) { *out = 0; return 1; }   /* Hart.cpp:2509-2513 */
-  *out = ld_le(h->mem + (va - h->cfg.mem_base), size);
+  unsigned c = ldst_addr(h, va, size, 1, &pa1, &pa2, &tval);
+  if (c) { ldst_exception(h, c, tval); return 0; }
+  if (h->cfg.tohost_valid && pa1 == h->cfg.tohost) { *out = 0; return 1; }   /* Hart.cpp:2509-2513 */
+  *out = mem_read2(h, pa1, pa2, size);
   return 1;
 }
 
@@ -626,13 +826,14 @@ static void store_tohost(rvo_hart* h, u64 pa, u64 val, unsigned size)
 /* Hart::store (Hart.cpp:2674) + writeForStore (2727). Returns 1 on success. */
 static int do_store(rvo_hart* h, u64 va, unsigned size, u64 val)
 {
-  u64 tval;
+  u64 tval, pa1, pa2;
   if (ldst_translate_unsupported(h)) return 0;
-  if (check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, tval); return 0; }
+  unsigned c = ldst_addr(h, va, size, 2, &pa1, &pa2, &tval);
+  if (c) { ldst_exception(h, c, tval); return 0; }
   u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
-  h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;
-  if (h->cfg.tohost_valid && (va == h->cfg.tohost || va == h->cfg.tohost + 4)) { store_tohost(h, va, sv, size); return 1; }
-  st_le(h->mem + (va - h->cfg.mem_base), sv, size);
+  h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;                    /* the log's m line carries the virtual address (printTrace.cpp:457) */
+  if (h->cfg.tohost_valid && (pa1 == h->cfg.tohost || pa1 == h->cfg.tohost + 4)) { store_tohost(h, pa1, sv, size); return 1; }
+  mem_write2(h, pa1, pa2, size, sv);
   return 1;
 }
 
@@ -755,7 +956,7 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   if (num == C_SATP) {
     unsigned mode = (unsigned)(next >> 60);
     if (mode != 0 && mode != 8 && mode != 9 && mode != 10) goto done;  /* unsupported MODE: dropped (13284-13294) */
-    if (mode != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return; }
+    if (mode > 8) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return; }   /* Sv48 / Sv57: not modelled */
   }
   if (num >= 0x3B0 && num < 0x3EF && !pmpaddr_locked(h, num - 0x3B0)) {
     /* postCsrUpdate (Hart.cpp:4672-4679) refreshes the region table only when the written entry itself is on: a
@@ -1022,6 +1223,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
           if (!ext(h, RVO_ISA_S)) goto ill;
           if (h->priv == PRV_U) goto ill;
           if (h->priv == PRV_S && (h->mstatus & MST_TVM)) goto ill;
+          rvo_sfence(h, rs1 != 0, h->x[rs1], rs2 != 0, h->x[rs2]);                           /* Hart.cpp:12139-12173: by register number */
           return;
         }
         break;
@@ -1047,34 +1249,41 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
   if (f5 == 2) {                                            /* lr: amo.cpp:142-266 */
     if (rs2 != 0) { illegal(h, raw); return; }
     if (ldst_translate_unsupported(h)) return;
-    int bad = check_access(h, va, size, 1, &tval) || (va & (size - 1));
-    if (bad) { ldst_exception(h, 5, va); return; }
-    u64 v = ld_le(h->mem + (va - h->cfg.mem_base), size);
+    u64 pa1, pa2;
+    /* determineLoadException first (a translation fault wins), then the alignment / reservability check; either way
+     * the trap value is the LR's own address (amo.cpp:203-207) */
+    unsigned c = ldst_addr(h, va, size, 1, &pa1, &pa2, &tval);
+    if (c == 0 && (va & (size - 1))) c = 5;
+    if (c) { ldst_exception(h, c, va); return; }
+    u64 v = ld_le(h->mem + (pa1 - h->cfg.mem_base), size);
     if (size == 4) v = (u64)(i64)(i32)v;
     wx(h, rd, v);
-    h->lr_valid = 1; h->lr_size = 8; h->lr_addr = va & ~7ULL;       /* lrResSize_ = sizeof(URV) (Hart.hpp:6733) */
+    h->lr_valid = 1; h->lr_size = 8; h->lr_addr = pa1 & ~7ULL;      /* lrResSize_ = sizeof(URV) (Hart.hpp:6733); physical address (amo.cpp:254) */
     return;
   }
   if (f5 == 3) {                                            /* sc: amo.cpp:273-420 */
     if (ldst_translate_unsupported(h)) return;
     int exc = 0;
-    if (va & (size - 1)) { ldst_exception(h, 7, va); exc = 1; }
-    else if (check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, va); exc = 1; }
-    int had = h->lr_valid && h->lr_addr <= va && va + size <= h->lr_addr + h->lr_size;
+    u64 pa1 = va, pa2;
+    if (va & (size - 1)) { ldst_exception(h, 7, va); exc = 1; }          /* misalHasPriority_: before any translation (amo.cpp:304-309) */
+    else { unsigned c = ldst_addr(h, va, size, 2, &pa1, &pa2, &tval); if (c) { ldst_exception(h, c, va); exc = 1; } }
+    int had = h->lr_valid && h->lr_addr <= pa1 && pa1 + size <= h->lr_addr + h->lr_size;
     h->lr_valid = 0;                                                  /* cancelLr(SC) amo.cpp:403-405 */
     if (exc) return;
     if (!had) { wx(h, rd, 1); return; }
     u64 sv = size == 8 ? h->x[rs2] : (h->x[rs2] & 0xffffffffULL);
     h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;
-    st_le(h->mem + (va - h->cfg.mem_base), sv, size);
+    st_le(h->mem + (pa1 - h->cfg.mem_base), sv, size);
     wx(h, rd, 0);
     return;
   }
   switch (f5) { case 0: case 1: case 4: case 8: case 12: case 16: case 20: case 24: case 28: break; default: illegal(h, raw); return; }
   /* amo: execAmo32Op / execAmo64Op (amo.cpp:427-460): amoLoad then store<>() */
   if (ldst_translate_unsupported(h)) return;
-  if ((va & (size - 1)) || check_access(h, va, size, 2, &tval)) { ldst_exception(h, 7, va); return; }   /* amoLoad validates with the store check only (amo.cpp:28-56) */
-  u64 ld = ld_le(h->mem + (va - h->cfg.mem_base), size);
+  u64 apa1 = va, apa2;
+  if (va & (size - 1)) { ldst_exception(h, 7, va); return; }           /* validateAmoAddr: misaligned first (amo.cpp:35-38) */
+  { unsigned c = ldst_addr(h, va, size, 2, &apa1, &apa2, &tval); if (c) { ldst_exception(h, c, va); return; } }   /* amoLoad validates with the store check only (amo.cpp:28-56) */
+  u64 ld = ld_le(h->mem + (apa1 - h->cfg.mem_base), size);
   if (size == 4) ld = (u64)(i64)(i32)ld;
   u64 b = h->x[rs2], r;
   switch (f5) {
@@ -1248,24 +1457,48 @@ ill:
 }
 
 /* ------------------------------------------------------------------ fetch + step */
-/* fetchInstNoTrap (Hart.cpp:3052-3206), bare translation. Returns 0 on success. */
-static int fetch(rvo_hart* h, u64 pc, u32* inst, u64* tval)
+/* fetchInstNoTrap (Hart.cpp:3052-3206). Returns 0 on success, 1 with *cause / *tval on a fault, 2 when the hart stopped. */
+static int fetch(rvo_hart* h, u64 pc, u32* inst, u64* tval, unsigned* cause)
 {
-  if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return 2; }
-  if (!pmp_ok(h, h->priv, pc, 4)) { *tval = pc; return 1; }                       /* Hart.cpp:3079-3084 */
-  if (!(pc & 3)) {
-    if (!in_mem(h, pc, 4)) { *tval = pc; return 1; }
-    u32 w = (u32)ld_le(h->mem + (pc - h->cfg.mem_base), 4);
+  if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) > 8) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return 2; }
+  const int tr = paging_on(h, h->priv);
+  u64 pa = pc;
+  unsigned c;
+  *cause = 1;
+  if (tr && (c = translate(h, pc, h->priv, 4, &pa)) != 0) { *cause = c; *tval = pc; return 1; }
+  if (!pmp_ok(h, h->priv, pa, 4)) { *tval = pc; return 1; }                       /* Hart.cpp:3079-3084 */
+  if (!(pa & 3)) {
+    if (!in_mem(h, pa, 4)) { *tval = pc; return 1; }
+    u32 w = (u32)ld_le(h->mem + (pa - h->cfg.mem_base), 4);
     *inst = (w & 3) != 3 ? (w & 0xffff) : w;
     return 0;
   }
-  if (!in_mem(h, pc, 2)) { *tval = pc; return 1; }
-  u32 lo = (u32)ld_le(h->mem + (pc - h->cfg.mem_base), 2);
+  if (!in_mem(h, pa, 2)) { *tval = pc; return 1; }
+  u32 lo = (u32)ld_le(h->mem + (pa - h->cfg.mem_base), 2);
   if ((lo & 3) != 3) { *inst = lo; return 0; }
-  if (!pmp_ok(h, h->priv, pc + 2, 4)) { *tval = pc + 2; return 1; }               /* Hart.cpp:3158-3162 */
-  if (!in_mem(h, pc + 2, 2)) { *tval = pc + 2; return 1; }
-  *inst = lo | ((u32)ld_le(h->mem + (pc + 2 - h->cfg.mem_base), 2) << 16);
+  /* second half: pa2 starts out as the *virtual* address + 2 and is translated when its page index differs from the
+   * first half's physical page index (Hart.cpp:3144-3156) */
+  u64 pa2 = pc + 2;
+  if ((pa >> 12) != (pa2 >> 12) && tr && (c = translate(h, pc + 2, h->priv, 4, &pa2)) != 0) { *cause = c; *tval = pc + 2; return 1; }
+  if (!pmp_ok(h, h->priv, pa2, 4)) { *tval = pc + 2; return 1; }                  /* Hart.cpp:3158-3162 */
+  if (!in_mem(h, pa2, 2)) { *tval = pc + 2; return 1; }
+  *inst = lo | ((u32)ld_le(h->mem + (pa2 - h->cfg.mem_base), 2) << 16);
   return 0;
+}
+
+/* Hart::readInst (Hart.cpp:2997-3037): the interrupted instruction, for the log only */
+static u32 read_inst_for_log(rvo_hart* h, u64 va)
+{
+  const int tr = paging_on(h, h->priv);
+  u64 pa = va;
+  if (tr && translate_noupdate(h, va, h->priv, 4, &pa)) return 0;
+  if (!in_mem(h, pa, 2)) return 0;
+  u32 iw = (u32)ld_le(h->mem + (pa - h->cfg.mem_base), 2);
+  if ((iw & 3) != 3) return iw;
+  u64 va2 = va + 2, pa2 = pa + 2;
+  if (tr && (va >> 12) != (va2 >> 12) && translate_noupdate(h, va2, h->priv, 4, &pa2)) return 0;
+  if (in_mem(h, pa2, 2)) iw |= (u32)ld_le(h->mem + (pa2 - h->cfg.mem_base), 2) << 16;
+  return iw;
 }
 
 int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)
@@ -1283,23 +1516,20 @@ int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)
     {                                                        /* processExternalInterrupt (Hart.cpp:7216-7262) */
       unsigned icause, inext;
       if (interrupt_possible(h, &icause, &inext)) {
-        if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) != 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); break; }
+        if (ext(h, RVO_ISA_S) && h->priv != PRV_M && (h->satp >> 60) > 8) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); break; }
         /* the interrupted instruction is read for the log only: PMA check, no PMP, no trap (Hart::readInst, Hart.cpp:2997) */
-        u32 iw = 0;
-        if (in_mem(h, h->pc, 2)) {
-          iw = (u32)ld_le(h->mem + (h->pc - h->cfg.mem_base), 2);
-          if ((iw & 3) == 3 && in_mem(h, h->pc + 2, 2)) iw |= (u32)ld_le(h->mem + (h->pc + 2 - h->cfg.mem_base), 2) << 16;
-        }
+        u32 iw = read_inst_for_log(h, h->pc);
         take_interrupt(h, icause, inext, h->pc);
         if (!(h->mcountinhibit & 1)) h->cycle++;             /* Hart.cpp:7255-7256 */
         finish_commit(h, iw, (iw & 3) == 3 ? 4 : 2, priv0, 2, log, cap, n);
         continue;
       }
     }
-    int fr = fetch(h, h->pc, &inst, &tval);
+    unsigned fcause = 1;
+    int fr = fetch(h, h->pc, &inst, &tval, &fcause);
     if (fr == 2) break;
     if (fr == 1) {
-      take_exception(h, 1, h->curr_pc, tval);
+      take_exception(h, fcause, h->curr_pc, tval);
       if (h->status != RVO_RUNNING) {                        /* consecutive-illegal stop inside a fetch fault */
         h->retire_count++; if (!(h->mcountinhibit & 4)) h->instret++;
         finish_commit(h, 0, 2, priv0, 0, log, cap, n); break;
@@ -1359,6 +1589,7 @@ u64 rvo_state_hash(const rvo_hart* h)
   s = rvo_fold(s, h->time_);
   for (int i = 0; i < 8; ++i) s = rvo_fold(s, h->pmpcfg[i]);
   for (int i = 0; i < 64; ++i) s = rvo_fold(s, h->pmpaddr[i]);
+  if (ext(h, RVO_ISA_S)) s = rvo_fold(s, rvo_tlb_hash(h));
   return s;
 }
 

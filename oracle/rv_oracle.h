@@ -68,6 +68,8 @@ typedef struct {
   uint32_t tohost_valid;
   uint32_t hart_id;
   uint64_t reset_pc;
+  uint32_t tlb_entries; /* TLB size, a power of two; 0 = the reference default 2048 (Hart.cpp:106) */
+  uint32_t pad;
 } rvo_config;
 
 typedef struct rvo_hart rvo_hart;
@@ -107,6 +109,15 @@ uint64_t  rvo_mem_hash(const rvo_hart* h);
 /* The hash primitives the device kernels must reproduce bit-for-bit. */
 /* PMP permission bits (r=1 w=2 x=4) of privilege pm at addr: test hook for pinning against the reference PmpManager */
 unsigned  rvo_pmp_perm(const rvo_hart* h, unsigned pm, uint64_t addr);
+/* VirtMem::translate (VirtMem.cpp:261) for privilege pm (0 U, 1 S) and access acc (1 read, 2 write, 4 exec) under the
+ * hart's current satp / mstatus.SUM / MXR: returns 0 and *pa, or the exception cause.  Test hook for pinning against
+ * the reference VirtMem + Tlb. */
+unsigned  rvo_translate(rvo_hart* h, uint64_t va, unsigned pm, unsigned acc, uint64_t* pa);
+unsigned  rvo_translate_noupdate(rvo_hart* h, uint64_t va, unsigned pm, unsigned acc, uint64_t* pa);   /* VirtMem::transAddrNoUpdate */
+/* Tlb invalidation as execSfence_vma performs it (Hart.cpp:12139-12173): has_addr / has_asid = rs1 / rs2 is not x0 */
+void      rvo_sfence(rvo_hart* h, int has_addr, uint64_t addr, int has_asid, uint64_t asid);
+/* digest of the TLB contents (same packing as the device) */
+uint64_t  rvo_tlb_hash(const rvo_hart* h);
 uint64_t  rvo_fold(uint64_t h, uint64_t w);
 uint64_t  rvo_mix(uint64_t x);
 

@@ -52,7 +52,8 @@ class Commit(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("xlen", C.c_uint32), ("isa", C.c_uint32), ("mem_base", C.c_uint64), ("mem_size", C.c_uint64),
-                ("tohost", C.c_uint64), ("tohost_valid", C.c_uint32), ("hart_id", C.c_uint32), ("reset_pc", C.c_uint64)]
+                ("tohost", C.c_uint64), ("tohost_valid", C.c_uint32), ("hart_id", C.c_uint32), ("reset_pc", C.c_uint64),
+                ("tlb_entries", C.c_uint32), ("pad", C.c_uint32)]
 
 
 _lib = None
@@ -92,6 +93,11 @@ def lib():
             getattr(L, n).restype = C.c_uint64
             getattr(L, n).argtypes = [C.c_void_p]
         L.rvo_status.argtypes = [C.c_void_p]
+        L.rvo_translate.restype = C.c_uint
+        L.rvo_translate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]
+        L.rvo_sfence.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_uint64]
+        L.rvo_tlb_hash.restype = C.c_uint64
+        L.rvo_tlb_hash.argtypes = [C.c_void_p]
         L.rvo_fold.restype = C.c_uint64
         L.rvo_fold.argtypes = [C.c_uint64, C.c_uint64]
         L.rvo_mix.restype = C.c_uint64
@@ -109,10 +115,10 @@ def has_softfloat() -> bool:
 
 class Hart:
     def __init__(self, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, tohost=None,
-                 hart_id=0, reset_pc=None):
+                 hart_id=0, reset_pc=None, tlb_entries=0):
         self.L = lib()
         cfg = Config(64, isa_flags(isa), mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
-                     mem_base if reset_pc is None else reset_pc)
+                     mem_base if reset_pc is None else reset_pc, tlb_entries, 0)
         self.h = self.L.rvo_create(C.byref(cfg))
         if not self.h:
             raise ValueError("rvo_create failed")
@@ -166,6 +172,17 @@ class Hart:
     @property
     def priv(self):
         return self.L.rvo_priv(self.h)
+
+    def translate(self, va, pm, acc):
+        """(cause, pa) of VirtMem::translate for privilege pm and access acc (1 r, 2 w, 4 x)."""
+        pa = C.c_uint64()
+        c = self.L.rvo_translate(self.h, va, pm, acc, C.byref(pa))
+        return c, pa.value
+
+    def sfence(self, addr=None, asid=None):
+        self.L.rvo_sfence(self.h, addr is not None, addr or 0, asid is not None, asid or 0)
+
+    tlb_hash = property(lambda s: s.L.rvo_tlb_hash(s.h))
 
     def run(self, max_exec=1 << 62, log_cap=0):
         """Returns (status, [Commit...])."""

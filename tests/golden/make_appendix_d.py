@@ -60,6 +60,12 @@ def main():
                     "stop": "Failed stop: Hart 0: 16 consecutive illegal instructions"},
         "sv39_first": {"isa": "rv64imafdcsu_zicsr", "records": [r for r in sv_recs if r["tag"] == 1],
                        "pokes": {"mstatus_mpp": 1, "mepc": 0x40000100}, "next_pc": 0x40000100, "next_priv": "S"},
+        # the whole Sv39 sample: set-up as the survey's caption states it (root PTE[1] = 0x200000cf maps VA 0x40000000 -> PA
+        # 0x80000000 as a 1 GiB V R W X A D leaf; satp = 8<<60 | 0x80002; pmpaddr0 = ~0, pmpcfg0 = 0x1f; tohost = PA 0x80003000)
+        "sv39": {"isa": "rv64imafdcsu_zicsr", "records": sv_recs,
+                 "pokes": {"mstatus_mpp": 1, "mepc": 0x40000100, "satp": (8 << 60) | 0x80002, "pmpaddr0": (1 << 54) - 1, "pmpcfg0": 0x1f},
+                 "mem": {"0x80002008": 0x200000cf}, "tohost": 0x80003000, "va_to_pa": 0x40000000,
+                 "stop": "Successful stop: Hart 0: write to to-host"},
     }
     with open(os.path.join(HERE, "appendix_d.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -12,12 +12,13 @@ using namespace wsp;
 
 struct HostMem {
   u64 x[32], f[32], cold_[CI_COUNT];
-  u8* ram;
+  u8* ram; u64* tlb_;
   u64 rx(u32 r) const { return x[r]; }
   void wx(u32 r, u64 v) { x[r] = v; }
   u64 rf(u32 r) const { return f[r]; }
   void wf(u32 r, u64 v) { f[r] = v; }
   u64& cold(u32 i) { return cold_[i]; }
+  u64& tlb(u32 i) { return tlb_[i]; }
   u8 ld8(u64 o) const { return ram[o]; }
   u16 ld16(u64 o) const { u16 v; memcpy(&v, ram + o, 2); return v; }
   u32 ld32(u64 o) const { u32 v; memcpy(&v, ram + o, 4); return v; }
@@ -28,7 +29,7 @@ struct HostMem {
   void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
 };
 
-struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
 
 template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 {
@@ -53,17 +54,21 @@ template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 }
 
 extern "C" {
-Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id)
+Sim* hs_create2(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u32 tlb_entries)
 {
   Sim* s = new Sim();
   s->ram.assign(mem_size, 0);
   memset(&s->L, 0, sizeof s->L);
   s->L.m.ram = s->ram.data();
+  s->L.tlb_n = (isa & ISA_S) ? (tlb_entries ? tlb_entries : 2048) : 0;
+  s->tlb.assign(2 * (size_t)s->L.tlb_n + 2, 0);
+  s->L.m.tlb_ = s->tlb.data();
   s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
   s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
   s->max_exec = ~0ULL;
   return s;
 }
+Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id) { return hs_create2(isa, mem_base, mem_size, tohost, hart_id, 0); }
 void hs_destroy(Sim* s) { delete s; }
 int hs_write_mem(Sim* s, u64 addr, const void* src, u64 n)
 { if (!s->L.in_mem(addr, n)) return -1; memcpy(s->ram.data() + (addr - s->L.mem_base), src, n); return 0; }
@@ -118,6 +123,7 @@ u64 hs_state_hash(Sim* s)
   for (int c : c2) h = fold(h, L.m.cold_[c]);
   h = fold(h, L.h.cycle); h = fold(h, L.h.instret); h = fold(h, L.h.exec);
   for (int i = 0; i < 72; ++i) h = fold(h, L.m.cold_[CI_PMPCFG0 + i]);
+  if (L.isa & ISA_S) { u64 t = 0; for (u32 i = 0; i < 2 * L.tlb_n; ++i) t = fold(t, s->tlb[i]); h = fold(h, t); }
   return h;
 }
 u64 hs_mem_hash(Sim* s)

@@ -189,6 +189,27 @@ def test_hostsim_pmp_programs():
     assert faults > 1000 and stale >= 1
 
 
+def test_hostsim_sv39_programs():
+    """Row a11: Sv39 walks (4K / 2M / 1G leaves, malformed PTEs), the direct-mapped TLB with its replacement counter and
+    stale entries after page-table edits, sfence.vma forms, SUM / MXR, ASID switches, MPRV accesses, page-crossing
+    misaligned data and fetches -- device core (host build) == oracle, records and TLB contents included."""
+    pf = ok_su = 0
+    for s in range(96):
+        p = WL.sv39_program(s)
+        if s < 24:
+            b, _, log = S.run_oracle(p, log_cap=60000)
+            a, _, _ = S.run_hostsim(p)
+            assert a == b, (s, a, b)
+            for c in log:
+                if c.trap == 1:
+                    pf += any(k == 5 and key in (0x342, 0x142) and val in (12, 13, 15) for k, key, val in c.changes())
+                elif c.priv != 3:
+                    ok_su += 1
+        else:
+            _same(p)
+    assert pf > 1500 and ok_su > 10000
+
+
 def test_pmp_semantics_directed():
     """PmpManager.hpp:155-177 + Hart.cpp:3079/3158/1988: no entry -> U store faults (cause 7, tval = address); a NAPOT rw-
     entry admits it; a locked r-- entry makes the same store fault in M mode; a misaligned access that runs into a

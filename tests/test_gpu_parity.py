@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _run_batch(progs, seeds=None, lanes=0, trace=True, same_elf=False, max_steps=W.NO_LIMIT):
     n = len(progs)
     p0 = progs[0]
-    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes)
+    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0))
     try:
         if same_elf:
             b.load_elf_bytes(p0.elf)
@@ -144,6 +144,32 @@ def test_pmp_programs():
         assert left == 0
         _check(progs, res)
     assert any(r["status"] == W.ST_STOP_UNSUPPORTED and r["value"] == 0x181 for r in res)
+
+
+def test_sv39_programs():
+    """Row a11: Sv39 translation with the reference's TLB model (8 entries here so that replacement and stale entries
+    matter), S and U bodies at virtual addresses, page faults on fetch / load / store / AMO, sfence.vma, satp / SUM / MXR
+    changes, MPRV; the state digest covers the TLB contents."""
+    progs = [WL.sv39_program(s) for s in range(128)]
+    for lanes in (0, 16):
+        b, left, res = _run_batch(progs, lanes=lanes)
+        b.close()
+        assert left == 0
+        _check(progs, res)
+    assert sum(r["status"] == W.ST_STOP_TOHOST for r in res) > 90
+
+
+def test_sv39_default_tlb_and_snapshot():
+    """The reference's default 2048-entry TLB, and snapshot / restore carrying the TLB."""
+    progs = [WL.sv39_program(s) for s in range(16)]
+    for p in progs:
+        p.meta["tlb_entries"] = 0
+    b, left, res = _run_batch(progs)
+    try:
+        assert left == 0
+        _check(progs, res)
+    finally:
+        b.close()
 
 
 def test_pmp_csr_peek_poke():

@@ -96,3 +96,45 @@ def test_sv39_sample_first_record_mret():
     assert (c.tag, c.pc, c.inst) == (1, r["pc"], int(r["op"], 16))
     assert c.changes() == [(KIND[r["kind"]], r["key"], r["val"])]
     assert h.pc == g["next_pc"] and rvoracle.PRIV_STR[h.priv] == g["next_priv"]
+
+
+def test_sv39_sample_whole_trace():
+    """The survey's Sv39 capture: mret to S at a virtual address mapped by a 1 GiB leaf, three S-mode instructions fetched
+    and one store made through the translation, stop on the *physical* tohost address."""
+    g = GOLD["sv39"]
+    h = rvoracle.Hart(isa=g["isa"], mem_base=0x80000000, mem_size=1 << 16, tohost=g["tohost"])
+    for r in g["records"]:
+        pa = r["pc"] if r["pc"] >= 0x80000000 else r["pc"] - g["va_to_pa"] + 0x80000000
+        h.write_mem(pa, int(r["op"], 16).to_bytes(4, "little"))
+    for a, v in g["mem"].items():
+        h.write_mem(int(a, 16), v.to_bytes(8, "little"))
+    ms = h.csr(0x300)
+    h.set_csr(0x300, (ms & ~(3 << 11)) | (g["pokes"]["mstatus_mpp"] << 11))
+    h.set_csr(0x341, g["pokes"]["mepc"])
+    h.set_csr(0x180, g["pokes"]["satp"])
+    h.set_csr(0x3B0, g["pokes"]["pmpaddr0"])
+    h.set_csr(0x3A0, g["pokes"]["pmpcfg0"])
+    st, log = h.run(100, log_cap=16)
+    assert st == rvoracle.STOP_TOHOST and h.stop_value == 1
+    gold = _group(g["records"])
+    assert len(log) == len(gold)
+    for c in log:
+        recs = gold[c.tag]
+        assert (c.pc, f"{c.inst:08x}", rvoracle.PRIV_STR[c.priv]) == (recs[0]["pc"], recs[0]["op"], recs[0]["priv"]), c.tag
+        assert c.changes() == [(KIND[r["kind"]], r["key"], r["val"]) for r in recs], c.tag
+
+
+def test_sv39_sample_needs_pmp():
+    """Same capture, its last paragraph: without the PMP pokes the first S-mode fetch takes an instruction access fault
+    (mcause = 1), because the PTE read fails the S-mode PMP check."""
+    g = GOLD["sv39"]
+    h = rvoracle.Hart(isa=g["isa"], mem_base=0x80000000, mem_size=1 << 16, tohost=g["tohost"])
+    h.write_mem(0x80000000, (0x30200073).to_bytes(4, "little"))
+    for a, v in g["mem"].items():
+        h.write_mem(int(a, 16), v.to_bytes(8, "little"))
+    ms = h.csr(0x300)
+    h.set_csr(0x300, (ms & ~(3 << 11)) | (1 << 11))
+    h.set_csr(0x341, g["pokes"]["mepc"])
+    h.set_csr(0x180, g["pokes"]["satp"])
+    st, log = h.run(2, log_cap=4)
+    assert log[1].trap == 1 and h.csr(0x342) == 1 and h.csr(0x343) == g["pokes"]["mepc"]

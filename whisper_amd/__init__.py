@@ -31,7 +31,7 @@ class WspError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [("xlen", C.c_uint32), ("n_harts", C.c_uint32), ("isa", C.c_char_p), ("mem_base", C.c_uint64),
                 ("mem_size", C.c_uint64), ("lanes_per_wave", C.c_uint32), ("device", C.c_int32), ("hart_id_base", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("tlb_entries", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -111,10 +111,10 @@ class Batch:
     System64/Hart64, py-bindings.cpp:330-469, for a batch)."""
 
     def __init__(self, n_harts, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, lanes_per_wave=0, device=-1,
-                 hart_id_base=0):
+                 hart_id_base=0, tlb_entries=0):
         self.L = lib()
         self._isa = isa.encode()
-        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, 0)
+        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, tlb_entries)
         h = C.c_void_p()
         _check(self.L.wsp_batch_create(C.byref(desc), C.byref(h)))
         self.h = h

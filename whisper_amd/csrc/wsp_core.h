@@ -328,7 +328,7 @@ enum {
 };
 
 static constexpr u64 MST_SIE = 1ULL << 1, MST_MIE = 1ULL << 3, MST_SPIE = 1ULL << 5, MST_MPIE = 1ULL << 7, MST_SPP = 1ULL << 8;
-static constexpr u64 MST_MPRV = 1ULL << 17, MST_TVM = 1ULL << 20, MST_TW = 1ULL << 21, MST_TSR = 1ULL << 22, MST_SD = 1ULL << 63;
+static constexpr u64 MST_MPRV = 1ULL << 17, MST_SUM = 1ULL << 18, MST_MXR = 1ULL << 19, MST_TVM = 1ULL << 20, MST_TW = 1ULL << 21, MST_TSR = 1ULL << 22, MST_SD = 1ULL << 63;
 static constexpr int MST_VS_SH = 9, MST_MPP_SH = 11, MST_FS_SH = 13, MST_XS_SH = 15;
 static constexpr u64 MSTATUS_WMASK = 0x7FFFAAULL;             // CsRegs.cpp:4704
 // medeleg: M ecall (11), double trap (16), reserved (17) hardwired zero (CsRegs.cpp:4726-4732); VS ecall (10) and the
@@ -351,13 +351,20 @@ struct Step {
 
 // ---------------------------------------------------------------------------------- lane context
 // MEM policy supplies: rx/wx/rf/wf (register files), cold(i) (CSR rows), ld8..ld64/st8..st64 at
-// a byte offset into this hart's RAM arena.
+// a byte offset into this hart's RAM arena, tlb(i) (word i of this hart's TLB, two words per entry).
+//
+// TLB entry (Tlb.hpp:28-46 without world id / VMID), packed:
+//   word 0: vpn[51:0] | level[53:52] | counter[55:54] | valid, global, user, r, w, x, accessed, dirty [63:56]
+//   word 1: ppn[43:0] | asid[59:44]
+enum : u32 { TE_VALID = 1, TE_GLOBAL = 2, TE_USER = 4, TE_R = 8, TE_W = 16, TE_X = 32, TE_A = 64, TE_D = 128 };
+static constexpr u64 TE_VPN_MASK = 0xfffffffffffffULL;
 template <class MEM> struct Lane {
   Hot h;
   Step s;
   MEM m;
   u64 mem_base, mem_size, tohost, text_lo, text_hi;   // tohost == ~0: none
   u32 isa, hart_id;
+  u32 tlb_n;                                           // TLB entries (power of two; 0 when the ISA has no S)
 
   WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
   WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
@@ -479,12 +486,21 @@ template <class MEM> struct Lane {
   {
     u32 cause, next;
     if (!interrupt_possible(cause, next)) return false;
-    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
-    // the interrupted instruction is read for the log only: PMA check, no PMP, no trap (Hart::readInst, Hart.cpp:2997)
+    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) > 8) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
+    // the interrupted instruction is read for the log only: translation without TLB / A-D side effects, PMA check, no PMP,
+    // no trap (Hart::readInst, Hart.cpp:2997-3037)
     u32 iw = 0;
-    if (in_mem(cur_pc, 2)) {
-      iw = m.ld16(cur_pc - mem_base);
-      if ((iw & 3) == 3 && in_mem(cur_pc + 2, 2)) iw |= (u32)m.ld16(cur_pc + 2 - mem_base) << 16;
+    {
+      const bool tr = paging_on(h.priv);
+      u64 pa = cur_pc;
+      if ((!tr || translate_noupdate(cur_pc, h.priv, 4, pa) == 0) && in_mem(pa, 2)) {
+        iw = m.ld16(pa - mem_base);
+        if ((iw & 3) == 3) {
+          u64 pa2 = pa + 2;
+          if (tr && (cur_pc >> 12) != ((cur_pc + 2) >> 12) && translate_noupdate(cur_pc + 2, h.priv, 4, pa2) != 0) iw = 0;
+          else if (in_mem(pa2, 2)) iw |= (u32)m.ld16(pa2 - mem_base) << 16;
+        }
+      }
     }
     take_interrupt(cause, next, cur_pc);
     if (!(h.flags & HF_INH_CY)) h.cycle++;                   // Hart.cpp:7255-7256
@@ -559,20 +575,169 @@ template <class MEM> struct Lane {
     }
     return dflt;
   }
-  // need: 1 load / LR, 2 store / SC / AMO (validateAmoAddr checks write permission only, amo.cpp:28-56)
-  WSP_HD bool check_access(u64 va, u32 size, u32 need, u64& tval)
+  // ---- Sv39 + TLB (virtual_memory/VirtMem.cpp, Tlb.hpp, Tlb.cpp): single stage, no Svadu (an access that would need to
+  // set A or D page-faults, VirtMem.hpp:1159), no Svpbmt / Svnapot / shadow stack.  The reference's PTE cache is coherent
+  // with stores and flushed on sfence / satp / PMP changes, so it is not modelled.
+  WSP_HD bool paging_on(u32 pm) { return ext(ISA_S) && pm != PRV_M && (m.cold(CI_SATP) >> 60) == 8; }
+  WSP_HD static u32 pf_cause(u32 acc) { return acc == 4 ? 12u : acc == 1 ? 13u : 15u; }      // stage1PageFaultType (VirtMem.cpp:31-40)
+  WSP_HD static u32 af_cause(u32 acc) { return acc == 4 ? 1u : acc == 1 ? 5u : 7u; }         // accessFaultType (VirtMem.cpp:57-66)
+  // VirtMem::pageTableWalk<Pte39, Va39> (VirtMem.cpp:694-892) behind the canonical-address check (:393-397).
+  // acc: 1 read 2 write 4 exec.  On success pa and the new TLB entry words.
+  WSP_HD u32 page_walk(u64 va, u32 pm, u32 acc, bool ad_check, u64& pa, u64& e0, u64& e1)
   {
-    const u32 pm = eff_priv();
-    u64 mask = size - 1;
-    if (!(va & mask)) { if (!(pmp_perm(pm, va) & need) || !in_mem(va, size)) { tval = va; return false; } return true; }
-    u64 va2 = (va + size - 1) & ~mask;
-    if (!(pmp_perm(pm, va) & need) || !in_mem(va, va2 - va)) { tval = va; return false; }
-    if (!(pmp_perm(pm, va2) & need) || !in_mem(va2, size)) { tval = va2; return false; }
+    const u32 pf = pf_cause(acc);
+    if ((u64)(((i64)va << 25) >> 25) != va) return pf;
+    const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
+    const u64 satp = m.cold(CI_SATP);
+    u64 root = (satp & 0xfffffffffffULL) << 12, pte = 0;
+    int ii = 2; u32 global = 0;
+    for (;;) {
+      const u64 pte_addr = root + ((va >> (12 + 9 * ii)) & 0x1ff) * 8;
+      // isAddrReadable: PMP as Supervisor (Hart.cpp:424-441); memRead: PMA read (Hart.cpp:337-339)
+      if (!(pmp_perm(PRV_S, pte_addr) & 1) || !in_mem(pte_addr, 8)) return af_cause(acc);
+      pte = m.ld64(pte_addr - mem_base);
+      if (pte >> 63) return pf;                                                   // N without Svnapot (VirtMem.hpp:1090)
+      if (!(pte & 1) || (!(pte & 2) && (pte & 4)) || ((pte >> 54) & 0x7f)) return pf;   // isValidPte (VirtMem.hpp:558)
+      global |= (u32)(pte >> 5) & 1;
+      if (!(pte & 0xe)) {                                                         // next level (:747-756)
+        if ((pte & 0xd0) || ((pte >> 61) & 3)) return pf;
+        if (--ii < 0) return pf;
+        root = ((pte >> 10) & 0xfffffffffffULL) << 12;
+        continue;
+      }
+      if ((pte >> 61) & 3) return pf;                                             // Svpbmt off (:772-773)
+      const bool u = (pte >> 4) & 1, r = (pte >> 1) & 1, w = (pte >> 2) & 1, x = (pte >> 3) & 1;
+      if (pm == PRV_U && !u) return pf;
+      if (pm == PRV_S && u && (!sum || acc == 4)) return pf;
+      if ((acc == 1 && !(r || (mxr && x))) || (acc == 2 && !w) || (acc == 4 && !x)) return pf;
+      for (int j = 0; j < ii; ++j) if ((pte >> (10 + 9 * j)) & 0x1ff) return pf;  // misaligned superpage (:804-806)
+      if (ad_check && (!((pte >> 6) & 1) || (acc == 2 && !((pte >> 7) & 1)))) return pf;   // faultOnFirstAccess_ (:809-814)
+      break;
+    }
+    u64 a = va & 0xfff;                                                           // computePhysAddr (VirtMem.cpp:665-689)
+    for (int j = 0; j < ii; ++j) a |= ((va >> (12 + 9 * j)) & 0x1ff) << (12 + 9 * j);
+    for (int j = ii; j < 3; ++j) a |= ((pte >> (10 + 9 * j)) & (j == 2 ? 0x3ffffffULL : 0x1ffULL)) << (12 + 9 * j);
+    pa = a;
+    const u64 fl = TE_VALID | (global ? TE_GLOBAL : 0) | ((pte & 16) ? TE_USER : 0) | ((pte & 2) ? TE_R : 0) | ((pte & 4) ? TE_W : 0) |
+                   ((pte & 8) ? TE_X : 0) | ((pte & 64) ? TE_A : 0) | ((pte & 128) ? TE_D : 0);
+    e0 = (va >> 12) | ((u64)(1 + ii) << 52) | (fl << 56);
+    e1 = (a >> 12) | (((satp >> 44) & 0xffff) << 44);
+    return 0;
+  }
+  // Tlb::findEntry (Tlb.hpp:63-71) on the packed words
+  WSP_HD static bool tlb_match(u64 e0, u64 e1, u64 vpn, u64 satp)
+  { return ((e0 >> 56) & TE_VALID) && (e0 & TE_VPN_MASK) == vpn && (((e0 >> 56) & TE_GLOBAL) || ((e1 >> 44) & 0xffff) == ((satp >> 44) & 0xffff)); }
+  // permission part of a TLB hit (VirtMem.cpp:283-310)
+  WSP_HD bool tlb_hit_ok(u32 fl, u32 pm, u32 acc) const
+  {
+    const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
+    if (pm == PRV_U && !(fl & TE_USER)) return false;
+    if (pm == PRV_S && (fl & TE_USER) && (acc == 4 || !sum)) return false;
+    if ((acc == 1 && !((fl & TE_R) || (mxr && (fl & TE_X)))) || (acc == 2 && !(fl & TE_W)) || (acc == 4 && !(fl & TE_X))) return false;
     return true;
   }
+  // VirtMem::translate (VirtMem.cpp:261-329): 0 or the exception cause
+  WSP_HD u32 translate(u64 va, u32 pm, u32 acc, u64& pa)
+  {
+    pa = va;
+    const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
+    const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
+    u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
+    if (tlb_match(e0, e1, vpn, satp)) {
+      e0 = (e0 & ~(3ULL << 54)) | ((((e0 >> 54) + 1) & 3) << 54);                 // findEntryUpdateTime (Tlb.hpp:91-100)
+      const u32 fl = (u32)(e0 >> 56);
+      if (!tlb_hit_ok(fl, pm, acc)) { m.tlb(ix) = e0; return pf_cause(acc); }
+      if ((fl & TE_A) && (acc != 2 || (fl & TE_D))) { m.tlb(ix) = e0; pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff); return 0; }
+      e0 &= ~((u64)TE_VALID << 56);                                               // :311-312 forget the entry, walk again
+      m.tlb(ix) = e0;
+    }
+    u64 n0, n1;
+    const u32 cause = page_walk(va, pm, acc, true, pa, n0, n1);
+    if (cause) { pa = va; return cause; }
+    if (((e0 >> 56) & TE_VALID) && ((e0 >> 54) & 2)) m.tlb(ix) = e0 - (1ULL << 54);   // Tlb::insertEntry (Tlb.cpp:74-92): busy slot, age it
+    else { m.tlb(ix) = n0; m.tlb(ix + 1) = n1; }
+    return 0;
+  }
+  // VirtMem::transAddrNoUpdate (VirtMem.cpp:143-205)
+  WSP_HD u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa)
+  {
+    pa = va;
+    const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
+    const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
+    const u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
+    if (tlb_match(e0, e1, vpn, satp)) {
+      if (!tlb_hit_ok((u32)(e0 >> 56), pm, acc)) return pf_cause(acc);
+      pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff);
+      return 0;
+    }
+    u64 n0, n1;
+    const u32 cause = page_walk(va, pm, acc, false, pa, n0, n1);
+    if (cause) pa = va;
+    return cause;
+  }
+  // Tlb::setMode on a satp.MODE change (Tlb.hpp:378-383) / Tlb::invalidate: valid and counter cleared, the rest kept
+  WSP_HD void tlb_invalidate_all() { for (u32 i = 0; i < tlb_n; ++i) m.tlb(2 * i) &= ~((3ULL << 54) | ((u64)TE_VALID << 56)); }
+  // execSfence_vma's TLB part (Hart.cpp:12139-12173; Tlb.hpp:176-284): entries are matched whether or not they are valid
+  WSP_HD void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v)
+  {
+    const u64 KEEP = ~((3ULL << 54) | ((u64)TE_VALID << 56));
+    const u64 asid = asid_v & 0xffffffffULL, vpn = addr >> 12;
+    const bool sv39 = (m.cold(CI_SATP) >> 60) == 8;                                // Tlb::mode_: sizeIn4kBytes(Bare) = 0
+    if (!has_addr) {
+      for (u32 i = 0; i < tlb_n; ++i) {
+        const u64 e0 = m.tlb(2 * i);
+        if (!has_asid || (!((e0 >> 56) & TE_GLOBAL) && ((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid)) m.tlb(2 * i) = e0 & KEEP;
+      }
+      return;
+    }
+    u64 max_size = 0, vpn_of_max = 0;
+    for (u32 i = 0; i < tlb_n; ++i) {
+      const u64 e0 = m.tlb(2 * i), evpn = e0 & TE_VPN_MASK; const u32 level = (u32)(e0 >> 52) & 3;
+      const u64 size = !sv39 ? 0 : level <= 1 ? 1 : level == 2 ? 512 : 262144;
+      const u64 pn = (!sv39 || level <= 1) ? evpn : level == 2 ? (evpn >> 9) << 9 : (evpn >> 18) << 18;
+      if (pn <= vpn && vpn < pn + size && (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL)))) {
+        if (size > max_size) { max_size = size; vpn_of_max = evpn; }
+        m.tlb(2 * i) = e0 & KEEP;
+      }
+    }
+    if (max_size > 1 && vpn_of_max <= vpn && vpn < vpn_of_max + max_size)          // "subpages covered by super-page"
+      for (u32 i = 0; i < tlb_n; ++i) {
+        const u64 e0 = m.tlb(2 * i);
+        if (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL))) m.tlb(2 * i) = e0 & KEEP;
+      }
+  }
+
+  // determineLoadException / determineStoreException (Hart.cpp:1988-2154, 13786-13935).  need: 1 load / LR, 2 store / SC / AMO
+  // (validateAmoAddr checks write permission only, amo.cpp:28-56).  0 and the physical addresses of the (up to two) parts,
+  // or the exception cause with tval.
+  WSP_HD u32 ldst_addr(u64 va, u32 size, u32 need, u64& pa1, u64& pa2, u64& tval)
+  {
+    const u32 pm = eff_priv(), af = need == 1 ? 5u : 7u;
+    const bool tr = paging_on(pm);
+    const u64 mask = size - 1;
+    const bool misal = (va & mask) != 0;
+    u32 c;
+    pa1 = va;
+    if (tr && (c = translate(va, pm, need, pa1)) != 0) { tval = va; return c; }
+    if (!misal) {
+      if (!(pmp_perm(pm, pa1) & need) || !in_mem(pa1, size)) { tval = va; return af; }
+      pa2 = pa1;
+      return 0;
+    }
+    const u64 va2 = (va + size - 1) & ~mask;
+    const bool cross = (va >> 12) != (va2 >> 12);
+    pa2 = (pa1 + size - 1) & ~mask;
+    if (cross && tr && (c = translate(va2, pm, need, pa2)) != 0) { tval = va2; return c; }
+    const u64 n1 = ((pa1 + size - 1) & ~mask) - pa1;                               // lower part stops at the alignment boundary (:2068-2069)
+    if (!(pmp_perm(pm, pa1) & need) || !in_mem(pa1, n1)) { tval = va; return af; }
+    if (!(pmp_perm(pm, pa2) & need) || !in_mem(pa2, size)) { tval = va2; return af; }
+    if (!cross) pa2 = pa1;
+    return 0;
+  }
+  // satp.MODE Sv48 / Sv57 can only get in through a host poke
   WSP_HD bool paging_unsupported()
   {
-    if (ext(ISA_S) && eff_priv() != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
+    if (ext(ISA_S) && eff_priv() != PRV_M && (m.cold(CI_SATP) >> 60) > 8) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return true; }
     return false;
   }
 
@@ -593,34 +758,54 @@ template <class MEM> struct Lane {
     }
     for (u32 i = 0; i < size; ++i) m.st8(off + i, (u8)(v >> (8 * i)));
   }
+  // Hart::memRead / memWrite over an item that may span two physical pages (Hart.hpp:3469-3567)
+  WSP_HD u64 mem_read2(u64 pa1, u64 pa2, u32 size)
+  {
+    if (pa1 == pa2) return mem_read(pa1 - mem_base, size);
+    const u32 size1 = size - (u32)(pa1 & (size - 1));
+    u64 v = 0;
+    for (u32 i = 0; i < size; ++i) v |= (u64)m.ld8((i < size1 ? pa1 + i : pa2 + (i - size1)) - mem_base) << (8 * i);
+    return v;
+  }
+  WSP_HD void mem_write2(u64 pa1, u64 pa2, u32 size, u64 v)
+  {
+    if (pa1 == pa2) { mem_write(pa1 - mem_base, size, v); return; }
+    const u32 size1 = size - (u32)(pa1 & (size - 1));
+    for (u32 i = 0; i < size; ++i) m.st8((i < size1 ? pa1 + i : pa2 + (i - size1)) - mem_base, (u8)(v >> (8 * i)));
+  }
 
   // Hart::load + readForLoad (Hart.cpp:2302, 2477)
   WSP_HD bool do_load(u64 va, u32 size, u64 cur_pc, u64& out)
   {
-    u64 tval;
+    u64 tval, pa1, pa2;
     if (paging_unsupported()) return false;
-    if (!check_access(va, size, 1, tval)) { take_exception(5, cur_pc, tval, false); return false; }
-    if (va == tohost) { out = 0; return true; }                           // Hart.cpp:2509-2513
-    out = mem_read(va - mem_base, size);
+    const u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
+    if (c) { take_exception(c, cur_pc, tval, false); return false; }
+    if (pa1 == tohost) { out = 0; return true; }                           // Hart.cpp:2509-2513
+    out = mem_read2(pa1, pa2, size);
     return true;
   }
   // Hart::store + writeForStore + handleStoreToHost (Hart.cpp:2674, 2727, 2615)
   WSP_HD bool do_store(u64 va, u32 size, u64 val, u64 cur_pc)
   {
-    u64 tval;
+    u64 tval, pa1, pa2;
     if (paging_unsupported()) return false;
-    if (!check_access(va, size, 2, tval)) { take_exception(7, cur_pc, tval, false); return false; }
+    const u32 c = ldst_addr(va, size, 2, pa1, pa2, tval);
+    if (c) { take_exception(c, cur_pc, tval, false); return false; }
     u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
-    s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
-    mem_write(va - mem_base, size, sv);
-    if (va + size > text_lo && va < text_hi) h.flags |= HF_CODE_DIRTY;    // invalidateDecodeCache (Hart.cpp:7375)
-    if (tohost != ~0ULL && (va == tohost || va == tohost + 4)) {
+    s.chg |= CH_MEM; s.maddr = va; s.mval = sv;                            // the log's m line carries the virtual address (printTrace.cpp:457)
+    if (pa1 + size > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;    // invalidateDecodeCache (Hart.cpp:7375, 2751-2753)
+    if (pa2 != pa1 && pa2 + size > text_lo && pa2 < text_hi) h.flags |= HF_CODE_DIRTY;
+    if (tohost != ~0ULL && (pa1 == tohost || pa1 == tohost + 4)) {
+      mem_write(pa1 - mem_base, size, sv);
       u64 v = sv;
-      if (size == 4) { if (va == tohost + 4) { h.htif_dev = (u32)sv; return true; } v |= (u64)h.htif_dev << 32; }
+      if (size == 4) { if (pa1 == tohost + 4) { h.htif_dev = (u32)sv; return true; } v |= (u64)h.htif_dev << 32; }
       else if (size == 8) h.htif_dev = 0;
       u32 cmd = (v >> 48) & 0xff, dev = (v >> 56) & 0xff;
       if (dev == 0 && cmd == 0 && (sv & 1)) stop(ST_STOP_TOHOST, v);
+      return true;
     }
+    mem_write2(pa1, pa2, size, sv);
     return true;
   }
 
@@ -715,7 +900,9 @@ template <class MEM> struct Lane {
       case C_SCAUSE: m.cold(CI_SCAUSE) = v; break;
       case C_MTVAL: m.cold(CI_MTVAL) = v; break;
       case C_STVAL: m.cold(CI_STVAL) = v; break;
-      case C_SATP: m.cold(CI_SATP) = v; break;
+      case C_SATP:                                         // updateAddressTranslation -> configTranslation -> Tlb::setMode (Hart.cpp:904-919, Tlb.hpp:378-383)
+        if ((m.cold(CI_SATP) >> 60) != (v >> 60)) tlb_invalidate_all();
+        m.cold(CI_SATP) = v; break;
       case C_MCYCLE: h.cycle = v; break;
       case C_MINSTRET: h.instret = v; break;
       default:
@@ -762,7 +949,7 @@ template <class MEM> struct Lane {
     if (num == C_SATP) {
       u32 mode = (u32)(next >> 60);
       if (mode != 0 && mode != 8 && mode != 9 && mode != 10) return;                      // unsupported MODE: write dropped (13284-13294)
-      if (mode != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return; }
+      if (mode > 8) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return; }                   // Sv48 / Sv57: not modelled
     }
     if (num >= 0x3B0 && num < 0x3EF && !pmpaddr_locked(num - 0x3B0)) {
       // postCsrUpdate (Hart.cpp:4672-4679) refreshes the region table only when the written entry itself is on: a pmpaddr
@@ -884,31 +1071,39 @@ template <class MEM> struct Lane {
   WSP_HD void exec_atomic(const Rec& r, u64 va, u64 b, u64 cur_pc)
   {
     u32 op = rec_op(r), rd = rec_rd(r), size = (r.w0 & F_DBL) ? 8 : 4;
-    u64 tval;
+    u64 tval, pa1 = va, pa2;
     if (paging_unsupported()) return;
     if (op == OP_LR) {                                                                     // amo.cpp:142-266
-      if ((va & (size - 1)) || !check_access(va, size, 1, tval)) { take_exception(5, cur_pc, va, false); return; }
-      u64 v = mem_read(va - mem_base, size);
+      // determineLoadException first (a translation fault wins), then alignment; the trap value is the LR's own address
+      u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
+      if (c == 0 && (va & (size - 1))) c = 5;
+      if (c) { take_exception(c, cur_pc, va, false); return; }
+      u64 v = mem_read(pa1 - mem_base, size);
       if (size == 4) v = (u64)(i64)(i32)v;
       wx(rd, v);
-      h.flags |= HF_LR_VALID; h.lr_addr = va & ~7ULL;                                      // lrResSize_ = 8 (Hart.hpp:6733)
+      h.flags |= HF_LR_VALID; h.lr_addr = pa1 & ~7ULL;                                     // lrResSize_ = 8 (Hart.hpp:6733); physical (amo.cpp:254)
       return;
     }
     if (op == OP_SC) {                                                                     // amo.cpp:273-420
-      bool exc = (va & (size - 1)) || !check_access(va, size, 2, tval);
-      bool had = (h.flags & HF_LR_VALID) && h.lr_addr <= va && va + size <= h.lr_addr + 8;
+      u32 c = 0;
+      if (va & (size - 1)) c = 7;                                                          // misalHasPriority_: before any translation (amo.cpp:304-309)
+      else c = ldst_addr(va, size, 2, pa1, pa2, tval);
+      bool had = (h.flags & HF_LR_VALID) && h.lr_addr <= pa1 && pa1 + size <= h.lr_addr + 8;
       h.flags &= ~HF_LR_VALID;                                                             // cancelLr(SC): amo.cpp:403-405
-      if (exc) { take_exception(7, cur_pc, va, false); return; }
+      if (c) { take_exception(c, cur_pc, va, false); return; }
       if (!had) { wx(rd, 1); return; }
       u64 sv = size == 8 ? b : (b & 0xffffffffULL);
       s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
-      mem_write(va - mem_base, size, sv);
-      if (va + size > text_lo && va < text_hi) h.flags |= HF_CODE_DIRTY;
+      mem_write(pa1 - mem_base, size, sv);
+      if (pa1 + size > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;
       wx(rd, 0);
       return;
     }
-    if ((va & (size - 1)) || !check_access(va, size, 2, tval)) { take_exception(7, cur_pc, va, false); return; }   // amo.cpp:28-56
-    u64 ld = mem_read(va - mem_base, size), res;
+    {                                                                                      // validateAmoAddr (amo.cpp:28-56): misaligned first
+      u32 c = (va & (size - 1)) ? 7u : ldst_addr(va, size, 2, pa1, pa2, tval);
+      if (c) { take_exception(c, cur_pc, va, false); return; }
+    }
+    u64 ld = mem_read(pa1 - mem_base, size), res;
     if (size == 4) ld = (u64)(i64)(i32)ld;
     switch ((u32)r.imm) {
       case 0: res = b + ld; break; case 1: res = b; break; case 4: res = b ^ ld; break; case 8: res = b | ld; break; case 12: res = b & ld; break;
@@ -1110,7 +1305,8 @@ template <class MEM> struct Lane {
         if ((h.priv == PRV_U && ext(ISA_S)) || (h.priv != PRV_M && (h.mstatus & MST_TW))) illegal(r, cur_pc);
         break;
       case OP_SFENCE_VMA:                                                                    // Hart.cpp:12108
-        if (h.priv == PRV_U || (h.priv == PRV_S && (h.mstatus & MST_TVM))) illegal(r, cur_pc);
+        if (h.priv == PRV_U || (h.priv == PRV_S && (h.mstatus & MST_TVM))) { illegal(r, cur_pc); break; }
+        sfence(rec_rs1(r) != 0, a, rec_rs2(r) != 0, b);                                      // by register number (Hart.cpp:12139-12173)
         break;
       case OP_CSRRW: case OP_CSRRS: case OP_CSRRC: exec_csr(r, op - OP_CSRRW, (r.w0 & F_IMM) ? (u64)rec_rs1(r) : a, cur_pc); break;
       case OP_LR: case OP_SC: case OP_AMO: exec_atomic(r, a, b, cur_pc); break;
@@ -1133,23 +1329,31 @@ template <class MEM> struct Lane {
   }
 
   // ---- fetch from RAM + decode (slow path; also the only path for self-modified code)
-  // fetchInstNoTrap (Hart.cpp:3052-3206), bare translation. Returns 0 ok, 1 fault (tval), 2 stop.
-  WSP_HD int fetch_slow(u64 pc, Rec& r, u64& tval)
+  // fetchInstNoTrap (Hart.cpp:3052-3206). Returns 0 ok, 1 fault (cause, tval), 2 stop.
+  WSP_HD int fetch_slow(u64 pc, Rec& r, u64& tval, u32& cause)
   {
-    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) != 0) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return 2; }
-    if (!(pmp_perm(h.priv, pc) & 4)) { tval = pc; return 1; }                      // Hart.cpp:3079-3084
+    if (ext(ISA_S) && h.priv != PRV_M && (m.cold(CI_SATP) >> 60) > 8) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return 2; }
+    const bool tr = paging_on(h.priv);
+    u64 pa = pc; u32 c;
+    cause = 1;
+    if (tr && (c = translate(pc, h.priv, 4, pa)) != 0) { cause = c; tval = pc; return 1; }
+    if (!(pmp_perm(h.priv, pa) & 4)) { tval = pc; return 1; }                      // Hart.cpp:3079-3084
     u32 inst;
-    if (!(pc & 3)) {
-      if (!in_mem(pc, 4)) { tval = pc; return 1; }
-      inst = m.ld32(pc - mem_base);
+    if (!(pa & 3)) {
+      if (!in_mem(pa, 4)) { tval = pc; return 1; }
+      inst = m.ld32(pa - mem_base);
       if ((inst & 3) != 3) inst &= 0xffff;
     } else {
-      if (!in_mem(pc, 2)) { tval = pc; return 1; }
-      inst = m.ld16(pc - mem_base);
+      if (!in_mem(pa, 2)) { tval = pc; return 1; }
+      inst = m.ld16(pa - mem_base);
       if ((inst & 3) == 3) {
-        if (!(pmp_perm(h.priv, pc + 2) & 4)) { tval = pc + 2; return 1; }            // Hart.cpp:3158-3162
-        if (!in_mem(pc + 2, 2)) { tval = pc + 2; return 1; }
-        inst |= (u32)m.ld16(pc + 2 - mem_base) << 16;
+        // second half: starts out as the *virtual* address + 2 and is translated when its page index differs from the first
+        // half's physical page index (Hart.cpp:3144-3156)
+        u64 pa2 = pc + 2;
+        if ((pa >> 12) != (pa2 >> 12) && tr && (c = translate(pc + 2, h.priv, 4, pa2)) != 0) { cause = c; tval = pc + 2; return 1; }
+        if (!(pmp_perm(h.priv, pa2) & 4)) { tval = pc + 2; return 1; }              // Hart.cpp:3158-3162
+        if (!in_mem(pa2, 2)) { tval = pc + 2; return 1; }
+        inst |= (u32)m.ld16(pa2 - mem_base) << 16;
       }
     }
     r = decode(inst, isa);
@@ -1169,10 +1373,10 @@ template <class MEM> struct Lane {
   }
   template <bool TRACE> WSP_HD bool fetch_slow_path(Rec& rec, u64& a, u64& b, u64 cur_pc, u32 priv0)
   {
-    u64 tval = 0;
-    int fr = fetch_slow(cur_pc, rec, tval);
+    u64 tval = 0; u32 fcause = 1;
+    int fr = fetch_slow(cur_pc, rec, tval, fcause);
     if (fr == 1) {
-      take_exception(1, cur_pc, tval, true);
+      take_exception(fcause, cur_pc, tval, true);
       if (h.status != ST_RUNNING) {                 // consecutive-illegal stop inside the fetch fault
         h.retired++; if (!(h.flags & HF_INH_IR)) h.instret++;
         commit<TRACE>(cur_pc, 0, 2, priv0, 0);

@@ -28,9 +28,10 @@ enum { H32_FCSR, H32_PRIV, H32_STATUS, H32_CONSEC_ILL, H32_HTIF_DEV, H32_FLAGS, 
 struct ProgDev { u64 text_lo, text_hi; const Rec* recs; };
 
 struct DevState {
-  u32 n_harts, n_waves, lpw, lpw_shift, S, isa, hart_id_base, pad;
+  u32 n_harts, n_waves, lpw, lpw_shift, S, isa, hart_id_base, tlb_n;
   u64 mem_base, mem_size;
   u64* x; u64* f; u64* hot64; u32* hot32; u64* cold;
+  u64* tlb;            // [n_harts][tlb_n][2] packed TLB entries (wsp_core.h); null when the ISA has no S
   u64* tohost; u64* max_exec; u32* prog;
   u8* arena;
   const ProgDev* progs;
@@ -50,12 +51,13 @@ __host__ __device__ static inline size_t arena_off(const DevState& d, u32 hart, 
 // (pre-decoded operand offsets, Rec.pad).  The f block uses slots 0..31.
 #define WSP_XSLOTS 33
 struct DevMem {
-  u64* xs; u64* fs; u64* cold_; u8* arena; u32 S, lpw_shift;
+  u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* arena; u32 S, lpw_shift;
   __device__ __forceinline__ u64 rx(u32 r) const { return xs[r ? r : 32]; }
   __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r] = v; }
   __device__ __forceinline__ u64 rf(u32 r) const { return fs[r]; }
   __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r] = v; }
   __device__ __forceinline__ u64& cold(u32 i) { return cold_[(size_t)i * S]; }
+  __device__ __forceinline__ u64& tlb(u32 i) { return tlb_[i]; }
   __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
   __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
   __device__ __forceinline__ u16 ld16(u64 o) const { return *(const u16*)p(o); }
@@ -86,6 +88,7 @@ __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& 
   L.m.xs = wsp_lds + ln * WSP_XSLOTS;
   L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot;
+  L.m.tlb_ = d.tlb + (size_t)(wave * d.lpw + ln) * 2 * d.tlb_n; L.tlb_n = d.tlb_n;
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
   L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + wave * d.lpw + ln;
@@ -154,7 +157,7 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
 {
   Lane<DevMem> L;
   L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = nullptr; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
@@ -725,6 +728,11 @@ __global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* o
   s = fold(s, d.hot64[H64_INSTRET * S + slot]);
   s = fold(s, d.hot64[H64_EXEC * S + slot]);          // time CSR == loop iterations (Hart.hpp:3101)
   for (u32 i = 0; i < 72; ++i) s = fold(s, d.cold[(size_t)(CI_PMPCFG0 + i) * S + slot]);   // pmpcfg0,2,..14 then pmpaddr0..63
+  if (d.isa & ISA_S) {                                  // TLB contents are architecturally visible (stale entries): part of the state
+    const u64* t = d.tlb + (size_t)hart * 2 * d.tlb_n; u64 th = 0;
+    for (u32 i = 0; i < 2 * d.tlb_n; ++i) th = fold(th, t[i]);
+    s = fold(s, th);
+  }
   wsp_result r;
   r.status = d.hot32[H32_STATUS * S + slot]; r.priv = d.hot32[H32_PRIV * S + slot];
   r.stop_value = d.hot64[H64_STOP_VALUE * S + slot]; r.pc = d.hot64[H64_PC * S + slot];
@@ -794,16 +802,17 @@ struct wsp_batch {
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
   double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
   bool has_fp = false;
-  void* snap[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* snap[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct SnapPart { void* live; size_t bytes; };
-static void snap_parts(wsp_batch* b, SnapPart out[9])
+static void snap_parts(wsp_batch* b, SnapPart out[10])
 {
   DevState& d = b->d; size_t S = d.S;
   out[0] = { d.x, 32 * S * 8 }; out[1] = { d.f, 32 * S * 8 }; out[2] = { d.hot64, H64_COUNT * S * 8 }; out[3] = { d.hot32, H32_COUNT * S * 4 };
   out[4] = { d.cold, CI_COUNT * S * 8 }; out[5] = { d.tohost, S * 8 }; out[6] = { d.max_exec, S * 8 }; out[7] = { d.prog, S * 4 };
   out[8] = { d.arena, (size_t)d.n_waves * d.lpw * d.mem_size };
+  out[9] = { d.tlb, (size_t)d.n_harts * 2 * d.tlb_n * 8 };
 }
 
 static int upload_progs(wsp_batch* b)
@@ -825,7 +834,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
   if (!b) return;
   hipSetDevice(b->device);
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
-  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -866,16 +875,18 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   d.n_harts = desc->n_harts; d.lpw = lpw; d.lpw_shift = (u32)__builtin_ctz(lpw);
   d.n_waves = (desc->n_harts + lpw - 1) / lpw; d.S = d.n_waves * 64; d.isa = isa; d.hart_id_base = desc->hart_id_base;
   d.mem_base = desc->mem_base; d.mem_size = desc->mem_size;
+  d.tlb_n = (isa & ISA_S) ? (desc->tlb_entries ? desc->tlb_entries : 2048u) : 0u;        // Hart.cpp:106
+  if (d.tlb_n & (d.tlb_n - 1)) { delete b; return fail(WSP_EINVAL, "tlb_entries must be a power of two"); }   // Tlb.cpp:11
   b->has_fp = (isa & ISA_F) != 0;
-  size_t S = d.S, arena_bytes = (size_t)d.n_waves * lpw * d.mem_size;
+  size_t S = d.S, arena_bytes = (size_t)d.n_waves * lpw * d.mem_size, tlb_bytes = (size_t)d.n_harts * 2 * d.tlb_n * 8;
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  if (arena_bytes + S * 1024 > free_b) { delete b; return fail(WSP_ENOMEM, "batch does not fit device memory"); }
+  if (arena_bytes + tlb_bytes + S * 1024 > free_b) { delete b; return fail(WSP_ENOMEM, "batch does not fit device memory"); }
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m_ = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); wsp_batch_destroy(b); return fail(WSP_ENOMEM, m_); } \
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
   ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
   ALLOC(d.cold, (CI_COUNT + 1) * S * 8);   /* + one row: per-slot store sink of the hot loop */ ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
-  ALLOC(d.arena, arena_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
+  ALLOC(d.arena, arena_bytes); if (tlb_bytes) ALLOC(d.tlb, tlb_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
 #undef ALLOC
   // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
   std::vector<u64> v64(S);
@@ -1188,6 +1199,15 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
             v &= 0x003fffffffffffffULL;
           }
         }
+        if (n == C_SATP && d.tlb_n) {   // a MODE change empties the TLB (Tlb::setMode, Tlb.hpp:378-383): valid and counter cleared, the rest kept
+          u64 old = 0; HIPOK(hipMemcpy(&old, d.cold + ix * S + s, 8, hipMemcpyDeviceToHost));
+          if ((old >> 60) != (v >> 60)) {
+            std::vector<u64> t(2 * (size_t)d.tlb_n); u64* dt = d.tlb + (size_t)hart * 2 * d.tlb_n;
+            HIPOK(hipMemcpy(t.data(), dt, t.size() * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < t.size(); i += 2) t[i] &= ~((3ULL << 54) | ((u64)TE_VALID << 56));
+            HIPOK(hipMemcpy(dt, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+          }
+        }
         HIPOK(hipMemcpy(d.cold + ix * S + s, &v, 8, hipMemcpyHostToDevice));
         if (n == C_MCOUNTINHIBIT) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + H32_FLAGS * S + s, 4, hipMemcpyDeviceToHost)); f = (f & ~(HF_INH_CY | HF_INH_IR)) | ((v & 1) ? (u32)HF_INH_CY : 0) | ((v & 4) ? (u32)HF_INH_IR : 0); HIPOK(hipMemcpy(d.hot32 + H32_FLAGS * S + s, &f, 4, hipMemcpyHostToDevice)); }
       } else return fail(WSP_EUNSUPPORTED, "CSR not modelled");
@@ -1299,8 +1319,9 @@ extern "C" int wsp_batch_snapshot(wsp_batch* b)
 {
   if (!b) return fail(WSP_EINVAL, "null batch");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[9]; snap_parts(b, parts);
-  for (int i = 0; i < 9; ++i) {
+  SnapPart parts[10]; snap_parts(b, parts);
+  for (int i = 0; i < 10; ++i) {
+    if (!parts[i].bytes) continue;
     if (!b->snap[i]) { if (hipMalloc(&b->snap[i], parts[i].bytes) != hipSuccess) return fail(WSP_ENOMEM, "snapshot allocation failed"); }
     HIPOK(hipMemcpyAsync(b->snap[i], parts[i].live, parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   }
@@ -1313,8 +1334,8 @@ extern "C" int wsp_batch_restore(wsp_batch* b)
   if (!b) return fail(WSP_EINVAL, "null batch");
   if (!b->snap[0]) return fail(WSP_EINVAL, "no snapshot taken");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[9]; snap_parts(b, parts);
-  for (int i = 0; i < 9; ++i) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
+  SnapPart parts[10]; snap_parts(b, parts);
+  for (int i = 0; i < 10; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   HIPOK(hipStreamSynchronize(b->stream));
   return WSP_OK;
 }

@@ -791,3 +791,219 @@ def pmp_program(seed: int, n: int = 300) -> Program:
     a.label("hang"); a.j("hang")
     assert a.here() < BASE + 0x4000, "text outgrew its PMP region"
     return _finish(a, f"pmp-{seed}", "rv64imafdcsu_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed))
+
+
+# ------------------------------------------------------------------------------------------ Sv39 paging
+_PTE_V, _PTE_R, _PTE_W, _PTE_X, _PTE_U, _PTE_G, _PTE_A, _PTE_D = 1, 2, 4, 8, 16, 32, 64, 128
+
+
+def sv39_program(seed: int, n: int = 300) -> Program:
+    """Sv39 paging: M mode opens PMP, builds a three-level page table (4 KiB pages with mixed
+    R/W/X/U/A/D bits, a 2 MiB window over the whole arena, a misaligned superpage, malformed PTEs), and drops to S (odd
+    seeds) or U (even seeds) at a virtual address that is not the physical one.  The body mixes loads, stores, AMOs, LR/SC
+    and FP accesses (aligned and not, also across page boundaries with different permissions), jumps into mapped,
+    unmapped and non-executable pages, 4-byte instructions that straddle a page boundary, page-table edits through the
+    window *without* sfence.vma (stale TLB entries are architecturally visible in the reference), the sfence.vma forms,
+    sstatus.SUM / MXR toggles and satp rewrites (new ASID).  `ecall` services run in M mode: MPRV loads and stores (translated
+    with the caller's privilege) and satp switches.  Every trap goes to one M handler that steps over the faulting
+    instruction (fetch faults resume at ra).  Run with a small `tlb_entries` so the replacement policy matters."""
+    rng = random.Random(0x5339 ^ seed)
+    smode = bool(seed & 1)
+    MEM = 1 << 18
+    TOHOST = BASE + 0x4000
+    PT_ROOT, PT_L1, PT_L0A, PT_L0B = BASE + 0x8000, BASE + 0x9000, BASE + 0xA000, BASE + 0xB000
+    PA_CODE, VA_CODE = BASE + 0x10000, 0x10000            # body code: 4 pages
+    PA_DATA, VA_DATA = BASE + 0x20000, 0x400000           # data: 16 pages (L0B)
+    VA_WIN = 0x40000000                                   # 2 MiB window onto the arena (L1[0] of root[1])
+    U = 0 if smode else _PTE_U
+    FULL = _PTE_V | _PTE_R | _PTE_W | _PTE_X | _PTE_A | _PTE_D
+
+    def pte(pa, flags, hi=0):
+        return (hi << 54) | ((pa >> 12) << 10) | flags
+
+    pt = {}
+    pt[PT_ROOT + 8 * 0] = pte(PT_L1, _PTE_V)
+    pt[PT_ROOT + 8 * 1] = pte(PT_L1 + 0x800, _PTE_V)      # second half of the L1 page serves root[1]
+    pt[PT_ROOT + 8 * 2] = pte(BASE + 0x1000, FULL | U)    # misaligned 1 GiB leaf
+    pt[PT_ROOT + 8 * 3] = pte(PT_L1, _PTE_V | _PTE_A)     # non-leaf with A set
+    pt[PT_L1 + 8 * 0] = pte(PT_L0A, _PTE_V)               # VA 0x0000_0000 .. : code pages
+    pt[PT_L1 + 8 * 2] = pte(PT_L0B, _PTE_V)               # VA 0x0040_0000 .. : data pages
+    pt[PT_L1 + 8 * 3] = pte(BASE + 0x1000, FULL | U)      # misaligned 2 MiB leaf
+    pt[PT_L1 + 8 * 4] = pte(BASE, FULL | U, hi=rng.choice([1, 0x80, 0x200]))   # reserved / PBMT / N bits
+    pt[PT_L1 + 0x800 + 8 * 0] = pte(BASE, _PTE_V | _PTE_R | _PTE_W | _PTE_A | _PTE_D | U)   # the window (2 MiB leaf)
+    for i in range(4):                                    # code pages: x, or rx; page 3 sometimes not executable
+        f = _PTE_V | _PTE_X | _PTE_A | U | rng.choice([0, _PTE_R])
+        if i == 3 and rng.random() < 0.5:
+            f = _PTE_V | _PTE_R | _PTE_A | U
+        pt[PT_L0A + 8 * (16 + i)] = pte(PA_CODE + 0x1000 * i, f)
+    data_flags = []
+    for i in range(16):
+        k = rng.random()
+        if k < 0.5:
+            f = _PTE_V | _PTE_R | _PTE_W | _PTE_A | _PTE_D | U
+        elif k < 0.8:
+            f = _PTE_V | _PTE_A | rng.choice([_PTE_R, _PTE_R | _PTE_W, _PTE_X, _PTE_R | _PTE_X]) | rng.choice([0, _PTE_D]) | rng.choice([U, U, _PTE_U ^ U]) | rng.choice([0, _PTE_G])
+        else:
+            f = rng.randrange(256)
+        data_flags.append(f)
+        pt[PT_L0B + 8 * i] = pte(PA_DATA + 0x1000 * rng.randrange(16), f)
+
+    d = Asm(TOHOST)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.org(PT_ROOT)
+    img = bytearray(0x4000)
+    for addr, v in pt.items():
+        img[addr - PT_ROOT:addr - PT_ROOT + 8] = v.to_bytes(8, "little")
+    d.data(bytes(img))
+    d.org(PA_DATA)
+    d.data(bytes(rng.getrandbits(8) for _ in range(0x10000)))
+
+    a = Asm(BASE)
+    N1, H0, H3, H1, H2 = 27, 28, 29, 30, 31     # reserved for the handler
+    MPRV, MXR = 1 << 17, 1 << 19
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    # a fault of M mode itself can only come from an MPRV access of this handler (4-byte instructions): step over it
+    a.csrr(N1, CSR["mstatus"]); a.srli(N1, N1, 11); a.andi(N1, N1, 3); a.addi(N1, N1, -3); a.bnez(N1, "from_below")
+    a.csrr(N1, CSR["mepc"]); a.addi(N1, N1, 4); a.csrw(CSR["mepc"], N1); a.mret()
+    a.label("from_below")
+    a.csrr(H0, CSR["mepc"]); a.csrr(H3, CSR["mstatus"])                  # what follows may fault and nest
+    a.csrr(H1, CSR["mcause"])
+    a.addi(H2, H1, -1); a.beqz(H2, "fetch_fault")
+    a.addi(H2, H1, -12); a.beqz(H2, "fetch_fault")
+    a.addi(H2, H1, -8); a.sltiu(H2, H2, 4); a.bnez(H2, "is_ecall")
+    # length of the faulting instruction: read it the way it was fetched (MPRV + MXR: the caller's translation)
+    a.li(H2, 0); a.li(H1, MPRV | MXR); a.csrs(CSR["mstatus"], H1); a.lhu(H2, 0, H0); a.csrc(CSR["mstatus"], H1)
+    a.andi(H2, H2, 3); a.addi(H2, H2, -3); a.bnez(H2, "len2"); a.addi(H0, H0, 2)
+    a.label("len2"); a.addi(H0, H0, 2); a.j("resume")
+    a.label("fetch_fault")
+    a.beq(H0, 1, "exit")                                                 # ra itself cannot be fetched: give up
+    a.mv(H0, 1); a.j("resume")
+    a.label("is_ecall")
+    a.beqz(17, "exit")
+    a.addi(H0, H0, 4)
+    for k, lbl in ((1, "svc_mprv_ld"), (2, "svc_mprv_st"), (3, "svc_satp"), (4, "svc_sfence")):
+        a.li(H2, k); a.beq(17, H2, lbl)
+    a.j("resume")
+    a.label("svc_mprv_ld"); a.li(H1, MPRV); a.csrs(CSR["mstatus"], H1); a.ld(H2, 0, 10); a.lbu(H2, 5, 10); a.csrc(CSR["mstatus"], H1); a.j("resume")
+    a.label("svc_mprv_st"); a.li(H1, MPRV); a.csrs(CSR["mstatus"], H1); a.sd(11, 0, 10); a.sh(11, 3, 10); a.csrc(CSR["mstatus"], H1); a.j("resume")
+    a.label("svc_satp"); a.csrrw(H2, CSR["satp"], 11); a.j("resume")
+    a.label("svc_sfence"); a.sfence_vma(10, 11)
+    a.label("resume")
+    a.csrw(CSR["mstatus"], H3); a.csrw(CSR["mepc"], H0); a.mret()
+    a.label("exit")
+    _exit_tohost(a, TOHOST, tmp1=30, tmp2=31)
+
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    a.li(5, 0x2000); a.csrs(CSR["mstatus"], 5)                           # FS on
+    a.li(5, (1 << 54) - 1); a.csrw(0x3B0, 5); a.li(5, 0x1F); a.csrw(0x3A0, 5)   # PMP: everything, for everyone
+    if seed % 8 == 7:
+        a.li(5, 0xB1FF); a.csrw(CSR["medeleg"], 5)                       # delegated faults land on stvec = 0, unmapped: the run ends in the
+                                                                         # consecutive-fault stop after exercising sepc / scause / stval
+    asid0 = rng.randrange(4)
+    a.li(5, (8 << 60) | (asid0 << 44) | (PT_ROOT >> 12)); a.csrw(CSR["satp"], 5)
+    a.csrr(6, CSR["satp"])
+    a.li(5, (5 << 60) | 1); a.csrw(CSR["satp"], 5); a.csrr(6, CSR["satp"])    # unsupported MODE: write dropped
+    for r in range(1, 27):
+        a.li(r, rng.choice([rng.getrandbits(64), rng.getrandbits(12), VA_DATA + 8 * rng.randrange(0x1000), 0]))
+    a.li(5, 3 << 11); a.csrc(CSR["mstatus"], 5)
+    if smode:
+        a.li(5, 1 << 11); a.csrs(CSR["mstatus"], 5)                      # MPP = S
+    a.li(5, VA_CODE); a.csrw(CSR["mepc"], 5); a.mret()
+    assert a.here() < BASE + 0x4000
+
+    # ---- the body, linked at its virtual address
+    b = Asm(VA_CODE)
+    P = 9
+    amo = ["amoswap", "amoadd", "amoxor", "amoand", "amoor", "amomin", "amomax", "amominu", "amomaxu"]
+    regs = [r for r in range(2, 27) if r not in (P, 10, 11, 17)]
+
+    def pick_va():
+        r = rng.random()
+        if r < 0.6:
+            return VA_DATA + rng.randrange(16) * 0x1000 + rng.choice([rng.randrange(0x1000), 0xFF8 + rng.randrange(12), rng.randrange(16)])
+        if r < 0.75:
+            return VA_WIN + rng.choice([0x20000 + rng.randrange(0x10000), 0x4000, 0x4008, MEM - 8, MEM + 8, 0xA000 + 8 * rng.randrange(16)])
+        if r < 0.85:
+            return VA_CODE + rng.randrange(0x4000)
+        return rng.choice([0x80000000 + rng.randrange(0x1000), 0xC0000000 + rng.randrange(0x1000), 0x600000 + rng.randrange(0x2000),
+                           0x800000 + rng.randrange(0x1000), (1 << 38) + 0x123, 0xFFFFFFC000000000 + rng.randrange(0x1000),
+                           rng.getrandbits(64), VA_DATA + 0x10000 + rng.randrange(0x1000), BASE + 0x100])
+
+    for i in range(n):
+        k = rng.random()
+        rd = rng.choice(regs); rs2 = rng.choice(regs)
+        if b.here() >= VA_CODE + 0x3000 - 0x80:
+            break
+        if k < 0.40:
+            m, sz = rng.choice(_LD + _ST)
+            t = pick_va()
+            if rng.random() < 0.55:
+                t -= t % sz
+            off = rng.randrange(-64, 64)
+            b.li(P, (t - off) & MASK64)
+            getattr(b, m)(rd if m.startswith("l") else rs2, off, P)
+        elif k < 0.50:
+            sfx = rng.choice(["w", "d"]); t = pick_va()
+            if rng.random() < 0.85:
+                t -= t % (4 if sfx == "w" else 8)
+            b.li(P, t & MASK64)
+            r = rng.random()
+            if r < 0.25:
+                getattr(b, f"lr_{sfx}")(rd, P)
+            elif r < 0.5:
+                getattr(b, f"lr_{sfx}")(rd, P); getattr(b, f"sc_{sfx}")(rd, rs2, P)
+            else:
+                getattr(b, f"{rng.choice(amo)}_{sfx}")(rd, rs2, P)
+        elif k < 0.56:
+            t = pick_va(); t -= t % rng.choice([1, 4, 8])
+            b.li(P, t & MASK64)
+            rng.choice([b.flw, b.fld, b.fsw, b.fsd])(rng.randrange(32), 0, P)
+        elif k < 0.64:                                                   # jumps: islands at the end of code page 2 / in page 3, data pages, unmapped
+            t = rng.choice([VA_CODE + 0x2FF0, VA_CODE + 0x2FFA, VA_CODE + 0x3000, VA_CODE + 0x3010, VA_DATA + 0x1000 * rng.randrange(16), 0x800000, 0xC0000000])
+            b.li(P, t); b.jalr(1, P, 0)
+        elif k < 0.74:                                                   # page-table edit through the window, no sfence
+            ix = rng.randrange(16)
+            f = rng.choice([data_flags[ix], FULL | U, _PTE_V | _PTE_R | _PTE_A | U, _PTE_V | _PTE_R | _PTE_W | _PTE_A | U, 0, rng.randrange(256)])
+            b.li(P, VA_WIN + (PT_L0B - BASE) + 8 * ix); b.li(rd, pte(PA_DATA + 0x1000 * rng.randrange(16), f)); b.sd(rd, 0, P)
+        elif k < 0.82:
+            r = rng.random()
+            va = pick_va() if rng.random() < 0.8 else 0
+            if r < 0.5:                                                  # sfence.vma in place (illegal from U) ...
+                b.li(10, va & MASK64); b.li(11, rng.randrange(4))
+                b.sfence_vma(rng.choice([0, 10]), rng.choice([0, 11]))
+            else:                                                        # ... or through M
+                b.li(10, va & MASK64); b.li(11, rng.randrange(4)); b.li(17, 4); b.ecall()
+        elif k < 0.88:
+            r = rng.random()
+            if r < 0.4:
+                b.li(rd, rng.choice([1 << 18, 1 << 19, 3 << 18])); rng.choice([b.csrs, b.csrc])(CSR["sstatus"], rd)
+            elif r < 0.7:                                                # satp: new ASID (direct in S, illegal in U)
+                b.li(rd, (8 << 60) | (rng.randrange(4) << 44) | (PT_ROOT >> 12)); b.csrw(CSR["satp"], rd)
+            else:
+                b.li(11, (8 << 60) | (rng.randrange(4) << 44) | (PT_ROOT >> 12)); b.li(17, 3); b.ecall()
+        elif k < 0.94:
+            t = pick_va(); t -= t % rng.choice([1, 8])
+            b.li(10, t & MASK64); b.li(11, rng.getrandbits(64)); b.li(17, rng.choice([1, 2])); b.ecall()
+        elif k < 0.96:
+            b.c_nop()                                                    # shifts the following 4-byte instructions off word alignment
+        else:
+            getattr(b, rng.choice(_RR))(rd, rng.choice(regs), rs2)
+    b.li(17, 0); b.ecall()
+    b.label("hang"); b.j("hang")
+    assert b.here() <= VA_CODE + 0x2FF0, "body outgrew its pages"
+    b.org(VA_CODE + 0x2FF0)
+    b.addi(6, 6, 1); b.addi(6, 6, 2); b.c_nop(); b.addi(6, 6, 3)
+    b.ret()                                                              # at 0x2FFE: straddles code pages 2 and 3
+    b.org(VA_CODE + 0x3010)
+    b.addi(6, 6, 4); b.ret()
+    code = b.assemble()
+    text = a.assemble()
+    segs = [(a.base, text, PF_R | PF_X), (d.base, d.assemble(), PF_R | PF_W), (PA_CODE, code, PF_R)]   # code lands inside the data image's span: last
+    syms = dict(a.symbols); syms.update(d.symbols)
+    elf = write_elf(segs, syms["_start"], syms)
+    return Program(f"sv39-{seed}", "rv64imafdcsu_zicsr", elf, syms["_start"], segs, syms, BASE, MEM, 60000, dict(seed=seed, tlb_entries=8))
