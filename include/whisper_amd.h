@@ -34,7 +34,7 @@ enum { WSP_ST_RUNNING = 0,
        WSP_ST_STOP_UNSUPPORTED = 4  /* left the modelled subset; stop_value holds the reason */ };
 
 /* Resources for peek/poke (Hart::peekIntReg/pokeIntReg ... Hart.hpp:219-325, Hart.cpp:1345-1560). */
-enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4 };
+enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4, WSP_RES_V = 5 /* whole vector register, vlen_bytes bytes */ };
 
 /* wsp_batch_run flags */
 enum { WSP_RUN_TRACE_HASH = 1 /* fold every commit record (printTrace.cpp:302-517) into trace_hash */ };
@@ -51,6 +51,8 @@ typedef struct {
   int32_t  device;          /* HIP device ordinal, -1 = current                                            */
   uint32_t hart_id_base;    /* mhartid of hart 0 (core_hart_id_offset)                                     */
   uint32_t tlb_entries;     /* TLB entries per hart, a power of two; 0 = 2048 (Hart.cpp:106; config tag tlb_entries) */
+  uint32_t vlen_bytes;      /* bytes per vector register: 16, 32 or 64; 0 = 64 (Hart.cpp:1081; config tag vector.bytes_per_vec) */
+  uint32_t reserved;
 } wsp_batch_desc;
 
 typedef struct {

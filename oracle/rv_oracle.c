@@ -83,6 +83,7 @@ enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
 /* CSR numbers */
 enum {
   C_FFLAGS = 0x001, C_FRM = 0x002, C_FCSR = 0x003,
+  C_VSTART = 0x008, C_VXSAT = 0x009, C_VXRM = 0x00A, C_VCSR = 0x00F, C_VL = 0xC20, C_VTYPE = 0xC21, C_VLENB = 0xC22,
   C_SSTATUS = 0x100, C_SIE = 0x104, C_STVEC = 0x105, C_SCOUNTEREN = 0x106, C_SENVCFG = 0x10A,
   C_SSCRATCH = 0x140, C_SEPC = 0x141, C_SCAUSE = 0x142, C_STVAL = 0x143, C_SIP = 0x144, C_SATP = 0x180,
   C_MSTATUS = 0x300, C_MISA = 0x301, C_MEDELEG = 0x302, C_MIDELEG = 0x303, C_MIE = 0x304, C_MTVEC = 0x305,
@@ -142,9 +143,13 @@ struct rvo_hart {
   int pmp_on;               /* some entry is not Off (cache over pmpcfg, kept by csr_store) */
   /* TLB (Tlb.hpp:28-46), direct mapped, tlb_n entries (Hart.cpp:106: 2048 by default) */
   struct rvo_tlbe* tlb; unsigned tlb_n;
+  /* vector unit (VecRegs.hpp): 32 registers of vlenb bytes; vtype reset = vill (CsRegs.cpp:5363) */
+  uint8_t vreg[32 * 64]; unsigned vlenb;
+  u64 vstart, vl, vtype; unsigned vxsat, vxrm;
   /* per-instruction trace capture */
   int has_exc;
   int ch_ireg; int ch_freg;
+  int ch_vreg; int ch_vgroup;       /* first register (operand 0) and register count of the vector group written */
   int ch_mem; u64 ch_mem_addr, ch_mem_val;
   unsigned ch_csr[8]; int ch_ncsr;
   u64 trace_hash;
@@ -162,6 +167,9 @@ rvo_hart* rvo_create(const rvo_config* cfg)
   /* reset mstatus: MPP=M, SXL=UXL=2 (CsRegs.cpp:4705-4710); FS/VS Off */
   h->mstatus = (3ULL << MST_MPP_SH) | (0xAULL << 32);
   h->pc = cfg->reset_pc;
+  h->vlenb = cfg->vlenb ? cfg->vlenb : 64;                                   /* Hart.cpp:1081 */
+  if (h->vlenb != 16 && h->vlenb != 32 && h->vlenb != 64) { free(h->mem); free(h); return NULL; }
+  h->vtype = 1ULL << 63;
   h->tlb_n = cfg->tlb_entries ? cfg->tlb_entries : 2048;
   if (h->tlb_n & (h->tlb_n - 1)) { free(h->mem); free(h); return NULL; }   /* Tlb.cpp:11 */
   h->tlb = (struct rvo_tlbe*)calloc(h->tlb_n, sizeof(struct rvo_tlbe));
@@ -184,6 +192,8 @@ u64  rvo_get_x(const rvo_hart* h, unsigned i) { return h->x[i & 31]; }
 void rvo_set_f(rvo_hart* h, unsigned i, u64 v) { h->f[i & 31] = v; }
 u64  rvo_get_f(const rvo_hart* h, unsigned i) { return h->f[i & 31]; }
 unsigned rvo_priv(const rvo_hart* h) { return h->priv; }
+unsigned rvo_get_vreg(const rvo_hart* h, unsigned i, void* dst) { memcpy(dst, h->vreg + (size_t)(i & 31) * h->vlenb, h->vlenb); return h->vlenb; }
+void rvo_set_vreg(rvo_hart* h, unsigned i, const void* src) { memcpy(h->vreg + (size_t)(i & 31) * h->vlenb, src, h->vlenb); }
 int  rvo_status(const rvo_hart* h) { return h->status; }
 u64  rvo_stop_value(const rvo_hart* h) { return h->stop_value; }
 u64  rvo_exec_count(const rvo_hart* h) { return h->exec_count; }
@@ -252,6 +262,7 @@ static int csr_class(const rvo_hart* h, unsigned num)
     case C_MCYCLE: case C_MINSTRET: case C_MVENDORID: case C_MARCHID: case C_MIMPID: case C_MHARTID:
     case C_MCONFIGPTR: return 1;
     case C_CYCLE: case C_TIME: case C_INSTRET: return ext(h, RVO_ISA_ZICNTR) ? 1 : 0;  /* CsRegs.cpp:2102 */
+    case C_VSTART: case C_VXSAT: case C_VXRM: case C_VCSR: case C_VL: case C_VTYPE: case C_VLENB: return ext(h, RVO_ISA_V) ? 1 : 0;   /* CsRegs::enableVector (CsRegs.cpp:2240) */
     default: break;
   }
   /* Implemented in the reference's default configuration but not modelled here. */
@@ -269,6 +280,9 @@ static u64 csr_peek(const rvo_hart* h, unsigned num)
     case C_FFLAGS: return h->fcsr & 0x1f;
     case C_FRM: return (h->fcsr >> 5) & 7;
     case C_FCSR: return h->fcsr;
+    case C_VSTART: return h->vstart; case C_VXSAT: return h->vxsat; case C_VXRM: return h->vxrm;
+    case C_VCSR: return (h->vxrm << 1) | h->vxsat;                         /* CsRegs.cpp:4556-4606 */
+    case C_VL: return h->vl; case C_VTYPE: return h->vtype; case C_VLENB: return h->vlenb;
     case C_SSTATUS: return h->mstatus & SSTATUS_RMASK;
     case C_SIE: return h->mie & h->mideleg & ~0x1444ULL;                /* CsRegs::readSie (CsRegs.cpp:195-229) */
     case C_SIP: return h->mip & h->mideleg & ~0x1444ULL;
@@ -380,6 +394,12 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
     case C_FFLAGS: h->fcsr = (h->fcsr & ~0x1fULL) | (v & 0x1f); break;         /* CsRegs.cpp:4462-4472 */
     case C_FRM:    h->fcsr = (h->fcsr & ~0xe0ULL) | ((v & 7) << 5); break;
     case C_FCSR:   h->fcsr = v & 0xff; break;
+    case C_VSTART: h->vstart = v & (h->vlenb * 8 - 1); break;                   /* mask = VLEN - 1 (Hart.cpp:1088-1103) */
+    case C_VXSAT:  h->vxsat = v & 1; break;
+    case C_VXRM:   h->vxrm = v & 3; break;
+    case C_VCSR:   h->vxsat = v & 1; h->vxrm = (v >> 1) & 3; break;
+    case C_VL:     h->vl = v; break;                                            /* poke only (write mask 0) */
+    case C_VTYPE:  h->vtype = v & 0x80000000000000ffULL; break;
     case C_MSTATUS: {                                                           /* CsRegs.cpp:3964-3976 */
       u64 nv = (h->mstatus & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK & mstatus_read_mask(h));   /* value &= writeMask & readMask */
       h->mstatus = legalize_mstatus(h, nv);
@@ -428,7 +448,7 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
 /* ------------------------------------------------------------------ trace capture */
 static void begin_inst(rvo_hart* h)
 {
-  h->has_exc = 0; h->ch_ireg = -1; h->ch_freg = -1; h->ch_mem = 0; h->ch_ncsr = 0;
+  h->has_exc = 0; h->ch_ireg = -1; h->ch_freg = -1; h->ch_mem = 0; h->ch_ncsr = 0; h->ch_vreg = -1; h->ch_vgroup = 0;
 }
 
 static inline void wx(rvo_hart* h, unsigned rd, u64 v)
@@ -455,6 +475,13 @@ static void finish_commit(rvo_hart* h, u32 inst, unsigned size, unsigned priv, i
   unsigned k = 0;
   if (h->ch_ireg > 0) { c.ch[k].kind = RVO_CH_R; c.ch[k].key = (u64)h->ch_ireg; c.ch[k].val = h->x[h->ch_ireg]; ++k; }
   if (h->ch_freg >= 0) { c.ch[k].kind = RVO_CH_F; c.ch[k].key = (u64)h->ch_freg; c.ch[k].val = h->f[h->ch_freg]; ++k; }
+  /* vector group (printTrace.cpp:424-441; Hart::lastVecReg Hart.cpp:5753): one v line per register of the group starting at
+   * operand 0; the record carries a digest of the register's bytes */
+  if (h->ch_vgroup) for (int r = 0; r < h->ch_vgroup && k < RVO_MAX_CHANGES; ++r) {
+    unsigned reg = (unsigned)(h->ch_vreg + r) & 31; u64 d = 0;
+    for (unsigned w = 0; w < h->vlenb / 8; ++w) d = rvo_fold(d, ld_le(h->vreg + (size_t)reg * h->vlenb + 8 * w, 8));
+    c.ch[k].kind = RVO_CH_V; c.ch[k].key = reg; c.ch[k].val = d; ++k;
+  }
   if (h->ch_mem) { c.ch[k].kind = RVO_CH_M; c.ch[k].key = h->ch_mem_addr; c.ch[k].val = h->ch_mem_val; ++k; }
   /* CSRs sorted by number (printTrace.cpp:479-489) */
   for (int i = 0; i < h->ch_ncsr; ++i)
@@ -944,6 +971,8 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   if (cls < 0) { stop(h, RVO_STOP_UNSUPPORTED, 0x10000 | num); return; }
   if (cls == 0) { illegal(h, inst); return; }
   if ((num == C_FFLAGS || num == C_FRM || num == C_FCSR) && !fp_legal(h)) { illegal(h, inst); return; }
+  if ((num == C_VSTART || num == C_VXSAT || num == C_VXRM || num == C_VCSR || num == C_VL || num == C_VTYPE || num == C_VLENB) &&
+      !(ext(h, RVO_ISA_V) && ((h->mstatus >> MST_VS_SH) & 3) != 0)) { illegal(h, inst); return; }      /* Hart.cpp:12952-12958 */
   if (!csr_readable(h, num) || (do_write && !csr_writeable(h, num))) { illegal(h, inst); return; }
   if (num == C_SATP && h->priv == PRV_S && (h->mstatus & MST_TVM)) { illegal(h, inst); return; }
   u64 prev = do_read ? csr_peek(h, num) : 0;
@@ -968,6 +997,8 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   }
   csr_store(h, num, next, 1);
   if ((num == C_FFLAGS || num == C_FRM || num == C_FCSR)) mark_fs_dirty(h);  /* postCsrUpdate: FS dirty on fp csr write */
+  if (num == C_VSTART || num == C_VXSAT || num == C_VXRM || num == C_VCSR)   /* postCsrUpdate: markVsDirty (Hart.cpp:4731-4734) */
+    if (((h->mstatus >> MST_VS_SH) & 3) != 3) write_mstatus_raw(h, h->mstatus | (3ULL << MST_VS_SH) | MST_SD);
 done:
   if (num == C_MINSTRET && !(h->mcountinhibit & 4)) h->instret--;
   if (num == C_MCYCLE) h->cycle--;
@@ -1071,6 +1102,8 @@ typedef __int128 i128;
 
 static void exec_fp(rvo_hart* h, u32 inst, u32 raw);
 static void exec_amo(rvo_hart* h, u32 inst, u32 raw);
+#include "rv_oracle_vec.inc"
+
 
 /* `inst` is the (possibly expanded) 32-bit encoding; `raw` the bits as fetched (mtval on illegal). */
 static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
@@ -1233,7 +1266,12 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
         exec_csr(h, raw, csrop, rd, inst >> 20, src, rs1 != 0); }
       return; }
     case 0x2f: exec_amo(h, inst, raw); return;
-    case 0x07: case 0x27: case 0x43: case 0x47: case 0x4b: case 0x4f: case 0x53: exec_fp(h, inst, raw); return;
+    case 0x07: case 0x27:
+      { unsigned w = (inst >> 12) & 7;                                      /* vector widths share the FP load/store opcodes */
+        if (w == 0 || w >= 5) { h->ch_vreg = (int)((inst >> 7) & 31); exec_vector_ldst(h, inst, raw, op == 0x27); if (op == 0x27) h->ch_vgroup = 0; return; } }
+      exec_fp(h, inst, raw); return;
+    case 0x43: case 0x47: case 0x4b: case 0x4f: case 0x53: exec_fp(h, inst, raw); return;
+    case 0x57: h->ch_vreg = (int)((inst >> 7) & 31); exec_vector(h, inst, raw); return;
     default: break;
   }
 ill:
@@ -1590,6 +1628,10 @@ u64 rvo_state_hash(const rvo_hart* h)
   for (int i = 0; i < 8; ++i) s = rvo_fold(s, h->pmpcfg[i]);
   for (int i = 0; i < 64; ++i) s = rvo_fold(s, h->pmpaddr[i]);
   if (ext(h, RVO_ISA_S)) s = rvo_fold(s, rvo_tlb_hash(h));
+  if (ext(h, RVO_ISA_V)) {
+    s = rvo_fold(s, h->vstart); s = rvo_fold(s, (h->vxrm << 1) | h->vxsat); s = rvo_fold(s, h->vl); s = rvo_fold(s, h->vtype);
+    for (unsigned w = 0; w < 32 * h->vlenb / 8; ++w) s = rvo_fold(s, ld_le(h->vreg + 8 * w, 8));
+  }
   return s;
 }
 

@@ -47,7 +47,7 @@ typedef struct {
   uint64_t val;
 } rvo_change;
 
-#define RVO_MAX_CHANGES 12
+#define RVO_MAX_CHANGES 16
 typedef struct {
   uint64_t tag;        /* execCount_ */
   uint64_t pc;         /* currPc_ */
@@ -69,7 +69,7 @@ typedef struct {
   uint32_t hart_id;
   uint64_t reset_pc;
   uint32_t tlb_entries; /* TLB size, a power of two; 0 = the reference default 2048 (Hart.cpp:106) */
-  uint32_t pad;
+  uint32_t vlenb;       /* bytes per vector register: 16, 32 or 64; 0 = the reference default 64 (Hart.cpp:1081) */
 } rvo_config;
 
 typedef struct rvo_hart rvo_hart;
@@ -92,6 +92,9 @@ uint64_t  rvo_get_f(const rvo_hart* h, unsigned i);
 int       rvo_peek_csr(const rvo_hart* h, unsigned num, uint64_t* v);
 int       rvo_poke_csr(rvo_hart* h, unsigned num, uint64_t v);
 unsigned  rvo_priv(const rvo_hart* h);
+/* vector register i (vlenb bytes, element 0 first); returns vlenb */
+unsigned  rvo_get_vreg(const rvo_hart* h, unsigned i, void* dst);
+void      rvo_set_vreg(rvo_hart* h, unsigned i, const void* src);
 
 /* Run until a stop condition or until `max_exec` instructions have been executed in total
  * (Hart::setInstructionCountLimit semantics: counts trapped instructions too).  If `log` is

@@ -17,7 +17,7 @@ ISA_BITS = dict(m=1, a=2, f=4, d=8, c=16, s=32, u=64, v=128, zicntr=256)
 
 RUNNING, STOP_TOHOST, STOP_ILLEGAL, STOP_LIMIT, STOP_UNSUPPORTED = range(5)
 CH_R, CH_F, CH_V, CH_M, CH_C = 1, 2, 3, 4, 5
-MAX_CHANGES = 12
+MAX_CHANGES = 16
 
 
 def isa_flags(isa: str) -> int:
@@ -53,7 +53,7 @@ class Commit(C.Structure):
 class Config(C.Structure):
     _fields_ = [("xlen", C.c_uint32), ("isa", C.c_uint32), ("mem_base", C.c_uint64), ("mem_size", C.c_uint64),
                 ("tohost", C.c_uint64), ("tohost_valid", C.c_uint32), ("hart_id", C.c_uint32), ("reset_pc", C.c_uint64),
-                ("tlb_entries", C.c_uint32), ("pad", C.c_uint32)]
+                ("tlb_entries", C.c_uint32), ("vlenb", C.c_uint32)]
 
 
 _lib = None
@@ -115,10 +115,10 @@ def has_softfloat() -> bool:
 
 class Hart:
     def __init__(self, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, tohost=None,
-                 hart_id=0, reset_pc=None, tlb_entries=0):
+                 hart_id=0, reset_pc=None, tlb_entries=0, vlenb=0):
         self.L = lib()
         cfg = Config(64, isa_flags(isa), mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
-                     mem_base if reset_pc is None else reset_pc, tlb_entries, 0)
+                     mem_base if reset_pc is None else reset_pc, tlb_entries, vlenb)
         self.h = self.L.rvo_create(C.byref(cfg))
         if not self.h:
             raise ValueError("rvo_create failed")
@@ -172,6 +172,12 @@ class Hart:
     @property
     def priv(self):
         return self.L.rvo_priv(self.h)
+
+    def vreg(self, i) -> bytes:
+        buf = C.create_string_buffer(64)
+        self.L.rvo_get_vreg.argtypes = [C.c_void_p, C.c_uint, C.c_char_p]
+        n = self.L.rvo_get_vreg(self.h, i, buf)
+        return buf.raw[:n]
 
     def translate(self, va, pm, acc):
         """(cause, pa) of VirtMem::translate for privilege pm and access acc (1 r, 2 w, 4 x)."""

@@ -53,6 +53,14 @@ def main():
         if m:
             final["executed"], final["retired"] = int(m.group(1)), int(m.group(2))
     sv_recs, _ = parse(bl[2])
+    # RVV sample: r / c lines parse as usual; the two v lines are elided in the capture ("head…tail", most significant byte first)
+    rvv_recs, rvv_extra = parse(bl[1])
+    vlines = []
+    for ln in rvv_extra:
+        m = re.match(r"^#(\d+) (\d+) +([MSU]) ([0-9a-f]{16}) +([0-9a-f]{8}) v ([0-9a-f]{2}) ([0-9a-f]+)…([0-9a-f]+) (.*)$", ln.rstrip())
+        if m:
+            vlines.append(dict(tag=int(m.group(1)), pc=int(m.group(4), 16), op=m.group(5), reg=int(m.group(6), 16), head=m.group(7), tail=m.group(8),
+                               text=m.group(9)))
     out = {
         "source": "SURVEY.md Appendix D (reference Whisper v1.861, captured by the survey session)",
         "fp_trap": {"isa": "rv64imafdcv_zicsr", "base": 0x80000000, "words": [words[a] for a in sorted(words)],
@@ -60,6 +68,8 @@ def main():
                     "stop": "Failed stop: Hart 0: 16 consecutive illegal instructions"},
         "sv39_first": {"isa": "rv64imafdcsu_zicsr", "records": [r for r in sv_recs if r["tag"] == 1],
                        "pokes": {"mstatus_mpp": 1, "mepc": 0x40000100}, "next_pc": 0x40000100, "next_priv": "S"},
+        # RVV sample (default VLEN = 512): csrrs x0, mstatus, x5 (= 0x2200) precedes it as #3; x5 is poked here
+        "rvv": {"isa": "rv64imafdcv_zicsr", "records": rvv_recs, "vlines": vlines, "x5": 0x2200, "first_pc": 0x80000008},
         # the whole Sv39 sample: set-up as the survey's caption states it (root PTE[1] = 0x200000cf maps VA 0x40000000 -> PA
         # 0x80000000 as a 1 GiB V R W X A D leaf; satp = 8<<60 | 0x80002; pmpaddr0 = ~0, pmpcfg0 = 0x1f; tohost = PA 0x80003000)
         "sv39": {"isa": "rv64imafdcsu_zicsr", "records": sv_recs,

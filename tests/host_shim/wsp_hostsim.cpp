@@ -12,13 +12,15 @@ using namespace wsp;
 
 struct HostMem {
   u64 x[32], f[32], cold_[CI_COUNT];
-  u8* ram; u64* tlb_;
+  u8* ram; u64* tlb_; u8* vreg_;
   u64 rx(u32 r) const { return x[r]; }
   void wx(u32 r, u64 v) { x[r] = v; }
   u64 rf(u32 r) const { return f[r]; }
   void wf(u32 r, u64 v) { f[r] = v; }
   u64& cold(u32 i) { return cold_[i]; }
   u64& tlb(u32 i) { return tlb_[i]; }
+  u64 vld(u32 o, u32 esz) const { u64 v = 0; memcpy(&v, vreg_ + o, (size_t)1 << esz); return v; }
+  void vst(u32 o, u32 esz, u64 v) { memcpy(vreg_ + o, &v, (size_t)1 << esz); }
   u8 ld8(u64 o) const { return ram[o]; }
   u16 ld16(u64 o) const { u16 v; memcpy(&v, ram + o, 2); return v; }
   u32 ld32(u64 o) const { u32 v; memcpy(&v, ram + o, 4); return v; }
@@ -29,7 +31,7 @@ struct HostMem {
   void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
 };
 
-struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<u8> vreg; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
 
 template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 {
@@ -54,7 +56,9 @@ template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 }
 
 extern "C" {
-Sim* hs_create2(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u32 tlb_entries)
+Sim* hs_create3(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u32 tlb_entries, u32 vlenb);
+Sim* hs_create2(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u32 tlb_entries) { return hs_create3(isa, mem_base, mem_size, tohost, hart_id, tlb_entries, 0); }
+Sim* hs_create3(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u32 tlb_entries, u32 vlenb)
 {
   Sim* s = new Sim();
   s->ram.assign(mem_size, 0);
@@ -63,6 +67,10 @@ Sim* hs_create2(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u3
   s->L.tlb_n = (isa & ISA_S) ? (tlb_entries ? tlb_entries : 2048) : 0;
   s->tlb.assign(2 * (size_t)s->L.tlb_n + 2, 0);
   s->L.m.tlb_ = s->tlb.data();
+  s->L.vlenb = (isa & ISA_V) ? (vlenb ? vlenb : 64) : 0;
+  s->vreg.assign(32 * (size_t)s->L.vlenb + 8, 0);
+  s->L.m.vreg_ = s->vreg.data();
+  s->L.m.cold_[CI_VTYPE] = 1ULL << 63;
   s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
   s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
   s->max_exec = ~0ULL;
@@ -124,8 +132,13 @@ u64 hs_state_hash(Sim* s)
   h = fold(h, L.h.cycle); h = fold(h, L.h.instret); h = fold(h, L.h.exec);
   for (int i = 0; i < 72; ++i) h = fold(h, L.m.cold_[CI_PMPCFG0 + i]);
   if (L.isa & ISA_S) { u64 t = 0; for (u32 i = 0; i < 2 * L.tlb_n; ++i) t = fold(t, s->tlb[i]); h = fold(h, t); }
+  if (L.isa & ISA_V) {
+    h = fold(h, L.m.cold_[CI_VSTART]); h = fold(h, L.m.cold_[CI_VCSR]); h = fold(h, L.m.cold_[CI_VL]); h = fold(h, L.m.cold_[CI_VTYPE]);
+    for (u32 i = 0; i < 32 * L.vlenb / 8; ++i) { u64 w; memcpy(&w, s->vreg.data() + 8 * i, 8); h = fold(h, w); }
+  }
   return h;
 }
+void hs_get_vreg(Sim* s, u32 i, void* dst) { memcpy(dst, s->vreg.data() + (size_t)(i & 31) * s->L.vlenb, s->L.vlenb); }
 u64 hs_mem_hash(Sim* s)
 {
   u64 sum = 0, nw = s->L.mem_size / 8;

@@ -34,6 +34,8 @@ def shim():
         L = C.CDLL(SHIM_LIB)
         L.hs_create.restype = C.c_void_p
         L.hs_create.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.hs_create3.restype = C.c_void_p
+        L.hs_create3.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.hs_create2.restype = C.c_void_p
         L.hs_create2.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         L.hs_destroy.argtypes = [C.c_void_p]
@@ -63,7 +65,7 @@ def result_tuple(status, value, pc, execn, retired, state_hash, mem_hash, trace_
 
 def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart_id=0):
     h = rvoracle.Hart(isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, tohost=prog.tohost, reset_pc=prog.entry,
-                      hart_id=hart_id, tlb_entries=prog.meta.get("tlb_entries", 0))
+                      hart_id=hart_id, tlb_entries=prog.meta.get("tlb_entries", 0), vlenb=prog.meta.get("vlenb", 0))
     for paddr, data, _ in prog.segments:
         h.write_mem(paddr, data)
     if seed_a0 is not None:
@@ -77,8 +79,8 @@ def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart
 
 def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0):
     L = shim()
-    s = L.hs_create2(rvoracle.isa_flags(prog.isa), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
-                     prog.meta.get("tlb_entries", 0))
+    s = L.hs_create3(rvoracle.isa_flags(prog.isa), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
+                     prog.meta.get("tlb_entries", 0), prog.meta.get("vlenb", 0))
     try:
         for paddr, data, _ in prog.segments:
             assert L.hs_write_mem(s, paddr, data, len(data)) == 0

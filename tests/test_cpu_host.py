@@ -210,6 +210,26 @@ def test_hostsim_sv39_programs():
     assert pf > 1500 and ok_su > 10000
 
 
+def test_hostsim_rvv_programs():
+    """Rows a14-a16 (first slice): vsetvl*, unit-stride loads / stores, integer and F/D vector arithmetic, reductions, moves,
+    masks, LMUL mf8..8, ta / ma, illegal configurations, faults inside vector loads (vstart) -- device core (host build) ==
+    oracle for VLEN 512 and 256."""
+    vw = traps = uns = 0
+    for s in range(40):
+        for vlenb in (64, 32):
+            p = WL.rvv_program(s, vlenb=vlenb)
+            if s < 12:
+                b, _, log = S.run_oracle(p, log_cap=40000)
+                a, _, _ = S.run_hostsim(p)
+                assert a == b, (s, vlenb, a, b)
+                vw += sum(1 for c in log if any(k == rvoracle.CH_V for k, _, _ in c.changes()))
+                traps += sum(1 for c in log if c.trap == 1)
+                uns += b["status"] == 4
+            else:
+                _same(p)
+    assert vw > 1500 and traps > 500 and uns >= 1
+
+
 def test_pmp_semantics_directed():
     """PmpManager.hpp:155-177 + Hart.cpp:3079/3158/1988: no entry -> U store faults (cause 7, tval = address); a NAPOT rw-
     entry admits it; a locked r-- entry makes the same store fault in M mode; a misaligned access that runs into a

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 def _run_batch(progs, seeds=None, lanes=0, trace=True, same_elf=False, max_steps=W.NO_LIMIT):
     n = len(progs)
     p0 = progs[0]
-    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0))
+    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0),
+                vlen_bytes=p0.meta.get("vlenb", 0))
     try:
         if same_elf:
             b.load_elf_bytes(p0.elf)
@@ -170,6 +171,25 @@ def test_sv39_default_tlb_and_snapshot():
         _check(progs, res)
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("vlenb", [64, 32])
+def test_rvv_programs(vlenb):
+    """Rows a14-a16 (first slice): strip-mined saxpy / daxpy and random vector code (vsetvl*, unit-stride loads / stores,
+    integer and F/D arithmetic, reductions, moves, masks, LMUL mf8..8, ta / ma, illegal configurations, vector load faults);
+    the state digest covers all 32 vector registers and the vector CSRs, the trace digest every vector register group written."""
+    progs = [WL.rvv_program(s, vlenb=vlenb) for s in range(96)]
+    for lanes in (0, 16):
+        b, left, res = _run_batch(progs, lanes=lanes)
+        try:
+            assert left == 0
+            _check(progs, res)
+            ro, h, _ = S.run_oracle(progs[3])
+            for v in (0, 8, 16, 25, 31):
+                assert b.peek(3, W.RES_V, v)[:vlenb] == h.vreg(v)
+        finally:
+            b.close()
+    assert any(r["status"] == W.ST_STOP_UNSUPPORTED and (r["value"] >> 17) & 1 for r in res)
 
 
 def test_pmp_csr_peek_poke():

@@ -138,3 +138,28 @@ def test_sv39_sample_needs_pmp():
     h.set_csr(0x180, g["pokes"]["satp"])
     st, log = h.run(2, log_cap=4)
     assert log[1].trap == 1 and h.csr(0x342) == 1 and h.csr(0x343) == g["pokes"]["mepc"]
+
+
+def test_rvv_sample_trace():
+    """The survey's RVV capture (default VLEN 512): vsetvli x6, x0, e32,m1,ta,ma / vid.v v1 / vadd.vv v2, v1, v1 after
+    mstatus.FS and VS were switched on: the vsetvli record (x6, mstatus VS -> Dirty, vl, vtype) and both register images."""
+    g = GOLD["rvv"]
+    h = rvoracle.Hart(isa=g["isa"], mem_base=0x80000000, mem_size=1 << 16)
+    words = [0x3002a073, int(g["records"][0]["op"], 16)] + [int(v["op"], 16) for v in g["vlines"]]   # csrrs x0, mstatus, x5 first
+    h.write_mem(g["first_pc"], b"".join(w.to_bytes(4, "little") for w in words))
+    h.pc = g["first_pc"]
+    h.set_x(5, g["x5"])
+    st, log = h.run(len(words), log_cap=8)
+    gold = _group(g["records"])
+    c = log[1]
+    recs = gold[4]
+    assert (c.pc, f"{c.inst:08x}") == (recs[0]["pc"], recs[0]["op"])
+    assert c.changes() == [(KIND[r["kind"]], r["key"], r["val"]) for r in recs]
+    for c, v in zip(log[2:], g["vlines"]):
+        assert (c.pc, f"{c.inst:08x}") == (v["pc"], v["op"])
+        ch = c.changes()
+        assert len(ch) == 1 and ch[0][0] == KIND["v"] and ch[0][1] == v["reg"]
+        img = h.vreg(v["reg"])[::-1].hex()                     # the log prints the most significant byte first
+        assert len(img) == 128 and img.startswith(v["head"]) and img.endswith(v["tail"])
+    assert h.vreg(1) == b"".join(i.to_bytes(4, "little") for i in range(16))
+    assert h.vreg(2) == b"".join((2 * i).to_bytes(4, "little") for i in range(16))

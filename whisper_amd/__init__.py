@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libwhisper_amd.so")
 SRC = os.path.join(HERE, "csrc", "wsp_lib.hip")
 
 ST_RUNNING, ST_STOP_TOHOST, ST_STOP_ILLEGAL, ST_STOP_LIMIT, ST_STOP_UNSUPPORTED = range(5)
-RES_PC, RES_X, RES_F, RES_CSR, RES_MEM = range(5)
+RES_PC, RES_X, RES_F, RES_CSR, RES_MEM, RES_V = range(6)
 RUN_TRACE_HASH = 1
 LOAD_EXEC = 1
 OK, EINVAL, ENODEV, ENOMEM, EIO, EFORMAT, ERANGE, EUNSUPPORTED, EHIP = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -31,7 +31,7 @@ class WspError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [("xlen", C.c_uint32), ("n_harts", C.c_uint32), ("isa", C.c_char_p), ("mem_base", C.c_uint64),
                 ("mem_size", C.c_uint64), ("lanes_per_wave", C.c_uint32), ("device", C.c_int32), ("hart_id_base", C.c_uint32),
-                ("tlb_entries", C.c_uint32)]
+                ("tlb_entries", C.c_uint32), ("vlen_bytes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -111,10 +111,10 @@ class Batch:
     System64/Hart64, py-bindings.cpp:330-469, for a batch)."""
 
     def __init__(self, n_harts, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, lanes_per_wave=0, device=-1,
-                 hart_id_base=0, tlb_entries=0):
+                 hart_id_base=0, tlb_entries=0, vlen_bytes=0):
         self.L = lib()
         self._isa = isa.encode()
-        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, tlb_entries)
+        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, tlb_entries, vlen_bytes, 0)
         h = C.c_void_p()
         _check(self.L.wsp_batch_create(C.byref(desc), C.byref(h)))
         self.h = h
@@ -148,7 +148,7 @@ class Batch:
         return v.value
 
     def poke(self, hart, res, idx, value):
-        if res == RES_MEM:
+        if res in (RES_MEM, RES_V):
             buf = bytes(value)
             _check(self.L.wsp_batch_poke(self.h, hart, res, idx, buf, len(buf)))
         else:
@@ -156,7 +156,9 @@ class Batch:
             _check(self.L.wsp_batch_poke(self.h, hart, res, idx, C.byref(v), 8))
 
     def peek(self, hart, res, idx, size=8):
-        if res == RES_MEM:
+        if res == RES_V:
+            size = 64
+        if res in (RES_MEM, RES_V):
             buf = C.create_string_buffer(size)
             _check(self.L.wsp_batch_peek(self.h, hart, res, idx, buf, size))
             return buf.raw

@@ -31,7 +31,7 @@ enum { ST_RUNNING = 0, ST_STOP_TOHOST = 1, ST_STOP_ILLEGAL = 2, ST_STOP_LIMIT = 
 enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
 
 // Unsupported-reason codes reported in wsp_result.stop_value when status == ST_STOP_UNSUPPORTED
-enum { UNS_PAGING = 0x180, UNS_PMP_STALE = 0x181, UNS_CSR_BASE = 0x10000, UNS_VECTOR = 0x20000 };
+enum { UNS_PAGING = 0x180, UNS_PMP_STALE = 0x181, UNS_CSR_BASE = 0x10000, UNS_VECTOR = 0x20000 /* | instruction << 20 */ };
 
 enum Op : u32 {
   OP_ILLEGAL = 0,
@@ -51,6 +51,7 @@ enum Op : u32 {
   OP_FSGNJ /* imm: 0 j 1 jn 2 jx */, OP_FMINMAX /* imm: 0 min 1 max */, OP_FCMP /* imm: 0 le 1 lt 2 eq */,
   OP_FCVT_F2I /* rs2: 0 w 1 wu 2 l 3 lu */, OP_FCVT_I2F, OP_FCVT_FF /* to F_DBL ? d.s : s.d */,
   OP_FMV_F2X, OP_FCLASS, OP_FMV_X2F,
+  OP_VEC, OP_VLD, OP_VST,               // RVV: OP-V (0x57), vector load, vector store; fields are taken from Rec.raw
   OP_SLOWFETCH,                         // predecoded slot cannot be trusted: fetch + decode from RAM
   OP_COUNT
 };
@@ -165,11 +166,13 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
       else if (f5 == 0 || f5 == 1 || f5 == 4 || f5 == 8 || f5 == 12 || f5 == 16 || f5 == 20 || f5 == 24 || f5 == 28) r = mk(OP_AMO, rd, rs1, rs2, (i32)f5, fl);
       break; }
     case 0x07:
+      if ((f3 == 0 || f3 >= 5) && (isa & ISA_V)) { r = mk(OP_VLD, rd, rs1, rs2, 0); break; }    // vector widths (Decoder.cpp decodeVecLoad)
       if (f3 == 2 && (isa & ISA_F)) r = mk(OP_FLW, rd, rs1, 0, immi);
       else if (f3 == 3 && (isa & ISA_D)) r = mk(OP_FLD, rd, rs1, 0, immi);
       break;
     case 0x27: {
       i32 imms = ((i32)(inst & 0xfe000000u) >> 20) | (i32)((inst >> 7) & 31);
+      if ((f3 == 0 || f3 >= 5) && (isa & ISA_V)) { r = mk(OP_VST, 0, rs1, rs2, 0); break; }
       if (f3 == 2 && (isa & ISA_F)) r = mk(OP_FSW, 0, rs1, rs2, imms);
       else if (f3 == 3 && (isa & ISA_D)) r = mk(OP_FSD, 0, rs1, rs2, imms);
       break; }
@@ -178,6 +181,7 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
       if (fmt == 0 && (isa & ISA_F)) r = mk(OP_FMA, rd, rs1, rs2, (i32)(f3 | (k << 3)), 0, inst >> 27);
       else if (fmt == 1 && (isa & ISA_D)) r = mk(OP_FMA, rd, rs1, rs2, (i32)(f3 | (k << 3)), F_DBL, inst >> 27);
       break; }
+    case 0x57: if (isa & ISA_V) r = mk(OP_VEC, 0, rs1, rs2, 0); break;       // rd stays out of the record: x[rd] is written explicitly
     case 0x53: {
       if (f7 & 2) break;
       u32 dbl = (f7 & 1) ? (u32)F_DBL : 0;
@@ -297,7 +301,8 @@ enum ColdIx {
   CI_SEPC, CI_SCAUSE, CI_STVAL, CI_SATP,
   CI_PMPCFG0,                        // pmpcfg0,2,..,14 (RV64: even numbered only, CsRegs.cpp:4777-4784)
   CI_PMPADDR0 = CI_PMPCFG0 + 8,      // pmpaddr0..63
-  CI_COUNT = CI_PMPADDR0 + 64
+  CI_VSTART = CI_PMPADDR0 + 64, CI_VCSR /* vxrm << 1 | vxsat */, CI_VL, CI_VTYPE,
+  CI_COUNT
 };
 
 // HF_HOT: the hart may use the pre-decoded fetch and the trap-free inline subset: M-mode, MPRV clear,
@@ -317,6 +322,7 @@ struct Hot {
 // CSR numbers
 enum {
   C_FFLAGS = 0x001, C_FRM = 0x002, C_FCSR = 0x003,
+  C_VSTART = 0x008, C_VXSAT = 0x009, C_VXRM = 0x00A, C_VCSR = 0x00F, C_VL = 0xC20, C_VTYPE = 0xC21, C_VLENB = 0xC22,
   C_SSTATUS = 0x100, C_SIE = 0x104, C_STVEC = 0x105, C_SCOUNTEREN = 0x106, C_SENVCFG = 0x10A,
   C_SSCRATCH = 0x140, C_SEPC = 0x141, C_SCAUSE = 0x142, C_STVAL = 0x143, C_SIP = 0x144, C_SATP = 0x180,
   C_MSTATUS = 0x300, C_MISA = 0x301, C_MEDELEG = 0x302, C_MIDELEG = 0x303, C_MIE = 0x304, C_MTVEC = 0x305,
@@ -342,10 +348,12 @@ static constexpr u64 MSTATUS_RESET = (3ULL << MST_MPP_SH) | (0xAULL << 32);   //
 // Per-step commit bookkeeping (what printDecodedInstTrace would print, printTrace.cpp:388-493).
 enum : u32 {
   CH_IREG = 1, CH_FREG = 2, CH_MEM = 4, CH_GEN = 8, CH_SSTATUS = 16, CH_SEPC = 32, CH_SCAUSE = 64, CH_STVAL = 128,
-  CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096
+  CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096,
+  CH_VREG = 8192, CH_VL = 16384, CH_VTYPE = 32768
 };
 struct Step {
   u32 chg, ireg, freg, gen_csr;
+  u32 vreg, vgroup;              // vector group written: first register (operand 0), register count (0: none)
   u64 ival, fval, maddr, mval;
 };
 
@@ -365,6 +373,7 @@ template <class MEM> struct Lane {
   u64 mem_base, mem_size, tohost, text_lo, text_hi;   // tohost == ~0: none
   u32 isa, hart_id;
   u32 tlb_n;                                           // TLB entries (power of two; 0 when the ISA has no S)
+  u32 vlenb;                                           // bytes per vector register (0 when the ISA has no V)
 
   WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
   WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
@@ -821,6 +830,7 @@ template <class MEM> struct Lane {
       case C_MSCRATCH: case C_MEPC: case C_MCAUSE: case C_MTVAL: case C_MIP: case C_MCYCLE: case C_MINSTRET:
       case C_MVENDORID: case C_MARCHID: case C_MIMPID: case C_MHARTID: case C_MCONFIGPTR: return 1;
       case C_CYCLE: case C_TIME: case C_INSTRET: return ext(ISA_ZICNTR) ? 1 : 0;
+      case C_VSTART: case C_VXSAT: case C_VXRM: case C_VCSR: case C_VL: case C_VTYPE: case C_VLENB: return ext(ISA_V) ? 1 : 0;   // CsRegs::enableVector
       default: break;
     }
     if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   // pmpcfg (even only on rv64), pmpaddr0..63
@@ -841,6 +851,8 @@ template <class MEM> struct Lane {
       case C_FFLAGS: return h.fcsr & 0x1f;
       case C_FRM: return (h.fcsr >> 5) & 7;
       case C_FCSR: return h.fcsr;
+      case C_VSTART: return m.cold(CI_VSTART); case C_VXSAT: return m.cold(CI_VCSR) & 1; case C_VXRM: return (m.cold(CI_VCSR) >> 1) & 3;
+      case C_VCSR: return m.cold(CI_VCSR); case C_VL: return m.cold(CI_VL); case C_VTYPE: return m.cold(CI_VTYPE); case C_VLENB: return vlenb;
       case C_SSTATUS: return h.mstatus & SSTATUS_RMASK;
       case C_SIE: return m.cold(CI_MIE) & m.cold(CI_MIDELEG) & ~0x1444ULL;   // CsRegs::readSie (CsRegs.cpp:195-229)
       case C_SIP: return m.cold(CI_MIP) & m.cold(CI_MIDELEG) & ~0x1444ULL;
@@ -872,6 +884,12 @@ template <class MEM> struct Lane {
       case C_FFLAGS: h.fcsr = (h.fcsr & ~0x1fu) | (u32)(v & 0x1f); break;
       case C_FRM: h.fcsr = (h.fcsr & ~0xe0u) | (u32)((v & 7) << 5); break;
       case C_FCSR: h.fcsr = (u32)(v & 0xff); break;
+      case C_VSTART: m.cold(CI_VSTART) = v & (vlenb * 8 - 1); break;          // mask = VLEN - 1 (Hart.cpp:1088-1103)
+      case C_VXSAT: m.cold(CI_VCSR) = (m.cold(CI_VCSR) & 6) | (v & 1); break;  // CsRegs.cpp:4556-4606
+      case C_VXRM: m.cold(CI_VCSR) = (m.cold(CI_VCSR) & 1) | ((v & 3) << 1); break;
+      case C_VCSR: m.cold(CI_VCSR) = v & 7; break;
+      case C_VL: m.cold(CI_VL) = v; break;                                     // poke only
+      case C_VTYPE: m.cold(CI_VTYPE) = v & 0x80000000000000ffULL; break;
       case C_MSTATUS: {   // value &= writeMask & readMask (CsRegs.cpp:3964): FS is read-only zero without F and S
         const u64 k = (ext(ISA_F) || ext(ISA_S)) ? MSTATUS_WMASK : (MSTATUS_WMASK & ~(3ULL << MST_FS_SH));
         h.mstatus = legalize_mstatus((h.mstatus & ~MSTATUS_WMASK) | (v & k)); break; }
@@ -937,6 +955,7 @@ template <class MEM> struct Lane {
     if (cls < 0) { stop(ST_STOP_UNSUPPORTED, UNS_CSR_BASE | num); return; }
     if (cls == 0) { illegal(r, cur_pc); return; }
     if (num <= C_FCSR && !fp_on()) { illegal(r, cur_pc); return; }                       // Hart.cpp:12945-12950
+    if (((num >= C_VSTART && num <= C_VCSR) || (num >= C_VL && num <= C_VLENB)) && !vec_on()) { illegal(r, cur_pc); return; }   // Hart.cpp:12952-12958
     if (!csr_readable(num) || (do_write && ((num >> 10) & 3) == 3)) { illegal(r, cur_pc); return; }
     if (num == C_SATP && h.priv == PRV_S && (h.mstatus & MST_TVM)) { illegal(r, cur_pc); return; }
     u64 prev = do_read ? csr_peek(num) : 0;
@@ -963,6 +982,7 @@ template <class MEM> struct Lane {
     if (num == C_MSTATUS) s.chg |= CH_MSTATUS; else if (num == C_SSTATUS) s.chg |= CH_SSTATUS;
     else { s.chg |= CH_GEN; s.gen_csr = num; }
     if (num <= C_FCSR) mark_fs_dirty();
+    else if (num <= C_VCSR) mark_vs_dirty();                                             // postCsrUpdate (Hart.cpp:4731-4734)
     if (w_ir) h.instret--;
     if (w_cy) h.cycle--;
   }
@@ -1114,6 +1134,475 @@ template <class MEM> struct Lane {
     }
     if (!do_store(va, size, res, cur_pc)) return;
     wx(rd, ld);
+  }
+
+  // ---- RVV (vector.cpp, vector-ls.cpp, vector-float.cpp, vector-mask.cpp, VecRegs.hpp), first slice: vsetvl*, unit-stride
+  // loads / stores, the generic integer vv/vx/vi group, multiply-add, merge / move, scalar moves, vid, integer reductions,
+  // F/D add/sub/mul/div, vfmacc, sum reductions and FP moves, at the reference's defaults (VLEN = 8 * vlenb, ELEN 64, every
+  // LMUL legal, agnostic = all ones, vill instead of a trap, non-zero vstart traps on arithmetic).  One lane runs its hart's
+  // element loop serially (lanes-per-element mapping is the next step).  Anything else in the vector encodings
+  // stops the hart UNSUPPORTED (UNS_VECTOR | instruction << 20).
+  WSP_HD u64 vtype() { return m.cold(CI_VTYPE); }
+  WSP_HD static u32 gm_x8(u32 gm) { return gm < 4 ? 8u << gm : gm > 4 ? 8u >> (8 - gm) : 0; }                 // VecRegs.hpp:354-361
+  WSP_HD static u64 ones_of(u32 esz) { return esz == 3 ? ~0ULL : (1ULL << (8u << esz)) - 1; }
+  WSP_HD bool vec_on() const { return ext(ISA_V) && ((h.mstatus >> MST_VS_SH) & 3) != 0; }                    // isVecLegal
+  WSP_HD void mark_vs_dirty() { if (((h.mstatus >> MST_VS_SH) & 3) != 3) { h.mstatus |= (3ULL << MST_VS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
+  WSP_HD u64 vrd(u32 reg, u32 ix, u32 esz) { return m.vld(reg * vlenb + (ix << esz), esz); }
+  WSP_HD i64 vrd_s(u32 reg, u32 ix, u32 esz) { const u32 sh = 64 - (8u << esz); return (i64)(vrd(reg, ix, esz) << sh) >> sh; }
+  // VecRegs::write (VecRegs.hpp:190-211): the first write fixes the group the commit record reports
+  WSP_HD void vwr(u32 reg, u32 ix, u32 esz, u32 groupx8, u64 v)
+  {
+    if (s.vgroup == 0) { s.vgroup = groupx8 >= 8 ? groupx8 / 8 : 1; s.chg |= CH_VREG; }
+    m.vst(reg * vlenb + (ix << esz), esz, v);
+  }
+  WSP_HD bool v_mask_bit(u32 ix) { return (m.vld(ix >> 3, 0) >> (ix & 7)) & 1; }                               // isActive(0, ix)
+  struct VCfg { u32 esz, gx8, vl, elem_max; bool ta, ma, vill; };
+  WSP_HD VCfg vcfg()
+  {
+    const u64 vt = vtype(); VCfg c;
+    c.esz = (u32)(vt >> 3) & 7; c.gx8 = gm_x8((u32)vt & 7); c.ta = (vt >> 6) & 1; c.ma = (vt >> 7) & 1; c.vill = (vt >> 63) != 0;
+    c.vl = (u32)m.cold(CI_VL);
+    const u32 vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> c.esz;
+    c.elem_max = vlmax > single ? vlmax : single;                                                               // VecRegs.hpp:388
+    return c;
+  }
+  // VecRegs::isDestActive (VecRegs.hpp:738-757)
+  WSP_HD bool v_dest_active(const VCfg& c, u32 vd, u32 ix, u32 esz, bool masked, u64& val)
+  {
+    val = vrd(vd, ix, esz);
+    if (ix >= c.vl) { if (c.ta) val = ones_of(esz); return false; }
+    if (masked && !v_mask_bit(ix)) { if (c.ma) val = ones_of(esz); return false; }
+    return true;
+  }
+  WSP_HD void vec_fail(const Rec& r, u64 cur_pc) { illegal(r, cur_pc); if (s.vgroup) mark_vs_dirty(); }       // postVecFail (vector.cpp:672-680)
+  WSP_HD void vec_success()                                                                                   // postVecSuccess (vector.cpp:637-669)
+  {
+    bool dirty = s.vgroup != 0;
+    if (m.cold(CI_VSTART) != 0) { m.cold(CI_VSTART) = 0; s.chg |= CH_GEN; s.gen_csr = C_VSTART; dirty = true; }
+    if (dirty) mark_vs_dirty();
+  }
+  WSP_HD void vec_unsupported(u32 inst) { stop(ST_STOP_UNSUPPORTED, (u64)UNS_VECTOR | ((u64)inst << 20)); }
+  WSP_HD bool v_check_sew_lmul_vstart(const VCfg& c, const Rec& r, u64 cur_pc)                                // vector.cpp:170-194
+  { if (!vec_on() || c.vill || m.cold(CI_VSTART) > 0) { vec_fail(r, cur_pc); return false; } return true; }
+  WSP_HD bool v_check_int(const VCfg& c, const Rec& r, u64 cur_pc, bool vs1_is_vec)                           // checkVecIntInst (vector.cpp:133-167)
+  {
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return false;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31;
+    if (!((inst >> 25) & 1) && (vd == 0 || vs2 == 0 || (vs1_is_vec && vs1 == 0))) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  WSP_HD bool v_check_emul(const Rec& r, u64 cur_pc, u32 groupx8, u32 a, u32 b, u32 c3)                       // checkVecOpsVsEmul (vector.cpp:197-219)
+  {
+    const u32 mk_ = (groupx8 >= 8 ? groupx8 / 8 : 1) - 1;
+    if ((a & mk_) || (b & mk_) || (c3 & mk_)) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  WSP_HD void v_set_vl_vtype(u32 rd, u64 elems, bool write_vl, u32 gm, u32 ew, bool ta, bool ma, bool vill)
+  {
+    if (write_vl) { m.cold(CI_VL) = elems; s.chg |= CH_VL; }
+    wx(rd, m.cold(CI_VL));
+    m.cold(CI_VTYPE) = (u64)gm | ((u64)ew << 3) | ((u64)ta << 6) | ((u64)ma << 7) | ((u64)vill << 63);
+    s.chg |= CH_VTYPE;
+  }
+  // Hart::vsetvl (vector.cpp:530-634)
+  WSP_HD void v_vsetvl(u32 rd, u32 rs1, u64 avl_reg, u64 vtv)
+  {
+    bool ma = (vtv >> 7) & 1, ta = (vtv >> 6) & 1;
+    u32 gm = vtv & 7, ew = (vtv >> 3) & 7;
+    bool vill = (vtv >> 63) != 0 || ew > 3 || (vtv >> 8) != 0;
+    u64 elems = 0;
+    if (gm == 4) vill = true;
+    else {
+      const u32 vlmax = (gm_x8(gm) * (vlenb * 8) / (8u << ew)) / 8;
+      if (vlmax == 0) vill = true;
+      else {
+        if (rd != 0 && rs1 == 0) elems = vlmax;
+        else if (rd == 0 && rs1 == 0) {
+          const u64 vt = vtype(); const u32 prev = gm_x8((u32)vt & 7) * vlenb / (8u << ((u32)(vt >> 3) & 7));
+          if (vlmax != prev && !vill) vill = true;                              // cannot change VLMAX: no legalisation at the defaults
+          elems = m.cold(CI_VL);
+        } else elems = avl_reg <= vlmax ? avl_reg : vlmax;
+      }
+      if (elems > vlmax) vill = true;
+    }
+    if (vill) { ma = ta = false; gm = ew = 0; elems = 0; }
+    v_set_vl_vtype(rd, elems, vill || rd != 0 || rs1 != 0, gm, ew, ta, ma, vill);
+    mark_vs_dirty();
+  }
+  WSP_HD void v_vsetivli(u32 rd, u32 avl, u32 imm)                                                            // vector.cpp:705-781
+  {
+    bool ma = (imm >> 7) & 1, ta = (imm >> 6) & 1;
+    u32 gm = imm & 7, ew = (imm >> 3) & 7;
+    bool vill = (imm >> 8) != 0 || ew > 3;
+    u64 elems = avl;
+    if (gm == 4) vill = true;
+    else {
+      const u32 vlmax = (gm_x8(gm) * (vlenb * 8) / (8u << ew)) / 8;
+      if (vlmax == 0) vill = true; else if (elems > vlmax) elems = vlmax;
+    }
+    if (vill) { ma = ta = false; gm = ew = 0; elems = 0; }
+    v_set_vl_vtype(rd, elems, true, gm, ew, ta, ma, vill);
+    vec_success();
+    mark_vs_dirty();
+  }
+  // unit-stride loads / stores (vector-ls.cpp:112-407)
+  WSP_HD bool v_ldst_legal(const VCfg& c, u32 inst, u32 eew, u32& gx8)
+  {
+    gx8 = c.gx8 * (8u << eew) / (8u << c.esz);                                  // emul = lmul * eew / sew
+    const bool sym = gx8 == 1 || gx8 == 2 || gx8 == 4 || gx8 == 8 || gx8 == 16 || gx8 == 32 || gx8 == 64;
+    const u32 vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
+    return sym && vec_on() && eew <= 3 && !c.vill && !(masked && vd == 0);      // isLegalVecLdSt (:32-62)
+  }
+  WSP_HD void v_ldst_fault(u32 cause, u32 ix, u64 tval, u64 cur_pc)             // :213-243, :395-403
+  {
+    mark_vs_dirty();
+    m.cold(CI_VSTART) = ix & (vlenb * 8 - 1); s.chg |= CH_GEN; s.gen_csr = C_VSTART;
+    take_exception(cause, cur_pc, tval, false);
+  }
+  WSP_HD void v_load_unit(const Rec& r, u64 base, u64 cur_pc, u32 eew)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
+    u32 gx8;
+    if (!v_ldst_legal(c, inst, eew, gx8)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, gx8, vd, 0, 0)) return;
+    const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
+    const u32 single = vlenb >> eew, vlmax = c.gx8 * vlenb / (8u << c.esz), elem_max = vlmax > single ? vlmax : single;   // elemMax(eew)
+    u64 addr = base + (u64)start * esz;
+    if (gx8 < 8) gx8 = 8;
+    if (start < c.vl)
+      for (u32 ix = start; ix < elem_max; ++ix, addr += esz) {
+        u64 elem;
+        if (!v_dest_active(c, vd, ix, eew, masked, elem)) { vwr(vd, ix, eew, gx8, elem); continue; }
+        u64 pa1, pa2, tval;
+        if (paging_unsupported()) return;
+        const u32 cause = ldst_addr(addr, esz, 1, pa1, pa2, tval);
+        if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+        elem = pa1 == tohost ? 0 : mem_read2(pa1, pa2, esz);
+        vwr(vd, ix, eew, gx8, elem);
+      }
+    vec_success();
+  }
+  WSP_HD void v_store_unit(const Rec& r, u64 base, u64 cur_pc, u32 eew)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
+    u32 gx8;
+    if (!v_ldst_legal(c, inst, eew, gx8)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, gx8, vd, 0, 0)) return;
+    const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
+    u64 addr = base + (u64)start * esz;
+    for (u32 ix = start; ix < c.vl; ++ix, addr += esz) {
+      if (masked && !v_mask_bit(ix)) continue;
+      const u64 elem = vrd(vd, ix, eew);
+      u64 pa1, pa2, tval;
+      if (paging_unsupported()) return;
+      const u32 cause = ldst_addr(addr, esz, 2, pa1, pa2, tval);
+      if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+      // writeForStore (Hart.cpp:2727-2800); vector stores leave no m line in the log (printTrace.cpp:452)
+      if (pa1 + esz > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;
+      if (pa2 != pa1 && pa2 + esz > text_lo && pa2 < text_hi) h.flags |= HF_CODE_DIRTY;
+      if (tohost != ~0ULL && (pa1 == tohost || pa1 == tohost + 4)) {
+        mem_write(pa1 - mem_base, esz, elem);
+        u64 v = elem;
+        if (esz == 4) { if (pa1 == tohost + 4) { h.htif_dev = (u32)elem; continue; } v |= (u64)h.htif_dev << 32; }
+        else if (esz == 8) h.htif_dev = 0;
+        if (((v >> 48) & 0xff) == 0 && ((v >> 56) & 0xff) == 0 && (elem & 1)) { stop(ST_STOP_TOHOST, v); return; }
+        continue;
+      }
+      mem_write2(pa1, pa2, esz, elem);
+    }
+    vec_success();
+  }
+  // integer element operation: a = vs2 element, b = vs1 element / scalar / immediate
+  enum { VI_ADD, VI_SUB, VI_RSUB, VI_AND, VI_OR, VI_XOR, VI_SLL, VI_SRL, VI_SRA, VI_MINU, VI_MIN, VI_MAXU, VI_MAX, VI_MUL };
+  WSP_HD static u64 vi_op(u32 op, u64 a, u64 b, u32 esz)
+  {
+    const u32 bits = 8u << esz, sh = 64 - bits, shm = bits - 1;
+    const i64 sa = (i64)(a << sh) >> sh, sb = (i64)(b << sh) >> sh;
+    const u64 on = ones_of(esz), ua = a & on, ub = b & on; u64 z;
+    switch (op) {
+      case VI_ADD: z = a + b; break; case VI_SUB: z = a - b; break; case VI_RSUB: z = b - a; break;
+      case VI_AND: z = a & b; break; case VI_OR: z = a | b; break; case VI_XOR: z = a ^ b; break;
+      case VI_SLL: z = ua << (b & shm); break; case VI_SRL: z = ua >> (b & shm); break; case VI_SRA: z = (u64)(sa >> (b & shm)); break;
+      case VI_MINU: z = ua < ub ? ua : ub; break; case VI_MIN: z = (u64)(sa < sb ? sa : sb); break;
+      case VI_MAXU: z = ua > ub ? ua : ub; break; case VI_MAX: z = (u64)(sa > sb ? sa : sb); break;
+      default: z = a * b; break;
+    }
+    return z & on;
+  }
+  // execVop_vv / vx / vi (vector.cpp:858-1111).  kind: 0 vv, 1 vx, 2 vi
+  WSP_HD void v_int_arith(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, kind == 0)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = vi_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
+  // vmacc / vnmsac / vmadd / vnmsub (vector.cpp:4836-5290): k 0 macc, 1 nmsac, 2 madd, 3 nmsub
+  WSP_HD void v_int_muladd(const Rec& r, u64 cur_pc, u32 k, bool vx, u64 xs)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, !vx)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, vx ? 0 : vs1)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u64 e1 = vx ? xs : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz), dd = vrd(vd, ix, c.esz);
+          d = (k == 0 ? e1 * e2 + dd : k == 1 ? dd - e1 * e2 : k == 2 ? e1 * dd + e2 : e2 - e1 * dd) & ones_of(c.esz);
+        }
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
+  // vmerge.vvm / vxm / vim, vmv.v.v / x / i (vector.cpp:7815-7970, 8098-8260)
+  WSP_HD void v_merge_mv(const Rec& r, u64 cur_pc, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool vm = (inst >> 25) & 1;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (vm) {
+      if (!v_check_emul(r, cur_pc, dg, vd, kind == 0 ? vs1 : 0, 0)) return;
+      if (0 < c.vl)
+        for (u32 ix = 0; ix < c.elem_max; ++ix) {
+          u64 d;
+          if (v_dest_active(c, vd, ix, c.esz, false, d)) d = (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & ones_of(c.esz);
+          vwr(vd, ix, c.esz, dg, d);
+        }
+      if (s.vgroup == 0) { s.vgroup = dg / 8; s.chg |= CH_VREG; }               // touchReg (vector.cpp:8150)
+      vec_success();
+      return;
+    }
+    if (vd == 0 || vs2 == 0 || (kind == 0 && vs1 == 0)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, false, d))
+          d = (v_mask_bit(ix) ? (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) : vrd(vs2, ix, c.esz)) & ones_of(c.esz);
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
+  // reduction prologue shared by the integer and FP sums (checkRedOpVsEmul, vector.cpp:222-258)
+  WSP_HD bool v_red_check(const VCfg& c, const Rec& r, u64 cur_pc)
+  {
+    const u32 inst = r.raw, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (masked && (vs2 == 0 || vs1 == 0)) { vec_fail(r, cur_pc); return false; }
+    const u32 lm = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    if (vs2 & (lm - 1)) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  WSP_HD void v_red_finish(const VCfg& c, u32 vd, u64 res)
+  {
+    vwr(vd, 0, c.esz, 8, res);
+    if (c.ta) for (u32 ix = 1; ix < (vlenb >> c.esz); ++ix) vwr(vd, ix, c.esz, 8, ones_of(c.esz));
+  }
+  WSP_HD void v_int_reduce(const Rec& r, u64 cur_pc, u32 op)                    // vector.cpp:3690-3860
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    if (!v_red_check(c, r, cur_pc)) return;
+    if (c.vl == 0) return;                                                      // no postVecSuccess (:3733-3734)
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    u64 res = vrd(vs1, 0, c.esz);
+    for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vi_op(op, res, vrd(vs2, ix, c.esz), c.esz); }
+    v_red_finish(c, vd, res);
+    vec_success();
+  }
+  WSP_HD void v_mv_s(const VCfg& c, u32 vd, u64 val)                            // vmv.s.x / vfmv.s.f body (vector.cpp:8033-8095)
+  {
+    if (0 < c.vl) { vwr(vd, 0, c.esz, 8, val & ones_of(c.esz)); if (c.ta) for (u32 i = 1; i < (vlenb >> c.esz); ++i) vwr(vd, i, c.esz, 8, ones_of(c.esz)); }
+    vec_success();
+  }
+  // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
+  WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
+  WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
+  {
+    if (!vec_on() || c.vill || m.cold(CI_VSTART) > 0) { vec_fail(r, cur_pc); return false; }
+    if (!v_fp_legal(c.esz) || !fp_rm(7, rm)) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  WSP_HD u64 vf_scalar(u32 fr, u32 esz) { return esz == 2 ? (u64)rf_s(fr) : m.rf(fr); }                       // FpRegs::read<T>
+  WSP_HD static u64 vf_op(u32 op, u64 a, u64 b, u32 esz, int rm, unsigned& fl)  // 0 add 1 sub 2 mul 3 div 4 rsub 5 rdiv
+  {
+    using namespace wsf;
+    if (op == 4 || op == 5) { const u64 t = a; a = b; b = t; op = op == 4 ? 1 : 3; }
+    if (esz == 2) return op == 0 ? f_add<F32>(a, b, rm, fl) : op == 1 ? f_sub<F32>(a, b, rm, fl) : op == 2 ? f_mul<F32>(a, b, rm, fl) : f_div<F32>(a, b, rm, fl);
+    return op == 0 ? f_add<F64>(a, b, rm, fl) : op == 1 ? f_sub<F64>(a, b, rm, fl) : op == 2 ? f_mul<F64>(a, b, rm, fl) : f_div<F64>(a, b, rm, fl);
+  }
+  WSP_HD void v_fp_arith(const Rec& r, u64 cur_pc, u32 op, bool vf, bool fma)   // vfadd.. (:655-1990), vfmacc (:2714-2860)
+  {
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_int(c, r, cur_pc, !vf)) return;
+    if (!v_check_fp(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, vf ? 0 : vs1)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0;
+    unsigned fl = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u64 e1 = vf ? sc : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz);
+          if (fma) d = c.esz == 2 ? wsf::f_fma<wsf::F32>(e1, e2, vrd(vd, ix, 2), rm, fl) : wsf::f_fma<wsf::F64>(e1, e2, vrd(vd, ix, 3), rm, fl);
+          else d = vf_op(op, e2, e1, c.esz, rm, fl);
+        }
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    or_fflags(fl);                                                              // updateAccruedFpBits
+    vec_success();
+  }
+  WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
+  {
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_fp(c, r, cur_pc, rm)) return;
+    if (!v_red_check(c, r, cur_pc)) return;
+    if (c.vl == 0) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    u64 res = vrd(vs1, 0, c.esz); unsigned fl = 0;
+    for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vf_op(0, res, vrd(vs2, ix, c.esz), c.esz, rm, fl); }
+    v_red_finish(c, vd, res);
+    or_fflags(fl);
+    vec_success();
+  }
+  WSP_HD bool v_fp_mv_check(const VCfg& c, const Rec& r, u64 cur_pc)            // vfmv.* prologue (:503-515, 585-595, 4169-4180)
+  {
+    int rm;
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return false;
+    if (!((r.raw >> 25) & 1) || !fp_rm(7, rm)) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  // dispatch: OP-V.  a = x[rs1], b = x[rs2]
+  WSP_HD void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc)
+  {
+    const u32 inst = r.raw, f3 = (inst >> 12) & 7, f6 = inst >> 26, rd = (inst >> 7) & 31, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31;
+    const bool vm = (inst >> 25) & 1;
+    s.vreg = rd;
+    if (f3 == 7) {                                                              // vsetvli / vsetivli / vsetvl
+      const bool is_vli = !(inst >> 31), is_ivli = (inst >> 30) == 3, is_vl = (inst >> 25) == 0x40;
+      if (!is_vli && !is_ivli && !is_vl) { illegal(r, cur_pc); return; }
+      if (!vec_on()) { vec_fail(r, cur_pc); return; }
+      if (is_ivli) { v_vsetivli(rd, rs1, (inst >> 20) & 0x3ff); return; }
+      v_vsetvl(rd, rs1, a, is_vli ? (u64)((inst >> 20) & 0x7ff) : b);
+      vec_success();
+      return;
+    }
+    const u64 imm = (u64)(i64)((i32)(rs1 << 27) >> 27), uimm = rs1;
+    if (f3 == 0 || f3 == 3 || f3 == 4) {                                        // OPIVV / OPIVI / OPIVX
+      const u32 kind = f3 == 0 ? 0 : f3 == 4 ? 1 : 2;
+      const u64 sc = kind == 1 ? a : imm;
+      int op = -1;
+      switch (f6) {
+        case 0x00: op = VI_ADD; break;
+        case 0x02: if (kind != 2) op = VI_SUB; break;
+        case 0x03: if (kind != 0) op = VI_RSUB; break;
+        case 0x04: if (kind != 2) op = VI_MINU; break;
+        case 0x05: if (kind != 2) op = VI_MIN; break;
+        case 0x06: if (kind != 2) op = VI_MAXU; break;
+        case 0x07: if (kind != 2) op = VI_MAX; break;
+        case 0x09: op = VI_AND; break; case 0x0a: op = VI_OR; break; case 0x0b: op = VI_XOR; break;
+        case 0x25: v_int_arith(r, cur_pc, VI_SLL, kind, kind == 2 ? uimm : sc); return;
+        case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
+        case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x17:
+          if (vm && rs2 != 0) { illegal(r, cur_pc); return; }                   // Decoder.cpp:336-343
+          v_merge_mv(r, cur_pc, kind, sc); return;
+        default: break;
+      }
+      if (op >= 0) { v_int_arith(r, cur_pc, (u32)op, kind, sc); return; }
+      vec_unsupported(inst); return;
+    }
+    if (f3 == 2 || f3 == 6) {                                                   // OPMVV / OPMVX
+      const bool vx = f3 == 6;
+      if (f6 <= 7 && !vx) { const u8 rop[8] = { VI_ADD, VI_AND, VI_OR, VI_XOR, VI_MINU, VI_MIN, VI_MAXU, VI_MAX }; v_int_reduce(r, cur_pc, rop[f6]); return; }
+      if (f6 == 0x10) {
+        const VCfg c = vcfg();
+        if (!vx) {
+          if (rs1 != 0) { vec_unsupported(inst); return; }                      // vcpop / vfirst: not in this slice
+          if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;                   // vmv.x.s (vector.cpp:7972-8030)
+          if (!vm) { vec_fail(r, cur_pc); return; }
+          wx(rd, (u64)vrd_s(rs2, 0, c.esz)); vec_success(); return;
+        }
+        if (rs2 != 0) { illegal(r, cur_pc); return; }                           // vmv.s.x (Decoder.cpp:735)
+        if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+        if (!vm) { vec_fail(r, cur_pc); return; }
+        v_mv_s(c, rd, a); return;
+      }
+      if (f6 == 0x14 && !vx && rs1 == 0x11) {                                   // vid.v (vector-mask.cpp:435-510)
+        const VCfg c = vcfg();
+        if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+        if ((!vm && rd == 0) || rs2 != 0) { vec_fail(r, cur_pc); return; }
+        if (!v_check_emul(r, cur_pc, c.gx8, rd, 0, 0)) return;
+        const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+        if (0 < c.vl) for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, rd, ix, c.esz, !vm, d)) d = ix & ones_of(c.esz); vwr(rd, ix, c.esz, dg, d); }
+        vec_success(); return;
+      }
+      if (f6 == 0x25) { v_int_arith(r, cur_pc, VI_MUL, vx ? 1 : 0, a); return; }
+      if (f6 == 0x2d) { v_int_muladd(r, cur_pc, 0, vx, a); return; }
+      if (f6 == 0x2f) { v_int_muladd(r, cur_pc, 1, vx, a); return; }
+      if (f6 == 0x29) { v_int_muladd(r, cur_pc, 2, vx, a); return; }
+      if (f6 == 0x2b) { v_int_muladd(r, cur_pc, 3, vx, a); return; }
+      vec_unsupported(inst); return;
+    }
+    const bool vf = f3 == 5;                                                    // OPFVV (1) / OPFVF (5)
+    switch (f6) {
+      case 0x00: v_fp_arith(r, cur_pc, 0, vf, false); return;
+      case 0x02: v_fp_arith(r, cur_pc, 1, vf, false); return;
+      case 0x24: v_fp_arith(r, cur_pc, 2, vf, false); return;
+      case 0x20: v_fp_arith(r, cur_pc, 3, vf, false); return;
+      case 0x27: if (!vf) break; v_fp_arith(r, cur_pc, 4, true, false); return;
+      case 0x21: if (!vf) break; v_fp_arith(r, cur_pc, 5, true, false); return;
+      case 0x2c: v_fp_arith(r, cur_pc, 0, vf, true); return;
+      case 0x01: case 0x03: if (vf) break; v_fp_redsum(r, cur_pc); return;
+      case 0x10: {
+        const VCfg c = vcfg();
+        if (!vf) {                                                              // vfmv.f.s (vector-float.cpp:503-583)
+          if (rs1 != 0) { illegal(r, cur_pc); return; }
+          if (!v_fp_mv_check(c, r, cur_pc)) return;
+          if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
+          if (c.esz == 2) wf_s(rd, (u32)vrd(rs2, 0, 2)); else wf(rd, vrd(rs2, 0, 3));
+          mark_fs_dirty(); vec_success(); return;
+        }
+        if (rs2 != 0) { illegal(r, cur_pc); return; }                           // vfmv.s.f (:585-655)
+        if (!v_fp_mv_check(c, r, cur_pc)) return;
+        if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
+        v_mv_s(c, rd, vf_scalar(rs1, c.esz)); return; }
+      case 0x17: {
+        if (!vf || !vm) break;                                                  // vfmerge: not in this slice
+        if (rs2 != 0) { illegal(r, cur_pc); return; }                           // vfmv.v.f (:4134-4215)
+        const VCfg c = vcfg();
+        if (!v_fp_mv_check(c, r, cur_pc)) return;
+        if (!v_check_emul(r, cur_pc, c.gx8, rd, 0, 0)) return;
+        if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
+        const u64 sc = vf_scalar(rs1, c.esz); const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+        if (0 < c.vl) for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, rd, ix, c.esz, false, d)) d = sc; vwr(rd, ix, c.esz, dg, d); }
+        vec_success(); return; }
+      default: break;
+    }
+    vec_unsupported(inst);
+  }
+  // vector loads / stores: unit-stride, nf = 0, mew = 0 only.  a = x[rs1]
+  WSP_HD void exec_vector_ldst(const Rec& r, u64 a, u64 cur_pc, bool store)
+  {
+    const u32 inst = r.raw, f3 = (inst >> 12) & 7;
+    s.vreg = (inst >> 7) & 31;
+    if (((inst >> 26) & 3) != 0 || ((inst >> 20) & 31) != 0 || (inst >> 29) != 0 || ((inst >> 28) & 1) != 0) { vec_unsupported(inst); return; }
+    const u32 eew = f3 == 0 ? 0 : f3 - 4;
+    if (store) v_store_unit(r, a, cur_pc, eew); else v_load_unit(r, a, cur_pc, eew);
   }
 
   // ---- the common, trap-free subset executed inline in the GPU hot loop (caller guarantees HF_HOT).
@@ -1324,6 +1813,9 @@ template <class MEM> struct Lane {
       case OP_FADD: case OP_FSUB: case OP_FMUL: case OP_FDIV: case OP_FSQRT: case OP_FMA: case OP_FSGNJ: case OP_FMINMAX:
       case OP_FCMP: case OP_FCVT_F2I: case OP_FCVT_I2F: case OP_FCVT_FF: case OP_FMV_F2X: case OP_FCLASS: case OP_FMV_X2F:
         exec_fp(r, a, cur_pc); break;
+      case OP_VEC: exec_vector(r, a, b, cur_pc); break;
+      case OP_VLD: exec_vector_ldst(r, a, cur_pc, false); break;
+      case OP_VST: exec_vector_ldst(r, a, cur_pc, true); break;
       default: illegal(r, cur_pc); break;
     }
   }
@@ -1367,7 +1859,7 @@ template <class MEM> struct Lane {
   WSP_HD void cold_begin(u64& cur_pc, u32& priv0)
   {
     cur_pc = h.pc; priv0 = h.priv;
-    s.chg = 0;
+    s.chg = 0; s.vgroup = 0;
     h.exec++;
     if (!(h.flags & HF_INH_CY)) h.cycle++;
   }
@@ -1432,6 +1924,14 @@ template <class MEM> struct Lane {
     u32 c = s.chg; bool any = false;
     if ((c & CH_IREG) && s.ireg) { t = fold(t, (u64)s.ireg ^ (1ULL << 60)); t = fold(t, s.ival); any = true; }
     if (c & CH_FREG) { t = fold(t, (u64)s.freg ^ (2ULL << 60)); t = fold(t, s.fval); any = true; }
+    if (s.vgroup) {          // one v line per register of the group (printTrace.cpp:424-441): the record carries a digest of its bytes
+      for (u32 g = 0; g < s.vgroup; ++g) {
+        const u32 reg = (s.vreg + g) & 31; u64 d = 0;
+        for (u32 w = 0; w < vlenb / 8; ++w) d = fold(d, m.vld(reg * vlenb + 8 * w, 3));
+        t = fold(t, (u64)reg ^ (3ULL << 60)); t = fold(t, d);
+      }
+      any = true;
+    }
     if (c & CH_MEM) { t = fold(t, s.maddr ^ (4ULL << 60)); t = fold(t, s.mval); any = true; }
     const u64 K = 5ULL << 60;
     bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
@@ -1445,6 +1945,8 @@ template <class MEM> struct Lane {
     if (c & CH_MEPC) { t = fold(t, (u64)C_MEPC ^ K); t = fold(t, m.cold(CI_MEPC) & epc_rmask()); any = true; }
     if (c & CH_MCAUSE) { t = fold(t, (u64)C_MCAUSE ^ K); t = fold(t, m.cold(CI_MCAUSE)); any = true; }
     if (c & CH_MTVAL) { t = fold(t, (u64)C_MTVAL ^ K); t = fold(t, m.cold(CI_MTVAL)); any = true; }
+    if (c & CH_VL) { t = fold(t, (u64)C_VL ^ K); t = fold(t, m.cold(CI_VL)); any = true; }
+    if (c & CH_VTYPE) { t = fold(t, (u64)C_VTYPE ^ K); t = fold(t, m.cold(CI_VTYPE)); any = true; }
     if (!any) { t = fold(t, 1ULL << 60); t = fold(t, 0); }                                   // printTrace.cpp:491-493
     h.thash = t;
   }

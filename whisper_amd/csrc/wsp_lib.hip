@@ -32,6 +32,8 @@ struct DevState {
   u64 mem_base, mem_size;
   u64* x; u64* f; u64* hot64; u32* hot32; u64* cold;
   u64* tlb;            // [n_harts][tlb_n][2] packed TLB entries (wsp_core.h); null when the ISA has no S
+  u8* vreg;            // [n_harts][32][vlenb] vector registers, element 0 first; null when the ISA has no V
+  u32 vlenb, pad2;
   u64* tohost; u64* max_exec; u32* prog;
   u8* arena;
   const ProgDev* progs;
@@ -51,13 +53,18 @@ __host__ __device__ static inline size_t arena_off(const DevState& d, u32 hart, 
 // (pre-decoded operand offsets, Rec.pad).  The f block uses slots 0..31.
 #define WSP_XSLOTS 33
 struct DevMem {
-  u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* arena; u32 S, lpw_shift;
+  u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* vreg_; u8* arena; u32 S, lpw_shift;
   __device__ __forceinline__ u64 rx(u32 r) const { return xs[r ? r : 32]; }
   __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r] = v; }
   __device__ __forceinline__ u64 rf(u32 r) const { return fs[r]; }
   __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r] = v; }
   __device__ __forceinline__ u64& cold(u32 i) { return cold_[(size_t)i * S]; }
   __device__ __forceinline__ u64& tlb(u32 i) { return tlb_[i]; }
+  // element of 1 << esz bytes at byte offset o (a multiple of the size) of this hart's vector register file
+  __device__ __forceinline__ u64 vld(u32 o, u32 esz) const
+  { const u8* q = vreg_ + o; return esz == 0 ? *q : esz == 1 ? *(const u16*)q : esz == 2 ? *(const u32*)q : *(const u64*)q; }
+  __device__ __forceinline__ void vst(u32 o, u32 esz, u64 v)
+  { u8* q = vreg_ + o; if (esz == 0) *q = (u8)v; else if (esz == 1) *(u16*)q = (u16)v; else if (esz == 2) *(u32*)q = (u32)v; else *(u64*)q = v; }
   __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
   __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
   __device__ __forceinline__ u16 ld16(u64 o) const { return *(const u16*)p(o); }
@@ -89,6 +96,7 @@ __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& 
   L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot;
   L.m.tlb_ = d.tlb + (size_t)(wave * d.lpw + ln) * 2 * d.tlb_n; L.tlb_n = d.tlb_n;
+  L.m.vreg_ = d.vreg + (size_t)(wave * d.lpw + ln) * 32 * d.vlenb; L.vlenb = d.vlenb;
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
   L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + wave * d.lpw + ln;
@@ -139,7 +147,7 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, H
   const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
   L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
   L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
   L.template cold_step<TRACE>(recs);
   wsp_store_hot(L, d, slot);
   HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
@@ -157,11 +165,11 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
 {
   Lane<DevMem> L;
   L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.vreg_ = nullptr; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
   Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
   const u32 op = w0 & 0xff;
   WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0;
@@ -733,6 +741,12 @@ __global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* o
     for (u32 i = 0; i < 2 * d.tlb_n; ++i) th = fold(th, t[i]);
     s = fold(s, th);
   }
+  if (d.isa & ISA_V) {
+    s = fold(s, d.cold[(size_t)CI_VSTART * S + slot]); s = fold(s, d.cold[(size_t)CI_VCSR * S + slot]);
+    s = fold(s, d.cold[(size_t)CI_VL * S + slot]); s = fold(s, d.cold[(size_t)CI_VTYPE * S + slot]);
+    const u64* v = (const u64*)(d.vreg + (size_t)hart * 32 * d.vlenb);
+    for (u32 i = 0; i < 32 * d.vlenb / 8; ++i) s = fold(s, v[i]);
+  }
   wsp_result r;
   r.status = d.hot32[H32_STATUS * S + slot]; r.priv = d.hot32[H32_PRIV * S + slot];
   r.stop_value = d.hot64[H64_STOP_VALUE * S + slot]; r.pc = d.hot64[H64_PC * S + slot];
@@ -762,7 +776,7 @@ static int parse_isa(const char* isa, u32* out, std::string* why)
     switch (c) {
       case 'i': break;
       case 'm': f |= ISA_M; break; case 'a': f |= ISA_A; break; case 'f': f |= ISA_F; break; case 'd': f |= ISA_D; break;
-      case 'c': f |= ISA_C; break; case 's': f |= ISA_S; break; case 'u': f |= ISA_U; break;
+      case 'c': f |= ISA_C; break; case 's': f |= ISA_S; break; case 'u': f |= ISA_U; break; case 'v': f |= ISA_V; break;
       case 'g': f |= ISA_M | ISA_A | ISA_F | ISA_D; break;
       default: if (why) *why = std::string("ISA letter '") + c + "' is not supported"; return WSP_EUNSUPPORTED;
     }
@@ -802,17 +816,18 @@ struct wsp_batch {
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
   double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
   bool has_fp = false;
-  void* snap[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* snap[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct SnapPart { void* live; size_t bytes; };
-static void snap_parts(wsp_batch* b, SnapPart out[10])
+static void snap_parts(wsp_batch* b, SnapPart out[11])
 {
   DevState& d = b->d; size_t S = d.S;
   out[0] = { d.x, 32 * S * 8 }; out[1] = { d.f, 32 * S * 8 }; out[2] = { d.hot64, H64_COUNT * S * 8 }; out[3] = { d.hot32, H32_COUNT * S * 4 };
   out[4] = { d.cold, CI_COUNT * S * 8 }; out[5] = { d.tohost, S * 8 }; out[6] = { d.max_exec, S * 8 }; out[7] = { d.prog, S * 4 };
   out[8] = { d.arena, (size_t)d.n_waves * d.lpw * d.mem_size };
   out[9] = { d.tlb, (size_t)d.n_harts * 2 * d.tlb_n * 8 };
+  out[10] = { d.vreg, (size_t)d.n_harts * 32 * d.vlenb };
 }
 
 static int upload_progs(wsp_batch* b)
@@ -834,7 +849,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
   if (!b) return;
   hipSetDevice(b->device);
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
-  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -877,21 +892,25 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   d.mem_base = desc->mem_base; d.mem_size = desc->mem_size;
   d.tlb_n = (isa & ISA_S) ? (desc->tlb_entries ? desc->tlb_entries : 2048u) : 0u;        // Hart.cpp:106
   if (d.tlb_n & (d.tlb_n - 1)) { delete b; return fail(WSP_EINVAL, "tlb_entries must be a power of two"); }   // Tlb.cpp:11
+  d.vlenb = (isa & ISA_V) ? (desc->vlen_bytes ? desc->vlen_bytes : 64u) : 0u;           // Hart.cpp:1081
+  if ((isa & ISA_V) && d.vlenb != 16 && d.vlenb != 32 && d.vlenb != 64) { delete b; return fail(WSP_EINVAL, "vlen_bytes must be 16, 32 or 64"); }
   b->has_fp = (isa & ISA_F) != 0;
+  size_t vreg_bytes = (size_t)d.n_harts * 32 * d.vlenb;
   size_t S = d.S, arena_bytes = (size_t)d.n_waves * lpw * d.mem_size, tlb_bytes = (size_t)d.n_harts * 2 * d.tlb_n * 8;
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  if (arena_bytes + tlb_bytes + S * 1024 > free_b) { delete b; return fail(WSP_ENOMEM, "batch does not fit device memory"); }
+  if (arena_bytes + tlb_bytes + vreg_bytes + S * 1024 > free_b) { delete b; return fail(WSP_ENOMEM, "batch does not fit device memory"); }
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m_ = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); wsp_batch_destroy(b); return fail(WSP_ENOMEM, m_); } \
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
   ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
   ALLOC(d.cold, (CI_COUNT + 1) * S * 8);   /* + one row: per-slot store sink of the hot loop */ ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
-  ALLOC(d.arena, arena_bytes); if (tlb_bytes) ALLOC(d.tlb, tlb_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
+  ALLOC(d.arena, arena_bytes); if (tlb_bytes) ALLOC(d.tlb, tlb_bytes); if (vreg_bytes) ALLOC(d.vreg, vreg_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
 #undef ALLOC
   // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
   std::vector<u64> v64(S);
   std::fill(v64.begin(), v64.end(), d.mem_base);      hipMemcpy(d.hot64 + (size_t)H64_PC * S, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::fill(v64.begin(), v64.end(), MSTATUS_RESET);   hipMemcpy(d.hot64 + (size_t)H64_MSTATUS * S, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::fill(v64.begin(), v64.end(), 1ULL << 63);      hipMemcpy(d.cold + (size_t)CI_VTYPE * S, v64.data(), S * 8, hipMemcpyHostToDevice);   // vtype resets to vill (CsRegs.cpp:5363)
   std::fill(v64.begin(), v64.end(), ~0ULL);           hipMemcpy(d.tohost, v64.data(), S * 8, hipMemcpyHostToDevice);
   hipMemcpy(d.max_exec, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::vector<u32> v32(S, (u32)PRV_M);                hipMemcpy(d.hot32 + (size_t)H32_PRIV * S, v32.data(), S * 4, hipMemcpyHostToDevice);
@@ -1129,6 +1148,7 @@ static int csr_loc(u32 num, u32* ix)
     case C_STVEC: *ix = CI_STVEC; return 2; case C_SCOUNTEREN: *ix = CI_SCOUNTEREN; return 2; case C_SENVCFG: *ix = CI_SENVCFG; return 2;
     case C_SSCRATCH: *ix = CI_SSCRATCH; return 2; case C_SEPC: *ix = CI_SEPC; return 2; case C_SCAUSE: *ix = CI_SCAUSE; return 2;
     case C_STVAL: *ix = CI_STVAL; return 2; case C_SATP: *ix = CI_SATP; return 2;
+    case C_VSTART: *ix = CI_VSTART; return 2; case C_VCSR: *ix = CI_VCSR; return 2; case C_VL: *ix = CI_VL; return 2; case C_VTYPE: *ix = CI_VTYPE; return 2;
     default:
       if (num >= 0x3A0 && num <= 0x3AF && !(num & 1)) { *ix = CI_PMPCFG0 + ((num - 0x3A0) >> 1); return 2; }
       if (num >= 0x3B0 && num <= 0x3EF) { *ix = CI_PMPADDR0 + (num - 0x3B0); return 2; }
@@ -1159,6 +1179,10 @@ extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
       else if (loc == 2) HIPOK(hipMemcpy(&v, d.cold + ix * S + s, 8, hipMemcpyDeviceToHost));
       else return fail(WSP_EUNSUPPORTED, "CSR not modelled");
       break; }
+    case WSP_RES_V:                      // Hart::peekVecReg (Hart.hpp:219-325): the whole register, element 0 first
+      if (!d.vlenb || idx > 31 || size < d.vlenb) return fail(WSP_ERANGE, "vector register");
+      HIPOK(hipMemcpy(val, d.vreg + ((size_t)hart * 32 + idx) * d.vlenb, d.vlenb, hipMemcpyDeviceToHost));
+      return WSP_OK;
     case WSP_RES_MEM: {
       if (idx < d.mem_base || idx - d.mem_base > d.mem_size - size || size > d.mem_size) return fail(WSP_ERANGE, "memory peek outside arena");
       u8* tmp = nullptr; HIPOK(hipMalloc(&tmp, size));
@@ -1212,6 +1236,10 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
         if (n == C_MCOUNTINHIBIT) { u32 f; HIPOK(hipMemcpy(&f, d.hot32 + H32_FLAGS * S + s, 4, hipMemcpyDeviceToHost)); f = (f & ~(HF_INH_CY | HF_INH_IR)) | ((v & 1) ? (u32)HF_INH_CY : 0) | ((v & 4) ? (u32)HF_INH_IR : 0); HIPOK(hipMemcpy(d.hot32 + H32_FLAGS * S + s, &f, 4, hipMemcpyHostToDevice)); }
       } else return fail(WSP_EUNSUPPORTED, "CSR not modelled");
       break; }
+    case WSP_RES_V:
+      if (!d.vlenb || idx > 31 || size < d.vlenb) return fail(WSP_ERANGE, "vector register");
+      HIPOK(hipMemcpy(d.vreg + ((size_t)hart * 32 + idx) * d.vlenb, val, d.vlenb, hipMemcpyHostToDevice));
+      break;
     case WSP_RES_MEM: return wsp_batch_load_image(b, hart, hart + 1, idx, val, size, 0);
     default: return fail(WSP_EINVAL, "unknown resource");
   }
@@ -1319,8 +1347,8 @@ extern "C" int wsp_batch_snapshot(wsp_batch* b)
 {
   if (!b) return fail(WSP_EINVAL, "null batch");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[10]; snap_parts(b, parts);
-  for (int i = 0; i < 10; ++i) {
+  SnapPart parts[11]; snap_parts(b, parts);
+  for (int i = 0; i < 11; ++i) {
     if (!parts[i].bytes) continue;
     if (!b->snap[i]) { if (hipMalloc(&b->snap[i], parts[i].bytes) != hipSuccess) return fail(WSP_ENOMEM, "snapshot allocation failed"); }
     HIPOK(hipMemcpyAsync(b->snap[i], parts[i].live, parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
@@ -1334,8 +1362,8 @@ extern "C" int wsp_batch_restore(wsp_batch* b)
   if (!b) return fail(WSP_EINVAL, "null batch");
   if (!b->snap[0]) return fail(WSP_EINVAL, "no snapshot taken");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[10]; snap_parts(b, parts);
-  for (int i = 0; i < 10; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
+  SnapPart parts[11]; snap_parts(b, parts);
+  for (int i = 0; i < 11; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   HIPOK(hipStreamSynchronize(b->stream));
   return WSP_OK;
 }

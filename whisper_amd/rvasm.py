@@ -270,6 +270,32 @@ class Asm:
     def sfence_vma(self, rs1=0, rs2=0):
         self._emit32(self.enc_r(0x73, 0, 0x09, 0, rs1, rs2))
 
+    # ------------------------------------------------------------------ RVV (the slice the simulator models)
+    @staticmethod
+    def vtype(sew=32, lmul=1, ta=False, ma=False):
+        """vtype immediate: sew in bits, lmul 1/2/4/8 or a fraction given as 'mf2' / 'mf4' / 'mf8'."""
+        l = {1: 0, 2: 1, 4: 2, 8: 3, "mf8": 5, "mf4": 6, "mf2": 7}[lmul]
+        return l | ({8: 0, 16: 1, 32: 2, 64: 3}[sew] << 3) | (int(ta) << 6) | (int(ma) << 7)
+
+    def vsetvli(self, rd, rs1, vtypei):
+        self._emit32(((vtypei & 0x7FF) << 20) | (rs1 << 15) | (7 << 12) | (rd << 7) | 0x57)
+
+    def vsetivli(self, rd, uimm, vtypei):
+        self._emit32((3 << 30) | ((vtypei & 0x3FF) << 20) | ((uimm & 31) << 15) | (7 << 12) | (rd << 7) | 0x57)
+
+    def vsetvl(self, rd, rs1, rs2):
+        self._emit32((0x40 << 25) | (rs2 << 20) | (rs1 << 15) | (7 << 12) | (rd << 7) | 0x57)
+
+    def vop(self, f6, f3, vd, vs2, s1, vm=1):
+        """Generic OP-V: funct6, funct3 (0 OPIVV 1 OPFVV 2 OPMVV 3 OPIVI 4 OPIVX 5 OPFVF 6 OPMVX), vd, vs2, vs1 / rs1 / imm5, vm (0 = masked by v0)."""
+        self._emit32((f6 << 26) | ((vm & 1) << 25) | ((vs2 & 31) << 20) | ((s1 & 31) << 15) | (f3 << 12) | ((vd & 31) << 7) | 0x57)
+
+    def vle(self, eew, vd, rs1, vm=1):
+        self._emit32(((vm & 1) << 25) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vd << 7) | 0x07)
+
+    def vse(self, eew, vs3, rs1, vm=1):
+        self._emit32(((vm & 1) << 25) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vs3 << 7) | 0x27)
+
     # ------------------------------------------------------------------ compressed (explicit)
     def c_nop(self):
         self._emit16(0x0001)

@@ -1007,3 +1007,174 @@ def sv39_program(seed: int, n: int = 300) -> Program:
     syms = dict(a.symbols); syms.update(d.symbols)
     elf = write_elf(segs, syms["_start"], syms)
     return Program(f"sv39-{seed}", "rv64imafdcsu_zicsr", elf, syms["_start"], segs, syms, BASE, MEM, 60000, dict(seed=seed, tlb_entries=8))
+
+
+# ------------------------------------------------------------------------------------------ RVV (config 3)
+# funct6 of the modelled OP-V instructions
+_V_INT_VVXI = {"vadd": 0x00, "vand": 0x09, "vor": 0x0A, "vxor": 0x0B, "vsll": 0x25, "vsrl": 0x28, "vsra": 0x29}   # vv vx vi
+_V_INT_VVX = {"vsub": 0x02, "vminu": 0x04, "vmin": 0x05, "vmaxu": 0x06, "vmax": 0x07}                              # vv vx
+_V_MUL = {"vmul": 0x25, "vmacc": 0x2D, "vnmsac": 0x2F, "vmadd": 0x29, "vnmsub": 0x2B}                              # OPMVV / OPMVX
+_V_RED = {"vredsum": 0, "vredand": 1, "vredor": 2, "vredxor": 3, "vredminu": 4, "vredmin": 5, "vredmaxu": 6, "vredmax": 7}
+_V_FP = {"vfadd": 0x00, "vfsub": 0x02, "vfmul": 0x24, "vfdiv": 0x20, "vfmacc": 0x2C}                                # vv vf
+
+
+def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
+    """RVV (BASELINE config 3 style): strip-mined saxpy / daxpy (vle, vfmacc.vf, vse), then a
+    random sequence over the modelled vector slice: vsetvli / vsetivli / vsetvl with SEW 8..64, LMUL mf8..8 (legal and
+    not), ta / ma; unit-stride loads and stores (aligned and not, in and out of the arena, masked); integer vv / vx / vi
+    arithmetic, multiply-add, merges and moves, vid, reductions, scalar moves; F/D arithmetic, vfmacc, ordered and unordered
+    sums, FP moves; misaligned register groups, v0 overlaps and non-zero vstart (illegal), vector CSR reads and writes, a
+    few unsupported encodings at the very end.  Traps go to an M handler that skips the instruction."""
+    rng = random.Random(0x727676 ^ seed ^ (vlenb << 20))
+    data_base = BASE + 0x4000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.org(data_base + 0x100)
+    d.label("xs")
+    import struct
+    nx = 200
+    d.data(b"".join(struct.pack("<f", rng.uniform(-100, 100)) for _ in range(nx)))
+    d.label("ys")
+    d.data(b"".join(struct.pack("<f", rng.uniform(-100, 100)) for _ in range(nx)))
+    d.align_data(8)
+    d.label("xd")
+    d.data(b"".join(struct.pack("<d", rng.uniform(-1e3, 1e3)) for _ in range(nx)))
+    d.label("yd")
+    d.data(b"".join(struct.pack("<d", rng.choice([rng.uniform(-1e3, 1e3), 1e300, -1e300, 5e-324, float("inf"), float("nan")])) for _ in range(nx)))
+    d.align_data(64)
+    d.label("arena")
+    d.data(bytes(rng.getrandbits(8) for _ in range(0x2000)))
+    S = d.symbols
+    ARENA = S["arena"]
+
+    H1, H2 = 30, 31
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    a.csrr(H1, CSR["mepc"]); a.addi(H1, H1, 4); a.csrw(CSR["mepc"], H1); a.mret()      # every instruction of the body is 4 bytes
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    if seed % 5 == 4:
+        a.vsetvli(6, 0, Asm.vtype(32, 1)); a.vop(0x00, 0, 1, 2, 3)          # VS still Off: both illegal
+    a.li(5, 0x2200); a.csrs(CSR["mstatus"], 5)                               # FS and VS on
+    a.vop(0x00, 0, 1, 2, 3)                                                  # vtype.vill at reset: illegal
+    a.csrr(6, 0xC21); a.csrr(6, 0xC22); a.csrr(6, 0xC20)
+
+    # ---- saxpy: y[i] += a * x[i] (e32) then daxpy (e64), strip-mined
+    for sew, xs, ys, ld in ((32, "xs", "ys", a.flw), (64, "xd", "yd", a.fld)):
+        lm = rng.choice([1, 2, 4, 8])
+        a.li(10, rng.randrange(60, nx)); a.li(11, S[xs]); a.li(12, S[ys]); a.li(13, S[xs] + 4 * (sew // 32)); ld(1, 0, 13)
+        top = a.here()
+        a.vsetvli(14, 10, Asm.vtype(sew, lm, ta=bool(rng.getrandbits(1)), ma=bool(rng.getrandbits(1))))
+        a.vle(sew, 8, 11); a.vle(sew, 16, 12)
+        a.vop(_V_FP["vfmacc"], 5, 16, 8, 1)                                  # vfmacc.vf v16, f1, v8
+        a.vse(sew, 16, 12)
+        a.slli(15, 14, sew // 32 + 1); a.add(11, 11, 15); a.add(12, 12, 15); a.sub(10, 10, 14)
+        a.bnez(10, top)
+        # ordered and unordered sums of what was just computed
+        a.vsetvli(14, 0, Asm.vtype(sew, lm, ta=True)); a.li(12, S[ys]); a.vle(sew, 16, 12)
+        a.vop(0x17, 4, 24, 0, 0)                                             # vmv.v.x v24, x0
+        a.vop(0x03, 1, 25, 16, 24); a.vop(0x01, 1, 26, 16, 24)               # vfredosum / vfredusum
+        a.vop(0x10, 1, 2, 25, 0)                                             # vfmv.f.s f2, v25
+
+    regs = [r for r in range(5, 28)]
+    P = 9
+    for r in regs:
+        a.li(r, rng.choice([rng.getrandbits(64), rng.getrandbits(8), ARENA + 8 * rng.randrange(0x300), 0, MASK64]))
+    cur = dict(sew=8, lmul=1)
+
+    def vreg(group_aligned=True):
+        lm = cur["lmul"] if isinstance(cur["lmul"], int) else 1
+        if group_aligned and rng.random() < 0.9:
+            return rng.randrange(0, 32 // lm) * lm
+        return rng.randrange(32)
+
+    for i in range(n):
+        k = rng.random()
+        vm = 1 if rng.random() < 0.7 else 0
+        if k < 0.14:
+            sew = rng.choice([8, 16, 32, 64]); lmul = rng.choice([1, 1, 2, 4, 8, "mf2", "mf4", "mf8"])
+            cur.update(sew=sew, lmul=lmul)
+            vt = Asm.vtype(sew, lmul, ta=bool(rng.getrandbits(1)), ma=bool(rng.getrandbits(1)))
+            r = rng.random()
+            if r < 0.5:
+                a.li(P, rng.choice([rng.randrange(0, 70), rng.randrange(0, 600), MASK64])); a.vsetvli(rng.choice([0, 6]), rng.choice([0, P, P]), vt)
+            elif r < 0.8:
+                a.vsetivli(6, rng.randrange(32), vt)
+            else:
+                a.li(P, rng.randrange(0, 300)); a.li(7, rng.choice([vt, vt, vt | 0x100, 4, 1 << 63, rng.getrandbits(8)])); a.vsetvl(6, rng.choice([0, P]), 7)
+        elif k < 0.32:
+            eew = rng.choice([8, 16, 32, 64, cur["sew"], cur["sew"]])
+            t = rng.choice([ARENA + rng.randrange(0x1800), ARENA + 8 * rng.randrange(0x300), ARENA + 0x2000 - rng.randrange(64), BASE + (1 << 16) - rng.randrange(1, 40),
+                            0x1000, ARENA + 64 * rng.randrange(0x40)])
+            if rng.random() < 0.01:
+                t = S["tohost"] - rng.randrange(1, 30)                       # a vector store that runs into tohost (may end the run)
+            if rng.random() < 0.7:
+                t -= t % (eew // 8)
+            a.li(P, t)
+            if rng.random() < 0.5:
+                a.vle(eew, vreg(), P, vm)
+            else:
+                a.vse(eew, vreg(), P, vm)
+        elif k < 0.60:
+            name = rng.choice(list(_V_INT_VVXI) + list(_V_INT_VVX) + ["vrsub"])
+            if name == "vrsub":
+                f6, forms = 0x03, [4, 3]
+            elif name in _V_INT_VVXI:
+                f6, forms = _V_INT_VVXI[name], [0, 4, 3]
+            else:
+                f6, forms = _V_INT_VVX[name], [0, 4]
+            f3 = rng.choice(forms)
+            a.vop(f6, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
+        elif k < 0.68:
+            name = rng.choice(list(_V_MUL)); f3 = rng.choice([2, 6])
+            a.vop(_V_MUL[name], f3, vreg(), vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+        elif k < 0.76:
+            r = rng.random()
+            if r < 0.35:
+                f3 = rng.choice([0, 4, 3]); a.vop(0x17, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), 0)   # vmerge
+            elif r < 0.7:
+                f3 = rng.choice([0, 4, 3]); a.vop(0x17, f3, vreg(), rng.choice([0, 0, 0, 3]), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), 1)   # vmv.v.*
+            elif r < 0.8:
+                a.vop(0x14, 2, vreg(), rng.choice([0, 0, 0, 2]), 0x11, vm)    # vid.v
+            elif r < 0.9:
+                a.vop(0x10, 2, rng.choice(regs), vreg(False), 0, rng.choice([1, 1, 1, 0]))      # vmv.x.s
+            else:
+                a.vop(0x10, 6, vreg(False), rng.choice([0, 0, 0, 1]), rng.choice(regs), rng.choice([1, 1, 1, 0]))   # vmv.s.x
+        elif k < 0.82:
+            a.vop(_V_RED[rng.choice(list(_V_RED))], 2, vreg(False), vreg(), vreg(False), vm)
+        elif k < 0.93:
+            r = rng.random()
+            if r < 0.6:
+                name = rng.choice(list(_V_FP)); f3 = rng.choice([1, 5])
+                a.vop(_V_FP[name], f3, vreg(), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
+            elif r < 0.7:
+                a.vop(rng.choice([0x27, 0x21]), 5, vreg(), vreg(), rng.randrange(32), vm)        # vfrsub / vfrdiv
+            elif r < 0.8:
+                a.vop(rng.choice([0x01, 0x03]), 1, vreg(False), vreg(), vreg(False), vm)          # vfredusum / vfredosum
+            elif r < 0.87:
+                a.vop(0x17, 5, vreg(), 0, rng.randrange(32), 1)                                   # vfmv.v.f
+            elif r < 0.94:
+                a.vop(0x10, 1, rng.randrange(32), vreg(False), 0, 1)                              # vfmv.f.s
+            else:
+                a.vop(0x10, 5, vreg(False), 0, rng.randrange(32), 1)                              # vfmv.s.f
+        elif k < 0.97:
+            r = rng.random()
+            if r < 0.3:
+                a.li(P, rng.randrange(0, 40)); a.csrw(0x008, P)                                   # vstart: the next arithmetic op traps, a load / store resumes
+            elif r < 0.5:
+                a.li(P, rng.getrandbits(3)); a.csrw(rng.choice([0x009, 0x00A, 0x00F]), P)
+            elif r < 0.7:
+                a.li(P, rng.choice([0, 1, 2, 3, 4, 5]) << 5); a.csrw(CSR["fcsr"], P)              # rounding mode (5: invalid -> FP vector ops trap)
+            else:
+                a.csrr(rng.choice(regs), rng.choice([0x008, 0x009, 0x00A, 0x00F, 0xC20, 0xC21, 0xC22, CSR["mstatus"], CSR["fcsr"]]))
+        else:
+            getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
+    if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x18, 0, 4, 8, 12)         # vmseq.vv
+    _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
+    assert a.here() < data_base
+    return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
