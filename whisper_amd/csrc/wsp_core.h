@@ -592,7 +592,7 @@ template <class MEM> struct Lane {
   WSP_HD static u32 af_cause(u32 acc) { return acc == 4 ? 1u : acc == 1 ? 5u : 7u; }         // accessFaultType (VirtMem.cpp:57-66)
   // VirtMem::pageTableWalk<Pte39, Va39> (VirtMem.cpp:694-892) behind the canonical-address check (:393-397).
   // acc: 1 read 2 write 4 exec.  On success pa and the new TLB entry words.
-  WSP_HD u32 page_walk(u64 va, u32 pm, u32 acc, bool ad_check, u64& pa, u64& e0, u64& e1)
+  WSP_HDN u32 page_walk(u64 va, u32 pm, u32 acc, bool ad_check, u64& pa, u64& e0, u64& e1)
   {
     const u32 pf = pf_cause(acc);
     if ((u64)(((i64)va << 25) >> 25) != va) return pf;
@@ -646,7 +646,7 @@ template <class MEM> struct Lane {
     return true;
   }
   // VirtMem::translate (VirtMem.cpp:261-329): 0 or the exception cause
-  WSP_HD u32 translate(u64 va, u32 pm, u32 acc, u64& pa)
+  WSP_HDN u32 translate(u64 va, u32 pm, u32 acc, u64& pa)
   {
     pa = va;
     const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
@@ -668,7 +668,7 @@ template <class MEM> struct Lane {
     return 0;
   }
   // VirtMem::transAddrNoUpdate (VirtMem.cpp:143-205)
-  WSP_HD u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa)
+  WSP_HDN u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa)
   {
     pa = va;
     const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
@@ -685,9 +685,9 @@ template <class MEM> struct Lane {
     return cause;
   }
   // Tlb::setMode on a satp.MODE change (Tlb.hpp:378-383) / Tlb::invalidate: valid and counter cleared, the rest kept
-  WSP_HD void tlb_invalidate_all() { for (u32 i = 0; i < tlb_n; ++i) m.tlb(2 * i) &= ~((3ULL << 54) | ((u64)TE_VALID << 56)); }
+  WSP_HDN void tlb_invalidate_all() { for (u32 i = 0; i < tlb_n; ++i) m.tlb(2 * i) &= ~((3ULL << 54) | ((u64)TE_VALID << 56)); }
   // execSfence_vma's TLB part (Hart.cpp:12139-12173; Tlb.hpp:176-284): entries are matched whether or not they are valid
-  WSP_HD void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v)
+  WSP_HDN void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v)
   {
     const u64 KEEP = ~((3ULL << 54) | ((u64)TE_VALID << 56));
     const u64 asid = asid_v & 0xffffffffULL, vpn = addr >> 12;
@@ -1259,7 +1259,7 @@ template <class MEM> struct Lane {
     m.cold(CI_VSTART) = ix & (vlenb * 8 - 1); s.chg |= CH_GEN; s.gen_csr = C_VSTART;
     take_exception(cause, cur_pc, tval, false);
   }
-  WSP_HD void v_load_unit(const Rec& r, u64 base, u64 cur_pc, u32 eew)
+  WSP_HD void v_load_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided)
   {
     const VCfg c = vcfg();
     const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
@@ -1268,10 +1268,11 @@ template <class MEM> struct Lane {
     if (!v_check_emul(r, cur_pc, gx8, vd, 0, 0)) return;
     const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
     const u32 single = vlenb >> eew, vlmax = c.gx8 * vlenb / (8u << c.esz), elem_max = vlmax > single ? vlmax : single;   // elemMax(eew)
-    u64 addr = base + (u64)start * esz;
+    const u64 stride = strided ? stride_reg : esz;                              // vector-ls.cpp:939-1040: the same loop stepping by x[rs2]
+    u64 addr = base + (u64)start * stride;
     if (gx8 < 8) gx8 = 8;
     if (start < c.vl)
-      for (u32 ix = start; ix < elem_max; ++ix, addr += esz) {
+      for (u32 ix = start; ix < elem_max; ++ix, addr += stride) {
         u64 elem;
         if (!v_dest_active(c, vd, ix, eew, masked, elem)) { vwr(vd, ix, eew, gx8, elem); continue; }
         u64 pa1, pa2, tval;
@@ -1283,7 +1284,7 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
-  WSP_HD void v_store_unit(const Rec& r, u64 base, u64 cur_pc, u32 eew)
+  WSP_HD void v_store_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided)
   {
     const VCfg c = vcfg();
     const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
@@ -1291,8 +1292,9 @@ template <class MEM> struct Lane {
     if (!v_ldst_legal(c, inst, eew, gx8)) { vec_fail(r, cur_pc); return; }
     if (!v_check_emul(r, cur_pc, gx8, vd, 0, 0)) return;
     const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
-    u64 addr = base + (u64)start * esz;
-    for (u32 ix = start; ix < c.vl; ++ix, addr += esz) {
+    const u64 stride = strided ? stride_reg : esz;
+    u64 addr = base + (u64)start * stride;
+    for (u32 ix = start; ix < c.vl; ++ix, addr += stride) {
       if (masked && !v_mask_bit(ix)) continue;
       const u64 elem = vrd(vd, ix, eew);
       u64 pa1, pa2, tval;
@@ -1427,6 +1429,65 @@ template <class MEM> struct Lane {
     if (0 < c.vl) { vwr(vd, 0, c.esz, 8, val & ones_of(c.esz)); if (c.ta) for (u32 i = 1; i < (vlenb >> c.esz); ++i) vwr(vd, i, c.esz, 8, ones_of(c.esz)); }
     vec_success();
   }
+  // ---- integer compares into a mask register (vector.cpp:1985-2800) and mask logicals (vector-mask.cpp:14-120)
+  WSP_HD void v_wr_mask_bit(u32 reg, u32 ix, bool v)                             // VecRegs::writeMaskRegister (VecRegs.hpp:817-838)
+  {
+    const u32 o = reg * vlenb + (ix >> 3); const u64 byte = m.vld(o, 0), bit = 1u << (ix & 7);
+    m.vst(o, 0, v ? (byte | bit) : (byte & ~bit));
+    if (s.vgroup == 0) { s.vgroup = 1; s.chg |= CH_VREG; }
+  }
+  WSP_HD bool v_rd_mask_bit(u32 reg, u32 ix) { return (m.vld(reg * vlenb + (ix >> 3), 0) >> (ix & 7)) & 1; }
+  enum { VC_EQ, VC_NE, VC_LTU, VC_LT, VC_LEU, VC_LE, VC_GTU, VC_GT };
+  WSP_HD static bool vc_op(u32 op, u64 a, u64 b, u32 esz)
+  {
+    const u32 sh = 64 - (8u << esz);
+    const i64 sa = (i64)(a << sh) >> sh, sb = (i64)(b << sh) >> sh;
+    const u64 ua = a & ones_of(esz), ub = b & ones_of(esz);
+    switch (op) {
+      case VC_EQ: return ua == ub; case VC_NE: return ua != ub; case VC_LTU: return ua < ub; case VC_LT: return sa < sb;
+      case VC_LEU: return ua <= ub; case VC_LE: return sa <= sb; case VC_GTU: return ua > ub; default: return sa > sb;
+    }
+  }
+  // execVmseq_vv ... execVmsgt_vi behind checkVecMaskInst (vector.cpp:366-458).  kind: 0 vv 1 vx 2 vi
+  WSP_HD void v_int_compare(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    if (masked && (vs2 == 0 || (kind == 0 && vs1 == 0))) { vec_fail(r, cur_pc); return; }
+    if (vs2 < vd + 1 && vd < vs2 + eg && vd != vs2) { vec_fail(r, cur_pc); return; }          // mask destination inside a source group
+    if (kind == 0 && vs1 < vd + 1 && vd < vs1 + eg && vd != vs1) { vec_fail(r, cur_pc); return; }
+    if ((vs2 | (kind == 0 ? vs1 : 0)) & (eg - 1)) { vec_fail(r, cur_pc); return; }
+    if (0 < c.vl) {
+      for (u32 ix = 0; ix < c.vl; ++ix) {                                       // isMaskDestActive (VecRegs.hpp:762-780)
+        bool flag = v_rd_mask_bit(vd, ix);
+        if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
+        else flag = vc_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
+        v_wr_mask_bit(vd, ix, flag);
+      }
+      for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);    // finishMaskDest (VecRegs.hpp:639-646)
+    }
+    vec_success();
+  }
+  WSP_HD void v_mask_logical(const Rec& r, u64 cur_pc, u32 k)                   // vector-mask.cpp:14-120; k = funct6 - 0x18
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31;
+    if (!((inst >> 25) & 1)) { vec_fail(r, cur_pc); return; }
+    if (0 < c.vl) {
+      for (u32 ix = 0; ix < c.vl; ++ix) {
+        const bool a = v_rd_mask_bit(vs2, ix), b = v_rd_mask_bit(vs1, ix); bool z;
+        switch (k) { case 0: z = a && !b; break; case 1: z = a && b; break; case 2: z = a || b; break; case 3: z = a != b; break;
+                     case 4: z = a || !b; break; case 5: z = !(a && b); break; case 6: z = !(a || b); break; default: z = a == b; break; }
+        v_wr_mask_bit(vd, ix, z);
+      }
+      for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);
+    }
+    if (s.vgroup == 0) { s.vgroup = 1; s.chg |= CH_VREG; }                      // touchMask
+    vec_success();
+  }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
   WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
   WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
@@ -1487,7 +1548,7 @@ template <class MEM> struct Lane {
     return true;
   }
   // dispatch: OP-V.  a = x[rs1], b = x[rs2]
-  WSP_HD void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc)
+  WSP_HDN void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc)
   {
     const u32 inst = r.raw, f3 = (inst >> 12) & 7, f6 = inst >> 26, rd = (inst >> 7) & 31, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31;
     const bool vm = (inst >> 25) & 1;
@@ -1521,6 +1582,9 @@ template <class MEM> struct Lane {
         case 0x17:
           if (vm && rs2 != 0) { illegal(r, cur_pc); return; }                   // Decoder.cpp:336-343
           v_merge_mv(r, cur_pc, kind, sc); return;
+        case 0x18: case 0x19: case 0x1c: case 0x1d: v_int_compare(r, cur_pc, f6 == 0x18 ? VC_EQ : f6 == 0x19 ? VC_NE : f6 == 0x1c ? VC_LEU : VC_LE, kind, sc); return;
+        case 0x1a: case 0x1b: if (kind == 2) break; v_int_compare(r, cur_pc, f6 == 0x1a ? VC_LTU : VC_LT, kind, sc); return;
+        case 0x1e: case 0x1f: if (kind == 0) break; v_int_compare(r, cur_pc, f6 == 0x1e ? VC_GTU : VC_GT, kind, sc); return;
         default: break;
       }
       if (op >= 0) { v_int_arith(r, cur_pc, (u32)op, kind, sc); return; }
@@ -1551,6 +1615,7 @@ template <class MEM> struct Lane {
         if (0 < c.vl) for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, rd, ix, c.esz, !vm, d)) d = ix & ones_of(c.esz); vwr(rd, ix, c.esz, dg, d); }
         vec_success(); return;
       }
+      if (f6 >= 0x18 && f6 <= 0x1f && !vx) { v_mask_logical(r, cur_pc, f6 - 0x18); return; }
       if (f6 == 0x25) { v_int_arith(r, cur_pc, VI_MUL, vx ? 1 : 0, a); return; }
       if (f6 == 0x2d) { v_int_muladd(r, cur_pc, 0, vx, a); return; }
       if (f6 == 0x2f) { v_int_muladd(r, cur_pc, 1, vx, a); return; }
@@ -1595,14 +1660,14 @@ template <class MEM> struct Lane {
     }
     vec_unsupported(inst);
   }
-  // vector loads / stores: unit-stride, nf = 0, mew = 0 only.  a = x[rs1]
-  WSP_HD void exec_vector_ldst(const Rec& r, u64 a, u64 cur_pc, bool store)
+  // vector loads / stores: unit-stride and strided, nf = 0, mew = 0 only.  a = x[rs1], b = x[rs2]
+  WSP_HDN void exec_vector_ldst(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store)
   {
-    const u32 inst = r.raw, f3 = (inst >> 12) & 7;
+    const u32 inst = r.raw, f3 = (inst >> 12) & 7, mop = (inst >> 26) & 3;
     s.vreg = (inst >> 7) & 31;
-    if (((inst >> 26) & 3) != 0 || ((inst >> 20) & 31) != 0 || (inst >> 29) != 0 || ((inst >> 28) & 1) != 0) { vec_unsupported(inst); return; }
+    if ((!(mop == 0 && ((inst >> 20) & 31) == 0) && mop != 2) || (inst >> 29) != 0 || ((inst >> 28) & 1) != 0) { vec_unsupported(inst); return; }
     const u32 eew = f3 == 0 ? 0 : f3 - 4;
-    if (store) v_store_unit(r, a, cur_pc, eew); else v_load_unit(r, a, cur_pc, eew);
+    if (store) v_store_unit(r, a, b, cur_pc, eew, mop == 2); else v_load_unit(r, a, b, cur_pc, eew, mop == 2);
   }
 
   // ---- the common, trap-free subset executed inline in the GPU hot loop (caller guarantees HF_HOT).
@@ -1814,8 +1879,8 @@ template <class MEM> struct Lane {
       case OP_FCMP: case OP_FCVT_F2I: case OP_FCVT_I2F: case OP_FCVT_FF: case OP_FMV_F2X: case OP_FCLASS: case OP_FMV_X2F:
         exec_fp(r, a, cur_pc); break;
       case OP_VEC: exec_vector(r, a, b, cur_pc); break;
-      case OP_VLD: exec_vector_ldst(r, a, cur_pc, false); break;
-      case OP_VST: exec_vector_ldst(r, a, cur_pc, true); break;
+      case OP_VLD: exec_vector_ldst(r, a, b, cur_pc, false); break;
+      case OP_VST: exec_vector_ldst(r, a, b, cur_pc, true); break;
       default: illegal(r, cur_pc); break;
     }
   }

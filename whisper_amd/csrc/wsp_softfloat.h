@@ -16,8 +16,10 @@
 #ifndef WSP_HD
 #  if defined(__HIPCC__) || defined(__CUDACC__)
 #    define WSP_HD __host__ __device__ __forceinline__
+#    define WSP_HDN __host__ __device__ __attribute__((noinline))     /* large, rarely taken paths: kept out of their callers' register budget */
 #  else
 #    define WSP_HD inline
+#    define WSP_HDN inline
 #  endif
 #endif
 

@@ -290,6 +290,12 @@ class Asm:
         """Generic OP-V: funct6, funct3 (0 OPIVV 1 OPFVV 2 OPMVV 3 OPIVI 4 OPIVX 5 OPFVF 6 OPMVX), vd, vs2, vs1 / rs1 / imm5, vm (0 = masked by v0)."""
         self._emit32((f6 << 26) | ((vm & 1) << 25) | ((vs2 & 31) << 20) | ((s1 & 31) << 15) | (f3 << 12) | ((vd & 31) << 7) | 0x57)
 
+    def vlse(self, eew, vd, rs1, rs2, vm=1):
+        self._emit32((2 << 26) | ((vm & 1) << 25) | (rs2 << 20) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vd << 7) | 0x07)
+
+    def vsse(self, eew, vs3, rs1, rs2, vm=1):
+        self._emit32((2 << 26) | ((vm & 1) << 25) | (rs2 << 20) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vs3 << 7) | 0x27)
+
     def vle(self, eew, vd, rs1, vm=1):
         self._emit32(((vm & 1) << 25) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vd << 7) | 0x07)
 
