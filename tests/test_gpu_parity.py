@@ -192,6 +192,57 @@ def test_rvv_programs(vlenb):
     assert any(r["status"] == W.ST_STOP_UNSUPPORTED and (r["value"] >> 17) & 1 for r in res)
 
 
+def _replicated(progs, reps, lanes=0, trace=True):
+    """Every program loaded into `reps` consecutive harts: returns (results, seconds in the step kernel)."""
+    p0 = progs[0]
+    n = len(progs) * reps
+    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0),
+                vlen_bytes=p0.meta.get("vlenb", 0))
+    try:
+        for i, p in enumerate(progs):
+            b.load_elf_bytes(p.elf, i * reps, (i + 1) * reps)
+            b.set_stop(max_inst=p.max_inst, lo=i * reps, hi=(i + 1) * reps)
+        left = b.run(W.NO_LIMIT, trace_hash=trace)
+        assert left == 0
+        secs = b.run_stats()[0]
+        return [r.as_dict() for r in b.results()], secs
+    finally:
+        b.close()
+
+
+def test_rvv_16384_harts():
+    """BASELINE config 3 size: 16384 harts (64 vector programs x 256 replicas, 64 lanes per wave).  One replica of every
+    program is checked against the oracle; the size-independent property for the rest is determinism: all replicas of a
+    program end with identical digests wherever they sit in the batch."""
+    progs = [WL.rvv_program(s) for s in range(64)]
+    reps = 256
+    res, secs = _replicated(progs, reps)
+    total = sum(r["exec"] for r in res)
+    print(f"rvv 16384 harts: {total} instructions in {secs:.3f} s = {total / secs / 1e9:.3f} GIPS")
+    for i, p in enumerate(progs):
+        ro, _, _ = S.run_oracle(p, hart_id=i * reps)
+        assert res[i * reps] == ro, p.name
+        first = dict(res[i * reps])
+        for k in range(1, reps):
+            assert res[i * reps + k] == first, (p.name, k)      # mhartid is not read by these programs
+
+
+def test_sv39_100k_harts():
+    """Towards BASELINE config 4 (125 000 fuzz programs per GPU under Sv39): 102 400 harts (200 paging programs x 512
+    replicas, 8-entry TLBs, 256 KiB arenas = 25 GiB).  Oracle check of one replica per program, determinism for the rest."""
+    progs = [WL.sv39_program(s) for s in range(200)]
+    reps = 512
+    res, secs = _replicated(progs, reps)
+    total = sum(r["exec"] for r in res)
+    print(f"sv39 102400 harts: {total} instructions in {secs:.3f} s = {total / secs / 1e9:.3f} GIPS")
+    for i, p in enumerate(progs):
+        ro, _, _ = S.run_oracle(p, hart_id=i * reps)
+        assert res[i * reps] == ro, p.name
+        first = dict(res[i * reps])
+        for k in range(1, reps):
+            assert res[i * reps + k] == first, (p.name, k)
+
+
 def test_pmp_csr_peek_poke():
     """pmpcfg / pmpaddr through the C-ABI poke/peek: masks, per-byte legalisation and locks as CsRegs / PmpManager."""
     p = WL.readme_program()
