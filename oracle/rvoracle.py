@@ -179,6 +179,10 @@ class Hart:
         n = self.L.rvo_get_vreg(self.h, i, buf)
         return buf.raw[:n]
 
+    def set_vreg(self, i, data: bytes):
+        self.L.rvo_set_vreg.argtypes = [C.c_void_p, C.c_uint, C.c_char_p]
+        self.L.rvo_set_vreg(self.h, i, bytes(data))
+
     def translate(self, va, pm, acc):
         """(cause, pa) of VirtMem::translate for privilege pm and access acc (1 r, 2 w, 4 x)."""
         pa = C.c_uint64()

@@ -1429,6 +1429,36 @@ template <class MEM> struct Lane {
     if (0 < c.vl) { vwr(vd, 0, c.esz, 8, val & ones_of(c.esz)); if (c.ta) for (u32 i = 1; i < (vlenb >> c.esz); ++i) vwr(vd, i, c.esz, 8, ones_of(c.esz)); }
     vec_success();
   }
+  // widening integer add / sub / mul (vector.cpp:1170-1560, 5270-5715).  op: 0 add 1 sub 2 mul; sa / sb: vs2 element / second operand signed
+  WSP_HD void v_int_widen(const Rec& r, u64 cur_pc, u32 op, bool sa, bool sb, bool vx, u64 xs)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, !vx)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 wg = c.gx8 * 2;
+    if (wg > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }                 // isDoubleWideLegal (VecRegs.hpp:261-274)
+    const u32 dsz = c.esz + 1, vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
+    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1, ewg = wg >= 8 ? wg / 8 : 1;
+    bool ok = !(vd & (ewg - 1)) && !(vs2 & (eg - 1)) && (vx || !(vs1 & (eg - 1)));      // checkVecOpsVsEmul, wide destination (vector.cpp:461-527)
+    for (u32 k = 0; k < (vx ? 1u : 2u); ++k) {                                  // checkDestSourceOverlap (vector.cpp:323-345)
+      const u32 src = k == 0 ? vs2 : vs1;
+      if (!(src >= vd + ewg || vd >= src + eg)) ok = ok && c.gx8 >= 8 && src == vd + ewg - eg;
+    }
+    if (!ok) { vec_fail(r, cur_pc); return; }
+    const u32 dg = wg < 8 ? 8 : wg, sh = 64 - (8u << c.esz);
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < elems; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, dsz, masked, d)) {
+          const u64 a = sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
+          const u64 braw = vx ? (xs & ones_of(c.esz)) : vrd(vs1, ix, c.esz);
+          const u64 b = sb ? (u64)((i64)(braw << sh) >> sh) : braw;
+          d = (op == 0 ? a + b : op == 1 ? a - b : a * b) & ones_of(dsz);
+        }
+        vwr(vd, ix, dsz, dg, d);
+      }
+    vec_success();
+  }
   // ---- integer compares into a mask register (vector.cpp:1985-2800) and mask logicals (vector-mask.cpp:14-120)
   WSP_HD void v_wr_mask_bit(u32 reg, u32 ix, bool v)                             // VecRegs::writeMaskRegister (VecRegs.hpp:817-838)
   {
@@ -1617,6 +1647,10 @@ template <class MEM> struct Lane {
       }
       if (f6 >= 0x18 && f6 <= 0x1f && !vx) { v_mask_logical(r, cur_pc, f6 - 0x18); return; }
       if (f6 == 0x25) { v_int_arith(r, cur_pc, VI_MUL, vx ? 1 : 0, a); return; }
+      if (f6 >= 0x30 && f6 <= 0x33) { v_int_widen(r, cur_pc, f6 >> 1 & 1, f6 & 1, f6 & 1, vx, a); return; }     // vwaddu vwadd vwsubu vwsub
+      if (f6 == 0x38) { v_int_widen(r, cur_pc, 2, false, false, vx, a); return; }                              // vwmulu
+      if (f6 == 0x3a) { v_int_widen(r, cur_pc, 2, true, false, vx, a); return; }                               // vwmulsu
+      if (f6 == 0x3b) { v_int_widen(r, cur_pc, 2, true, true, vx, a); return; }                                // vwmul
       if (f6 == 0x2d) { v_int_muladd(r, cur_pc, 0, vx, a); return; }
       if (f6 == 0x2f) { v_int_muladd(r, cur_pc, 1, vx, a); return; }
       if (f6 == 0x29) { v_int_muladd(r, cur_pc, 2, vx, a); return; }

@@ -1136,16 +1136,21 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         elif k < 0.66:
             name = rng.choice(list(_V_MUL)); f3 = rng.choice([2, 6])
             a.vop(_V_MUL[name], f3, vreg(), vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
-        elif k < 0.68:
+        elif k < 0.70:
             r = rng.random()
-            if r < 0.75:                                                     # compares into a mask register (often v0), then used as masks
+            if r < 0.6:                                                     # compares into a mask register (often v0), then used as masks
                 f6 = rng.choice([0x18, 0x19, 0x1A, 0x1B, 0x1C, 0x1D, 0x1E, 0x1F])
                 forms = [0, 4, 3] if f6 in (0x18, 0x19, 0x1C, 0x1D) else [0, 4] if f6 in (0x1A, 0x1B) else [4, 3]
                 f3 = rng.choice(forms)
                 a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
-            else:
+            elif r < 0.88:
                 a.vop(rng.choice(range(0x18, 0x20)), 2, rng.choice([0, vreg(False)]), vreg(False), vreg(False), rng.choice([1, 1, 1, 0]))   # vmand.mm ...
-        elif k < 0.76:
+            else:                                                            # widening add / sub / mul: destination group twice as wide
+                lm = cur["lmul"] if isinstance(cur["lmul"], int) else 1
+                vdw = rng.randrange(0, 32 // min(2 * lm, 16)) * min(2 * lm, 16) if rng.random() < 0.85 else rng.randrange(32)
+                f3 = rng.choice([2, 6])
+                a.vop(rng.choice([0x30, 0x31, 0x32, 0x33, 0x38, 0x3A, 0x3B]), f3, vdw % 32, vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+        elif k < 0.77:
             r = rng.random()
             if r < 0.35:
                 f3 = rng.choice([0, 4, 3]); a.vop(0x17, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), 0)   # vmerge
@@ -1187,7 +1192,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x30, 2, 4, 8, 12)         # vwaddu.vv
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x0C, 0, 4, 8, 12)         # vrgather.vv
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
