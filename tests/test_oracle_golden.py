@@ -205,3 +205,48 @@ def test_rvv_widening_known_answers():
         h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
         h.run(3)
         assert h.csr(0x342) == 2, (sew, vd, vs2)
+
+
+def test_rvv_fp_known_answers():
+    """The eight vector multiply-add forms, vfmin / vfmax, vfsgnj* and the FP compares at SEW 32 / 64 against numpy on exactly
+    representable operands plus NaN / signed-zero cases (semantics from the V spec; parity unpinned beyond that)."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(9)
+    for sew, ft, ut in [(32, np.float32, np.uint32), (64, np.float64, np.uint64)]:
+        n = 512 // sew
+        A = rng.integers(-40, 40, n).astype(ft); B = rng.integers(-40, 40, n).astype(ft); D = rng.integers(-40, 40, n).astype(ft)
+        A[0], B[0] = np.nan, 1.0; A[1], B[1] = 0.0, -0.0; A[2], B[2] = -0.0, 0.0; A[3], B[3] = np.nan, np.nan; B[4] = A[4]
+
+        def run(f6, f3=1, vd_init=None):
+            a = Asm(0x80000000)
+            a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(f6, f3, 4, 8, 9)
+            h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+            h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+            h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes()); h.set_vreg(4, (D if vd_init is None else vd_init).tobytes())
+            h.run(3)
+            return h
+        # vs2 = A, vs1 = B, vd = D
+        fma = {0x28: B * D + A, 0x29: -(B * D) - A, 0x2A: B * D - A, 0x2B: -(B * D) + A, 0x2C: B * A + D, 0x2D: -(B * A) - D, 0x2E: B * A - D,
+               0x2F: -(B * A) + D}
+        for f6, want in fma.items():
+            got = np.frombuffer(run(f6).vreg(4), dtype=ft)
+            ok = (got == want) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), (sew, hex(f6), got, want)
+        with np.errstate(invalid="ignore"):
+            for f6, want in {0x04: np.fmin(A, B), 0x06: np.fmax(A, B)}.items():
+                h = run(f6)
+                got = np.frombuffer(h.vreg(4), dtype=ft)
+                assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), (sew, hex(f6))
+                assert np.signbit(got[1]) == (f6 == 0x04) and np.signbit(got[2]) == (f6 == 0x04)        # min(+0,-0) = -0, max = +0
+                assert got.view(ut)[3] == (0x7fc00000 if sew == 32 else 0x7ff8000000000000)
+                assert h.csr(0x003) & 0x1f == 0                                                       # quiet NaNs raise nothing
+            for f6, want in {0x08: np.copysign(A, B), 0x09: np.copysign(A, -B), 0x0A: np.copysign(A, np.where(np.signbit(A) ^ np.signbit(B), -1.0, 1.0))}.items():
+                got = np.frombuffer(run(f6).vreg(4), dtype=ut)
+                assert (got == want.astype(ft).view(ut)).all(), (sew, hex(f6))
+            cmp_ = {0x18: A == B, 0x19: A <= B, 0x1B: A < B, 0x1C: A != B}
+            for f6, want in cmp_.items():
+                h = run(f6)
+                bits = int.from_bytes(h.vreg(4), "little")
+                assert [(bits >> i) & 1 for i in range(n)] == [int(w) for w in want], (sew, hex(f6))
+                assert (h.csr(0x003) & 0x10 != 0) == (f6 in (0x19, 0x1B))                              # le / lt signal on quiet NaNs

@@ -1479,16 +1479,23 @@ template <class MEM> struct Lane {
     }
   }
   // execVmseq_vv ... execVmsgt_vi behind checkVecMaskInst (vector.cpp:366-458).  kind: 0 vv 1 vx 2 vi
+  WSP_HD bool v_check_mask_inst(const VCfg& c, const Rec& r, u64 cur_pc, bool two_src)
+  {
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return false;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    bool ok = !(masked && (vs2 == 0 || (two_src && vs1 == 0)));
+    ok = ok && !(vs2 < vd + 1 && vd < vs2 + eg && vd != vs2);                    // mask destination inside a source group
+    ok = ok && !(two_src && vs1 < vd + 1 && vd < vs1 + eg && vd != vs1);
+    ok = ok && !((vs2 | (two_src ? vs1 : 0)) & (eg - 1));
+    if (!ok) vec_fail(r, cur_pc);
+    return ok;
+  }
   WSP_HD void v_int_compare(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
   {
     const VCfg c = vcfg();
-    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    if (!v_check_mask_inst(c, r, cur_pc, kind == 0)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
-    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1;
-    if (masked && (vs2 == 0 || (kind == 0 && vs1 == 0))) { vec_fail(r, cur_pc); return; }
-    if (vs2 < vd + 1 && vd < vs2 + eg && vd != vs2) { vec_fail(r, cur_pc); return; }          // mask destination inside a source group
-    if (kind == 0 && vs1 < vd + 1 && vd < vs1 + eg && vd != vs1) { vec_fail(r, cur_pc); return; }
-    if ((vs2 | (kind == 0 ? vs1 : 0)) & (eg - 1)) { vec_fail(r, cur_pc); return; }
     if (0 < c.vl) {
       for (u32 ix = 0; ix < c.vl; ++ix) {                                       // isMaskDestActive (VecRegs.hpp:762-780)
         bool flag = v_rd_mask_bit(vd, ix);
@@ -1534,27 +1541,89 @@ template <class MEM> struct Lane {
     if (esz == 2) return op == 0 ? f_add<F32>(a, b, rm, fl) : op == 1 ? f_sub<F32>(a, b, rm, fl) : op == 2 ? f_mul<F32>(a, b, rm, fl) : f_div<F32>(a, b, rm, fl);
     return op == 0 ? f_add<F64>(a, b, rm, fl) : op == 1 ? f_sub<F64>(a, b, rm, fl) : op == 2 ? f_mul<F64>(a, b, rm, fl) : f_div<F64>(a, b, rm, fl);
   }
-  WSP_HD void v_fp_arith(const Rec& r, u64 cur_pc, u32 op, bool vf, bool fma)   // vfadd.. (:655-1990), vfmacc (:2714-2860)
+  // doFmin / doFmax (vector-float.cpp:97-172)
+  template <class F> WSP_HD static u64 vf_minmax(bool mx, u64 a, u64 b, unsigned& fl)
   {
+    using namespace wsf;
+    const bool n1 = is_nan<F>(a), n2 = is_nan<F>(b);
+    u64 z;
+    if (n1 && n2) z = F::QNAN; else if (n1) z = b; else if (n2) z = a;
+    else z = mx ? (lt_ord<F>(b, a) ? a : b) : (lt_ord<F>(a, b) ? a : b);
+    if (is_snan<F>(a) || is_snan<F>(b)) fl |= FL_NV;
+    else if (!n1 && !n2 && ((a ^ b) & F::SIGN) && eq_ord<F>(a, b)) z = mx ? (z & ~(u64)F::SIGN) : (z | F::SIGN);
+    return z;
+  }
+  // vfadd.. (:655-1990) op 0-5; the eight multiply-add forms (:2128-3300) op 8 + (funct6 - 0x28); vfmin / vfmax (:7569-7860) op 16 / 17;
+  // vfsgnj / vfsgnjn / vfsgnjx (:7863-8240) op 18-20
+  WSP_HD void v_fp_arith(const Rec& r, u64 cur_pc, u32 op, bool vf)
+  {
+    using namespace wsf;
     const VCfg c = vcfg(); int rm = 0;
     if (!v_check_int(c, r, cur_pc, !vf)) return;
     if (!v_check_fp(c, r, cur_pc, rm)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, vf ? 0 : vs1)) return;
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
-    const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0;
+    const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0, sign = c.esz == 2 ? 0x80000000ull : 0x8000000000000000ull;
+    const bool w = c.esz == 2;
     unsigned fl = 0;
     if (0 < c.vl)
       for (u32 ix = 0; ix < c.elem_max; ++ix) {
         u64 d;
         if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
-          const u64 e1 = vf ? sc : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz);
-          if (fma) d = c.esz == 2 ? wsf::f_fma<wsf::F32>(e1, e2, vrd(vd, ix, 2), rm, fl) : wsf::f_fma<wsf::F64>(e1, e2, vrd(vd, ix, 3), rm, fl);
-          else d = vf_op(op, e2, e1, c.esz, rm, fl);
+          u64 e1 = vf ? sc : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz);
+          if (op < 8) d = vf_op(op, e2, e1, c.esz, rm, fl);
+          else if (op < 16) {
+            const u32 k = op - 8;
+            u64 dd = vrd(vd, ix, c.esz);
+            if (k & 1) e1 = w ? fneg<F32>(e1, fl) : fneg<F64>(e1, fl);
+            if (k < 4) {                                                         // *madd / *msub: vd is a multiplicand, vs2 the addend
+              if (k == 1 || k == 2) e2 = w ? fneg<F32>(e2, fl) : fneg<F64>(e2, fl);
+              d = w ? f_fma<F32>(e1, dd, e2, rm, fl) : f_fma<F64>(e1, dd, e2, rm, fl);
+            } else {                                                             // *macc / *msac: vd is the addend
+              if (k == 5 || k == 6) dd = w ? fneg<F32>(dd, fl) : fneg<F64>(dd, fl);
+              d = w ? f_fma<F32>(e1, e2, dd, rm, fl) : f_fma<F64>(e1, e2, dd, rm, fl);
+            }
+          }
+          else if (op < 18) d = w ? vf_minmax<F32>(op == 17, e2, e1, fl) : vf_minmax<F64>(op == 17, e2, e1, fl);
+          else d = (e2 & ~sign) | ((op == 18 ? e1 : op == 19 ? ~e1 : e2 ^ e1) & sign);
         }
         vwr(vd, ix, c.esz, dg, d);
       }
     or_fflags(fl);                                                              // updateAccruedFpBits
+    vec_success();
+  }
+  // vmfeq / vmfle / vmflt / vmfne .vv / .vf, vmfgt / vmfge .vf (:4219-4925) behind checkVecFpMaskInst (:335-395).  op: 0 eq 1 le 2 lt 3 ne 4 gt 5 ge
+  WSP_HD void v_fp_compare(const Rec& r, u64 cur_pc, u32 op, bool vf)
+  {
+    using namespace wsf;
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_mask_inst(c, r, cur_pc, !vf)) return;
+    if (!v_fp_legal(c.esz) || !fp_rm(7, rm)) { vec_fail(r, cur_pc); return; }
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0;
+    const bool w = c.esz == 2;
+    unsigned fl = 0;
+    if (0 < c.vl) {
+      for (u32 ix = 0; ix < c.vl; ++ix) {
+        bool flag = v_rd_mask_bit(vd, ix);
+        if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
+        else {
+          const u64 a = vrd(vs2, ix, c.esz), b = vf ? sc : vrd(vs1, ix, c.esz);
+          const bool nan = w ? (is_nan<F32>(a) || is_nan<F32>(b)) : (is_nan<F64>(a) || is_nan<F64>(b));
+          const bool sn = w ? (is_snan<F32>(a) || is_snan<F32>(b)) : (is_snan<F64>(a) || is_snan<F64>(b));
+          flag = op == 3;
+          if (nan) { if (sn || (op != 0 && op != 3)) fl |= FL_NV; }
+          else {
+            const bool lt = w ? lt_ord<F32>(a, b) : lt_ord<F64>(a, b), eq = w ? eq_ord<F32>(a, b) : eq_ord<F64>(a, b);
+            flag = op == 0 ? eq : op == 1 ? (lt || eq) : op == 2 ? lt : op == 3 ? !eq : op == 4 ? (!lt && !eq) : !lt;
+          }
+        }
+        v_wr_mask_bit(vd, ix, flag);
+      }
+      for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);
+    }
+    or_fflags(fl);
     vec_success();
   }
   WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
@@ -1659,13 +1728,23 @@ template <class MEM> struct Lane {
     }
     const bool vf = f3 == 5;                                                    // OPFVV (1) / OPFVF (5)
     switch (f6) {
-      case 0x00: v_fp_arith(r, cur_pc, 0, vf, false); return;
-      case 0x02: v_fp_arith(r, cur_pc, 1, vf, false); return;
-      case 0x24: v_fp_arith(r, cur_pc, 2, vf, false); return;
-      case 0x20: v_fp_arith(r, cur_pc, 3, vf, false); return;
-      case 0x27: if (!vf) break; v_fp_arith(r, cur_pc, 4, true, false); return;
-      case 0x21: if (!vf) break; v_fp_arith(r, cur_pc, 5, true, false); return;
-      case 0x2c: v_fp_arith(r, cur_pc, 0, vf, true); return;
+      case 0x00: v_fp_arith(r, cur_pc, 0, vf); return;
+      case 0x02: v_fp_arith(r, cur_pc, 1, vf); return;
+      case 0x24: v_fp_arith(r, cur_pc, 2, vf); return;
+      case 0x20: v_fp_arith(r, cur_pc, 3, vf); return;
+      case 0x27: if (!vf) break; v_fp_arith(r, cur_pc, 4, true); return;
+      case 0x21: if (!vf) break; v_fp_arith(r, cur_pc, 5, true); return;
+      case 0x28: case 0x29: case 0x2a: case 0x2b: case 0x2c: case 0x2d: case 0x2e: case 0x2f:
+        v_fp_arith(r, cur_pc, 8 + (f6 - 0x28), vf); return;
+      case 0x04: v_fp_arith(r, cur_pc, 16, vf); return;
+      case 0x06: v_fp_arith(r, cur_pc, 17, vf); return;
+      case 0x08: case 0x09: case 0x0a: v_fp_arith(r, cur_pc, 18 + (f6 - 0x08), vf); return;
+      case 0x18: v_fp_compare(r, cur_pc, 0, vf); return;
+      case 0x19: v_fp_compare(r, cur_pc, 1, vf); return;
+      case 0x1b: v_fp_compare(r, cur_pc, 2, vf); return;
+      case 0x1c: v_fp_compare(r, cur_pc, 3, vf); return;
+      case 0x1d: if (!vf) break; v_fp_compare(r, cur_pc, 4, true); return;
+      case 0x1f: if (!vf) break; v_fp_compare(r, cur_pc, 5, true); return;
       case 0x01: case 0x03: if (vf) break; v_fp_redsum(r, cur_pc); return;
       case 0x10: {
         const VCfg c = vcfg();

@@ -1015,7 +1015,9 @@ _V_INT_VVXI = {"vadd": 0x00, "vand": 0x09, "vor": 0x0A, "vxor": 0x0B, "vsll": 0x
 _V_INT_VVX = {"vsub": 0x02, "vminu": 0x04, "vmin": 0x05, "vmaxu": 0x06, "vmax": 0x07}                              # vv vx
 _V_MUL = {"vmul": 0x25, "vmacc": 0x2D, "vnmsac": 0x2F, "vmadd": 0x29, "vnmsub": 0x2B}                              # OPMVV / OPMVX
 _V_RED = {"vredsum": 0, "vredand": 1, "vredor": 2, "vredxor": 3, "vredminu": 4, "vredmin": 5, "vredmaxu": 6, "vredmax": 7}
-_V_FP = {"vfadd": 0x00, "vfsub": 0x02, "vfmul": 0x24, "vfdiv": 0x20, "vfmacc": 0x2C}                                # vv vf
+_V_FP = {"vfadd": 0x00, "vfsub": 0x02, "vfmul": 0x24, "vfdiv": 0x20, "vfmadd": 0x28, "vfnmadd": 0x29, "vfmsub": 0x2A, "vfnmsub": 0x2B,
+         "vfmacc": 0x2C, "vfnmacc": 0x2D, "vfmsac": 0x2E, "vfnmsac": 0x2F, "vfmin": 0x04, "vfmax": 0x06, "vfsgnj": 0x08, "vfsgnjn": 0x09,
+         "vfsgnjx": 0x0A}                                                                                               # vv vf
 
 
 def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
@@ -1166,9 +1168,12 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
             a.vop(_V_RED[rng.choice(list(_V_RED))], 2, vreg(False), vreg(), vreg(False), vm)
         elif k < 0.93:
             r = rng.random()
-            if r < 0.6:
+            if r < 0.5:
                 name = rng.choice(list(_V_FP)); f3 = rng.choice([1, 5])
                 a.vop(_V_FP[name], f3, vreg(), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
+            elif r < 0.6:                                                    # vmfeq vmfle vmflt vmfne (.vv / .vf), vmfgt vmfge (.vf)
+                f6 = rng.choice([0x18, 0x19, 0x1B, 0x1C, 0x1D, 0x1F]); f3 = 5 if f6 in (0x1D, 0x1F) else rng.choice([1, 5])
+                a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
             elif r < 0.7:
                 a.vop(rng.choice([0x27, 0x21]), 5, vreg(), vreg(), rng.randrange(32), vm)        # vfrsub / vfrdiv
             elif r < 0.8:
