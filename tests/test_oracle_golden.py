@@ -250,3 +250,76 @@ def test_rvv_fp_known_answers():
                 bits = int.from_bytes(h.vreg(4), "little")
                 assert [(bits >> i) & 1 for i in range(n)] == [int(w) for w in want], (sew, hex(f6))
                 assert (h.csr(0x003) & 0x10 != 0) == (f6 in (0x19, 0x1B))                              # le / lt signal on quiet NaNs
+
+
+def test_rvv_whole_register_and_mask_ldst():
+    """vl2re32.v / vs2r.v move 2 * VLENB bytes whatever vl / vtype say (even vill); vlm.v / vsm.v move ceil(vl / 8) bytes and fill
+    the rest of the register with ones (the reference forces tail-agnostic); odd register numbers and nf = 3 are illegal."""
+    from whisper_amd.rvasm import Asm
+    import random
+    rng = random.Random(3)
+    blob = bytes(rng.randrange(256) for _ in range(256))
+
+    def hart(build):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5)
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.write_mem(0x80001000, blob); h.pc = 0x80000000
+        h.set_x(5, 0x6600); h.set_x(10, 0x80001000); h.set_x(11, 0x80002000)
+        return h
+    h = hart(lambda a: (a.vsetivli(6, 3, Asm.vtype(16, 1)), a.vls(False, 32, 8, 10, lumop=8, nf=1), a.vls(True, 8, 8, 11, lumop=8, nf=1)))
+    h.run(4)
+    assert h.vreg(8) + h.vreg(9) == blob[:128] and h.read_mem(0x80002000, 128) == blob[:128] and h.read_mem(0x80002080, 8) == bytes(8)
+    h = hart(lambda a: (a.li(7, 1 << 63), a.vsetvl(6, 0, 7), a.vls(False, 8, 4, 10, lumop=8, nf=3)))      # vill: still legal
+    h.run(5)
+    assert h.csr(0xC21) >> 63 == 1 and b"".join(h.vreg(i) for i in range(4, 8)) == blob and h.csr(0x342) == 0
+    for v, nf in [(9, 2), (8, 3), (4, 8)]:
+        h = hart(lambda a: a.vls(False, 8, v, 10, lumop=8, nf=nf - 1))
+        h.run(2)
+        assert h.csr(0x342) == 2, (v, nf)
+    h = hart(lambda a: (a.vsetivli(6, 19, Asm.vtype(32, 2)), a.vls(False, 8, 3, 10, lumop=0xB), a.vls(True, 8, 3, 11, lumop=0xB)))
+    h.run(4)
+    assert h.vreg(3) == blob[:3] + b"\xff" * 61 and h.read_mem(0x80002000, 4) == blob[:3] + b"\0"
+
+
+def test_rvv_mask_scan_move_extend_known_answers():
+    """vmv2r.v, vcpop.m / vfirst.m, vmsbf / vmsif / vmsof, viota.m, vzext / vsext against values worked out from the V spec."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, 128, dtype=np.uint8)
+    mask_bits = [0, 0, 0, 1, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0]                   # first set bit at 3, five... four set bits
+    mask = np.zeros(64, dtype=np.uint8); mask[0] = 0x68; mask[1] = 0x04
+
+    def run(build, steps):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5)
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+        h.set_vreg(8, img[:64].tobytes()); h.set_vreg(9, img[64:].tobytes()); h.set_vreg(2, mask.tobytes())
+        h.run(steps)
+        return h
+    h = run(lambda a: (a.vsetivli(6, 1, Asm.vtype(8, 1)), a.vop(0x27, 3, 12, 8, 1)), 3)             # vmv2r.v v12, v8: whole registers whatever vl is
+    assert h.vreg(12) + h.vreg(13) == img.tobytes()
+    h = run(lambda a: (a.vsetivli(6, 16, Asm.vtype(8, 1)), a.vop(0x10, 2, 10, 2, 0x10), a.vop(0x10, 2, 11, 2, 0x11), a.vop(0x10, 2, 12, 3, 0x11)), 5)
+    assert (h.x(10), h.x(11), h.x(12)) == (4, 3, 2**64 - 1)
+    for k, want in [(1, [1, 1, 1] + [0] * 13), (3, [1, 1, 1, 1] + [0] * 12), (2, [0, 0, 0, 1] + [0] * 12)]:
+        h = run(lambda a: (a.vsetivli(6, 16, Asm.vtype(8, 1)), a.vop(0x14, 2, 4, 2, k)), 3)
+        bits = int.from_bytes(h.vreg(4), "little")
+        assert [(bits >> i) & 1 for i in range(16)] == want and bits >> 16 == 0                      # past vl: kept (was zero)
+    h = run(lambda a: (a.vsetivli(6, 16, Asm.vtype(16, 1)), a.vop(0x14, 2, 4, 2, 0x10)), 3)           # viota.m: exclusive prefix count
+    got = np.frombuffer(h.vreg(4), dtype=np.uint16)[:16]
+    assert list(got) == list(np.concatenate([[0], np.cumsum(mask_bits)[:-1]]))
+    for sew, f, sign in [(16, 2, 0), (32, 4, 1), (64, 8, 1), (64, 2, 0), (32, 2, 1)]:
+        code = {(2, 0): 6, (2, 1): 7, (4, 0): 4, (4, 1): 5, (8, 0): 2, (8, 1): 3}[(f, sign)]
+        h = run(lambda a: (a.vsetvli(6, 0, Asm.vtype(sew, 1)), a.vop(0x12, 2, 4, 8, code)), 3)
+        n = 512 // sew
+        src = img[:n * sew // 8 // f].view({1: np.uint8, 2: np.uint16, 4: np.uint32}[sew // 8 // f])
+        if sign:
+            src = src.view({1: np.int8, 2: np.int16, 4: np.int32}[sew // 8 // f])
+        want = src.astype(np.int64).astype({16: np.uint16, 32: np.uint32, 64: np.uint64}[sew])
+        assert h.vreg(4) == want.tobytes(), (sew, f, sign)
+    h = run(lambda a: (a.vsetvli(6, 0, Asm.vtype(8, 1)), a.vop(0x12, 2, 4, 8, 6)), 3)                 # SEW 8 has no narrower source
+    assert h.csr(0x342) == 2

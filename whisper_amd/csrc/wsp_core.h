@@ -1259,9 +1259,17 @@ template <class MEM> struct Lane {
     m.cold(CI_VSTART) = ix & (vlenb * 8 - 1); s.chg |= CH_GEN; s.gen_csr = C_VSTART;
     take_exception(cause, cur_pc, tval, false);
   }
-  WSP_HD void v_load_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided)
+  // vlm.v / vsm.v (vector-ls.cpp:484-559): the unit-stride byte loop over ceil(vl / 8) bytes at SEW 8, LMUL 1, tail agnostic
+  WSP_HD bool v_mask_cfg(VCfg& c, const Rec& r, u64 cur_pc)
   {
-    const VCfg c = vcfg();
+    if (!vec_on() || c.vill || !((r.raw >> 25) & 1)) { vec_fail(r, cur_pc); return false; }
+    c.vl = (c.vl + 7) / 8; c.esz = 0; c.gx8 = 8; c.ta = true; c.ma = false;
+    return true;
+  }
+  WSP_HD void v_load_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided, bool mask_ls = false)
+  {
+    VCfg c = vcfg();
+    if (mask_ls && !v_mask_cfg(c, r, cur_pc)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
     u32 gx8;
     if (!v_ldst_legal(c, inst, eew, gx8)) { vec_fail(r, cur_pc); return; }
@@ -1284,9 +1292,10 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
-  WSP_HD void v_store_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided)
+  WSP_HD void v_store_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided, bool mask_ls = false)
   {
-    const VCfg c = vcfg();
+    VCfg c = vcfg();
+    if (mask_ls && !v_mask_cfg(c, r, cur_pc)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
     u32 gx8;
     if (!v_ldst_legal(c, inst, eew, gx8)) { vec_fail(r, cur_pc); return; }
@@ -1301,19 +1310,46 @@ template <class MEM> struct Lane {
       if (paging_unsupported()) return;
       const u32 cause = ldst_addr(addr, esz, 2, pa1, pa2, tval);
       if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
-      // writeForStore (Hart.cpp:2727-2800); vector stores leave no m line in the log (printTrace.cpp:452)
-      if (pa1 + esz > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;
-      if (pa2 != pa1 && pa2 + esz > text_lo && pa2 < text_hi) h.flags |= HF_CODE_DIRTY;
-      if (tohost != ~0ULL && (pa1 == tohost || pa1 == tohost + 4)) {
-        mem_write(pa1 - mem_base, esz, elem);
-        u64 v = elem;
-        if (esz == 4) { if (pa1 == tohost + 4) { h.htif_dev = (u32)elem; continue; } v |= (u64)h.htif_dev << 32; }
-        else if (esz == 8) h.htif_dev = 0;
-        if (((v >> 48) & 0xff) == 0 && ((v >> 56) & 0xff) == 0 && (elem & 1)) { stop(ST_STOP_TOHOST, v); return; }
-        continue;
-      }
-      mem_write2(pa1, pa2, esz, elem);
+      if (!v_store_elem(pa1, pa2, esz, elem)) return;
     }
+    vec_success();
+  }
+  // writeForStore (Hart.cpp:2727-2800); vector stores leave no m line in the log (printTrace.cpp:452).  False: the hart stopped
+  WSP_HD bool v_store_elem(u64 pa1, u64 pa2, u32 esz, u64 elem)
+  {
+    if (pa1 + esz > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;
+    if (pa2 != pa1 && pa2 + esz > text_lo && pa2 < text_hi) h.flags |= HF_CODE_DIRTY;
+    if (tohost != ~0ULL && (pa1 == tohost || pa1 == tohost + 4)) {
+      mem_write(pa1 - mem_base, esz, elem);
+      u64 v = elem;
+      if (esz == 4) { if (pa1 == tohost + 4) { h.htif_dev = (u32)elem; return true; } v |= (u64)h.htif_dev << 32; }
+      else if (esz == 8) h.htif_dev = 0;
+      if (((v >> 48) & 0xff) == 0 && ((v >> 56) & 0xff) == 0 && (elem & 1)) { stop(ST_STOP_TOHOST, v); return false; }
+      return true;
+    }
+    mem_write2(pa1, pa2, esz, elem);
+    return true;
+  }
+  // vl<nf>re<eew>.v (vectorLoadWholeReg, vector-ls.cpp:565-670) and vs<nf>r.v (vectorStoreWholeReg, :747-821): nf whole registers
+  // from vstart, independent of vtype and vl
+  WSP_HD void v_ldst_whole(const Rec& r, u64 base, u64 cur_pc, u32 eew, bool store)
+  {
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, nf = (inst >> 29) + 1;
+    if ((nf & (nf - 1)) || !vec_on() || !((inst >> 25) & 1)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, nf * 8, vd, 0, 0)) return;
+    if (store) eew = 0;
+    const u32 esz = 1u << eew, count = vlenb * nf / esz, start = (u32)m.cold(CI_VSTART);
+    u64 addr = base + (u64)start * esz;
+    if (!store && start >= count) { vec_success(); return; }
+    for (u32 ix = start; ix < count; ++ix, addr += esz) {
+      u64 pa1, pa2, tval;
+      if (paging_unsupported()) return;
+      const u32 cause = ldst_addr(addr, esz, store ? 2 : 1, pa1, pa2, tval);
+      if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); if (!store) { s.vgroup = 1; s.chg |= CH_VREG; } return; }
+      if (store) { if (!v_store_elem(pa1, pa2, 1, vrd(vd, ix, 0))) return; }
+      else vwr(vd, ix, eew, nf * 8, pa1 == tohost ? 0 : mem_read2(pa1, pa2, esz));
+    }
+    if (!store) { s.vgroup = 1; s.chg |= CH_VREG; }                             // touchReg(vd, groupX8 = 8): the log names vd alone
     vec_success();
   }
   // integer element operation: a = vs2 element, b = vs1 element / scalar / immediate
@@ -1525,6 +1561,101 @@ template <class MEM> struct Lane {
     if (s.vgroup == 0) { s.vgroup = 1; s.chg |= CH_VREG; }                      // touchMask
     vec_success();
   }
+  // vmv<nr>r.v (vmvr_v, vector.cpp:8261-8302)
+  WSP_HD void v_mv_whole(const Rec& r, u64 cur_pc, u32 nr)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31;
+    if (!((inst >> 25) & 1) || (vd & (nr - 1)) || (vs2 & (nr - 1))) { vec_fail(r, cur_pc); return; }
+    if (vd != vs2) for (u32 i = 0; i < nr * vlenb / 8; ++i) m.vst(vd * vlenb + i * 8, 3, m.vld(vs2 * vlenb + i * 8, 3));
+    s.vgroup = nr; s.chg |= CH_VREG;                                            // touchReg(vd, nr * 8)
+    vec_success();
+  }
+  // vcpop.m / vfirst.m (vector-mask.cpp:128-187)
+  WSP_HD void v_mask_scan_x(const Rec& r, u64 cur_pc, bool first)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, rd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    u64 res = first ? ~0ull : 0;
+    for (u32 ix = 0; ix < c.vl; ++ix) {
+      if (masked && !v_mask_bit(ix)) continue;
+      if (!v_rd_mask_bit(vs2, ix)) continue;
+      if (first) { res = ix; break; }
+      ++res;
+    }
+    wx(rd, res);
+    vec_success();
+  }
+  // vmsbf.m / vmsof.m / vmsif.m (vector-mask.cpp:190-338): k 1 before-first, 2 only-first, 3 including-first; bits past vl are kept
+  WSP_HD void v_mask_set_first(const Rec& r, u64 cur_pc, u32 k)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (vd == vs2 || (masked && vd == 0)) { vec_fail(r, cur_pc); return; }
+    if (0 < c.vl) {
+      bool found = false;
+      for (u32 ix = 0; ix < c.vl; ++ix) {
+        bool flag = v_rd_mask_bit(vd, ix);
+        if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
+        else {
+          const bool input = v_rd_mask_bit(vs2, ix);
+          if (k == 1) { found = found || input; flag = !found; }
+          else if (k == 3) { flag = !found; found = found || input; }
+          else { flag = !found && input; found = found || input; }
+        }
+        v_wr_mask_bit(vd, ix, flag);
+      }
+    }
+    vec_success();
+  }
+  // viota.m (vector-mask.cpp:341-430)
+  WSP_HD void v_iota(const Rec& r, u64 cur_pc)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 group = c.gx8 <= 8 ? 1 : c.gx8 / 8;
+    if (!vec_on() || c.vill || m.cold(CI_VSTART) > 0 || (vs2 >= vd && vs2 < vd + group) || (masked && vd == 0)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, 0, 0)) return;
+    u32 sum = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        bool src = v_rd_mask_bit(vs2, ix); u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = sum & ones_of(c.esz); else src = false;
+        vwr(vd, ix, c.esz, 8 * group, d);
+        if (src) ++sum;
+      }
+    vec_success();
+  }
+  // checkDestSourceOverlap (vector.cpp:323-345)
+  WSP_HD static bool v_overlap_ok(u32 dest, u32 dw, u32 dgx8, u32 src, u32 sw, u32 sgx8)
+  {
+    if (sw == dw) return true;
+    const u32 sg = sgx8 >= 8 ? sgx8 / 8 : 1, dg = dgx8 >= 8 ? dgx8 / 8 : 1;
+    if (src >= dest + dg || dest >= src + sg) return true;
+    if (dw > sw) return sgx8 >= 8 && src == dest + dg - sg;
+    return src == dest;
+  }
+  // vzext / vsext .vf2 .vf4 .vf8 (vector.cpp:6673-7200)
+  WSP_HD void v_ext(const Rec& r, u64 cur_pc, u32 factor, bool sign)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 from = c.gx8 / factor, eg = c.gx8 >= 8 ? c.gx8 / 8 : 1, lf = factor == 2 ? 1 : factor == 4 ? 2 : 3;
+    if (from == 0 || (vd % eg) || (eg > factor && (vs2 % (eg / factor))) || !v_overlap_ok(vd, 8u << c.esz, c.gx8, vs2, (8u << c.esz) / factor, from) ||
+        c.esz < lf) { vec_fail(r, cur_pc); return; }
+    const u32 ssz = c.esz - lf, dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = (sign ? (u64)vrd_s(vs2, ix, ssz) : vrd(vs2, ix, ssz)) & ones_of(c.esz);
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
   WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
   WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
@@ -1676,6 +1807,10 @@ template <class MEM> struct Lane {
         case 0x07: if (kind != 2) op = VI_MAX; break;
         case 0x09: op = VI_AND; break; case 0x0a: op = VI_OR; break; case 0x0b: op = VI_XOR; break;
         case 0x25: v_int_arith(r, cur_pc, VI_SLL, kind, kind == 2 ? uimm : sc); return;
+        case 0x27:                                                              // vmv<nr>r.v (Decoder.cpp:633-638)
+          if (kind != 2) break;
+          if (rs1 != 0 && rs1 != 1 && rs1 != 3 && rs1 != 7) { illegal(r, cur_pc); return; }
+          v_mv_whole(r, cur_pc, rs1 + 1); return;
         case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
         case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
         case 0x17:
@@ -1695,7 +1830,8 @@ template <class MEM> struct Lane {
       if (f6 == 0x10) {
         const VCfg c = vcfg();
         if (!vx) {
-          if (rs1 != 0) { vec_unsupported(inst); return; }                      // vcpop / vfirst: not in this slice
+          if (rs1 == 0x10 || rs1 == 0x11) { v_mask_scan_x(r, cur_pc, rs1 == 0x11); return; }
+          if (rs1 != 0) { illegal(r, cur_pc); return; }                         // Decoder.cpp:512-516
           if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;                   // vmv.x.s (vector.cpp:7972-8030)
           if (!vm) { vec_fail(r, cur_pc); return; }
           wx(rd, (u64)vrd_s(rs2, 0, c.esz)); vec_success(); return;
@@ -1704,6 +1840,12 @@ template <class MEM> struct Lane {
         if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
         if (!vm) { vec_fail(r, cur_pc); return; }
         v_mv_s(c, rd, a); return;
+      }
+      if (f6 == 0x12 && !vx && rs1 >= 2 && rs1 <= 7) { v_ext(r, cur_pc, rs1 < 4 ? 8 : rs1 < 6 ? 4 : 2, rs1 & 1); return; }   // Decoder.cpp:521-527
+      if (f6 == 0x14 && !vx && rs1 != 0x11) {                                   // Decoder.cpp:538-544
+        if (rs1 >= 1 && rs1 <= 3) { v_mask_set_first(r, cur_pc, rs1); return; }
+        if (rs1 == 0x10) { v_iota(r, cur_pc); return; }
+        illegal(r, cur_pc); return;
       }
       if (f6 == 0x14 && !vx && rs1 == 0x11) {                                   // vid.v (vector-mask.cpp:435-510)
         const VCfg c = vcfg();
@@ -1778,8 +1920,19 @@ template <class MEM> struct Lane {
   {
     const u32 inst = r.raw, f3 = (inst >> 12) & 7, mop = (inst >> 26) & 3;
     s.vreg = (inst >> 7) & 31;
-    if ((!(mop == 0 && ((inst >> 20) & 31) == 0) && mop != 2) || (inst >> 29) != 0 || ((inst >> 28) & 1) != 0) { vec_unsupported(inst); return; }
+    const u32 lumop = (inst >> 20) & 31, nf = inst >> 29, mew = (inst >> 28) & 1;
     const u32 eew = f3 == 0 ? 0 : f3 - 4;
+    if (mop == 0 && lumop == 8) {                                               // whole registers (Decoder.cpp:949-967, 1184-1195)
+      if (store) { if (mew || f3 != 0 || (nf != 0 && nf != 1 && nf != 3 && nf != 7)) { illegal(r, cur_pc); return; } }
+      else if (mew) { vec_fail(r, cur_pc); return; }
+      v_ldst_whole(r, a, cur_pc, eew, store); return;
+    }
+    if (mop == 0 && lumop == 0xb) {                                             // vlm.v / vsm.v (Decoder.cpp:968-972, 1196-1200)
+      if (nf != 0 || mew != 0 || f3 != 0) { illegal(r, cur_pc); return; }
+      if (store) v_store_unit(r, a, b, cur_pc, 0, false, true); else v_load_unit(r, a, b, cur_pc, 0, false, true);
+      return;
+    }
+    if ((!(mop == 0 && lumop == 0) && mop != 2) || nf != 0 || mew != 0) { vec_unsupported(inst); return; }
     if (store) v_store_unit(r, a, b, cur_pc, eew, mop == 2); else v_load_unit(r, a, b, cur_pc, eew, mop == 2);
   }
 

@@ -302,6 +302,11 @@ class Asm:
     def vse(self, eew, vs3, rs1, vm=1):
         self._emit32(((vm & 1) << 25) | (rs1 << 15) | ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | (vs3 << 7) | 0x27)
 
+    def vls(self, store, eew, v, rs1, lumop=0, vm=1, nf=0, mew=0, mop=0):
+        """Generic vector load / store word: lumop 8 = whole registers (nf = count - 1), 0xb = mask (vlm.v / vsm.v)."""
+        self._emit32((nf << 29) | (mew << 28) | (mop << 26) | ((vm & 1) << 25) | ((lumop & 31) << 20) | (rs1 << 15) |
+                     ({8: 0, 16: 5, 32: 6, 64: 7}[eew] << 12) | ((v & 31) << 7) | (0x27 if store else 0x07))
+
     # ------------------------------------------------------------------ compressed (explicit)
     def c_nop(self):
         self._emit16(0x0001)

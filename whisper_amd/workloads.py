@@ -1118,13 +1118,33 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 t -= t % (eew // 8)
             a.li(P, t)
             r = rng.random()
-            if r < 0.35:
+            if r < 0.3:
                 a.vle(eew, vreg(), P, vm)
-            elif r < 0.7:
+            elif r < 0.6:
                 a.vse(eew, vreg(), P, vm)
+            elif r < 0.7:                                                    # whole registers: vl<nf>re<eew>.v / vs<nf>r.v (also illegal nf / alignment / masked)
+                nf = rng.choice([1, 1, 2, 2, 4, 8, 3]); st = rng.random() < 0.5
+                v = rng.randrange(0, 32 // nf) * nf if rng.random() < 0.9 else rng.randrange(32)
+                a.vls(st, 8 if st and rng.random() < 0.9 else eew, v, P, lumop=8, vm=rng.choice([1] * 9 + [0]), nf=nf - 1, mew=rng.choice([0] * 19 + [1]))
+            elif r < 0.76:                                                   # vlm.v / vsm.v
+                a.vls(rng.random() < 0.5, 8, rng.choice([0, vreg(False)]), P, lumop=0xB, vm=rng.choice([1] * 9 + [0]))
             else:                                                            # strided: positive, zero, negative and unaligned strides
                 a.li(7, rng.choice([eew // 8, 2 * (eew // 8), 24, 0, -(eew // 8), 3, 0x400]) & MASK64)
                 (a.vlse if rng.random() < 0.5 else a.vsse)(eew, vreg(), P, 7, vm)
+        elif k < 0.36:                                                   # whole-register moves, mask scans, extensions
+            q = rng.random()
+            if q < 0.2:
+                nr = rng.choice([1, 2, 4, 8, 3, 5])
+                al = (lambda: rng.randrange(0, 32 // nr) * nr) if nr in (1, 2, 4, 8) and rng.random() < 0.9 else (lambda: rng.randrange(32))
+                a.vop(0x27, 3, al(), al(), nr - 1, rng.choice([1] * 9 + [0]))                 # vmv<nr>r.v
+            elif q < 0.4:
+                a.vop(0x10, 2, rng.choice(regs), vreg(False), rng.choice([0x10, 0x11, 0x10, 0x11, 0x12]), vm)   # vcpop.m / vfirst.m
+            elif q < 0.6:
+                a.vop(0x14, 2, rng.choice([0, vreg(False), vreg(False)]), vreg(False), rng.choice([1, 2, 3, 1, 2, 3, 4]), vm)   # vmsbf / vmsof / vmsif
+            elif q < 0.75:
+                a.vop(0x14, 2, vreg(), vreg(False), 0x10, vm)             # viota.m
+            else:
+                a.vop(0x12, 2, vreg(), vreg(False) if rng.random() < 0.7 else vreg(), rng.randrange(2, 8), vm)   # vzext / vsext .vf8 .vf4 .vf2
         elif k < 0.60:
             name = rng.choice(list(_V_INT_VVXI) + list(_V_INT_VVX) + ["vrsub"])
             if name == "vrsub":
