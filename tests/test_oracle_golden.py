@@ -323,3 +323,64 @@ def test_rvv_mask_scan_move_extend_known_answers():
         assert h.vreg(4) == want.tobytes(), (sew, f, sign)
     h = run(lambda a: (a.vsetvli(6, 0, Asm.vtype(8, 1)), a.vop(0x12, 2, 4, 8, 6)), 3)                 # SEW 8 has no narrower source
     assert h.csr(0x342) == 2
+
+
+def test_rvv_div_mulh_slide_gather_known_answers():
+    """vdiv[u] / vrem[u] (x / 0, min / -1), vmulh[u|su], vslide*, vrgather against numpy / the V spec's definitions."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(13)
+
+    def run(sew, build, A, B, steps=3, xs=0, lmul=1, D=None):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, lmul))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600); h.set_x(11, xs)
+        h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes())
+        if D is not None:
+            h.set_vreg(4, D.tobytes())
+        h.run(steps)
+        return h
+    for sew, st, ut in [(8, np.int8, np.uint8), (16, np.int16, np.uint16), (32, np.int32, np.uint32), (64, np.int64, np.uint64)]:
+        n = 512 // sew
+        A = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy(); B = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy()
+        B[0] = 0; A[1] = 1 << (sew - 1); B[1] = (1 << sew) - 1; B[2] = 1; A[3] = 0
+        sa, sb = A.view(st).astype(object), B.view(st).astype(object); ua, ub = A.astype(object), B.astype(object)
+        m = (1 << sew) - 1
+
+        def tdiv(x, y):
+            q = abs(x) // abs(y)
+            return q if (x < 0) == (y < 0) else -q
+        want = {
+            0x20: [(x // y if y else m) & m for x, y in zip(ua, ub)],
+            0x21: [(tdiv(x, y) if y else -1) & m for x, y in zip(sa, sb)],
+            0x22: [(x % y if y else x) & m for x, y in zip(ua, ub)],
+            0x23: [((x - tdiv(x, y) * y) if y else x) & m for x, y in zip(sa, sb)],
+            0x24: [((x * y) >> sew) & m for x, y in zip(ua, ub)],
+            0x26: [((x * y) >> sew) & m for x, y in zip(sa, ub)],
+            0x27: [((x * y) >> sew) & m for x, y in zip(sa, sb)],
+        }
+        for f6, w in want.items():
+            h = run(sew, lambda a: a.vop(f6, 2, 4, 8, 9), A, B)
+            got = [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)]
+            assert got == [int(v) for v in w], (sew, hex(f6))
+        # slides: vslideup.vi 3 keeps vd[0..2]; vslidedown.vi 3 reads zero past VLMAX; vslide1up / vslide1down insert x11
+        D = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy()
+        xs = int(rng.integers(0, 2**63))
+        h = run(sew, lambda a: a.vop(0x0E, 3, 4, 8, 3), A, B, D=D)
+        assert list(np.frombuffer(h.vreg(4), dtype=ut)) == list(D[:3]) + list(A[:n - 3])
+        h = run(sew, lambda a: a.vop(0x0F, 3, 4, 8, 3), A, B, D=D)
+        assert list(np.frombuffer(h.vreg(4), dtype=ut)) == list(A[3:]) + [0, 0, 0]
+        h = run(sew, lambda a: a.vop(0x0E, 6, 4, 8, 11), A, B, D=D, xs=xs)
+        assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)] == [xs & m] + [int(v) for v in A[:n - 1]]
+        h = run(sew, lambda a: a.vop(0x0F, 6, 4, 8, 11), A, B, D=D, xs=xs)
+        assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)] == [int(v) for v in A[1:]] + [xs & m]
+        # vrgather.vv: indices beyond VLMAX give zero
+        I = rng.integers(0, 2 * n, n).astype(ut)
+        h = run(sew, lambda a: a.vop(0x0C, 0, 4, 8, 9), A, I)
+        assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)] == [int(A[i]) if i < n else 0 for i in I]
+        h = run(sew, lambda a: a.vop(0x0C, 4, 4, 8, 11), A, I, xs=5)
+        assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)] == [int(A[5])] * n
+        h = run(sew, lambda a: a.vop(0x0C, 0, 8, 8, 9), A, I)                                        # vd overlaps the table
+        assert h.csr(0x342) == 2

@@ -1353,7 +1353,8 @@ template <class MEM> struct Lane {
     vec_success();
   }
   // integer element operation: a = vs2 element, b = vs1 element / scalar / immediate
-  enum { VI_ADD, VI_SUB, VI_RSUB, VI_AND, VI_OR, VI_XOR, VI_SLL, VI_SRL, VI_SRA, VI_MINU, VI_MIN, VI_MAXU, VI_MAX, VI_MUL };
+  enum { VI_ADD, VI_SUB, VI_RSUB, VI_AND, VI_OR, VI_XOR, VI_SLL, VI_SRL, VI_SRA, VI_MINU, VI_MIN, VI_MAXU, VI_MAX, VI_MUL,
+         VI_DIVU, VI_DIV, VI_REMU, VI_REM, VI_MULHU, VI_MULHSU, VI_MULH };
   WSP_HD static u64 vi_op(u32 op, u64 a, u64 b, u32 esz)
   {
     const u32 bits = 8u << esz, sh = 64 - bits, shm = bits - 1;
@@ -1365,6 +1366,15 @@ template <class MEM> struct Lane {
       case VI_SLL: z = ua << (b & shm); break; case VI_SRL: z = ua >> (b & shm); break; case VI_SRA: z = (u64)(sa >> (b & shm)); break;
       case VI_MINU: z = ua < ub ? ua : ub; break; case VI_MIN: z = (u64)(sa < sb ? sa : sb); break;
       case VI_MAXU: z = ua > ub ? ua : ub; break; case VI_MAX: z = (u64)(sa > sb ? sa : sb); break;
+      // vdivu / vdiv / vremu / vrem (vector.cpp:6171-6640): x / 0 = all ones, x % 0 = x, min / -1 = min, min % -1 = 0
+      case VI_DIVU: z = ub ? ua / ub : ~0ull; break;
+      case VI_REMU: z = ub ? ua % ub : ua; break;
+      case VI_DIV: z = sb == 0 ? ~0ull : (sa == (i64)(~0ull << shm) && sb == -1) ? (u64)sa : (u64)(sa / sb); break;
+      case VI_REM: z = sb == 0 ? (u64)sa : (sa == (i64)(~0ull << shm) && sb == -1) ? 0 : (u64)(sa % sb); break;
+      // vmulhu / vmulhsu (signed vs2 x unsigned vs1) / vmulh (vector.cpp:4495-4870): narrow widths multiply in 64 bits
+      case VI_MULHU: z = esz == 3 ? wsf::mul64x64(a, b).hi : (ua * ub) >> bits; break;
+      case VI_MULHSU: if (esz == 3) { u64 hi = wsf::mul64x64(a, b).hi; if ((i64)a < 0) hi -= b; z = hi; } else z = (u64)((sa * (i64)ub) >> bits); break;
+      case VI_MULH: if (esz == 3) { u64 hi = wsf::mul64x64(a, b).hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; z = hi; } else z = (u64)((sa * sb) >> bits); break;
       default: z = a * b; break;
     }
     return z & on;
@@ -1656,6 +1666,61 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
+  // ---- permutation: vrgather .vv / .vx / .vi (vector.cpp:3302-3507), vslideup / vslidedown .vx / .vi, vslide1up / vslide1down .vx (:3968-4310)
+  WSP_HD bool v_valid_index(u32 reg, u64 ix, u32 gx8, u32 esz) const           // VecRegs::isValidIndex (VecRegs.hpp:154-163)
+  {
+    const u64 file = 32ull * vlenb, size = 1ull << esz;
+    if (ix >= file) return false;
+    if (ix * size > (((u64)vlenb * gx8) >> 3) - size) return false;
+    return (u64)reg * vlenb + ix * size <= file - size;
+  }
+  WSP_HD static bool v_overlap_any(u32 a, u32 b, u32 gx8) { const u32 g = gx8 >= 8 ? gx8 / 8 : 1; return b < a + g && a < b + g; }   // Hart.hpp:4846-4852
+  WSP_HD void v_gather(const Rec& r, u64 cur_pc, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, kind == 0)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (v_overlap_any(vd, vs2, c.gx8) || (kind == 0 && v_overlap_any(vd, vs1, c.gx8))) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u64 from = kind == 0 ? vrd(vs1, ix, c.esz) : scalar;
+          d = 0;
+          if ((kind != 0 || from < (u64)vlenb * 8) && v_valid_index(vs2, from, c.gx8, c.esz)) d = vrd(vs2, (u32)from, c.esz);
+        }
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
+  WSP_HD void v_slide(const Rec& r, u64 cur_pc, bool up, bool one, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (up && v_overlap_any(vd, vs2, c.gx8)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
+    const u64 amount = one ? 1 : scalar;
+    if (0 < c.vl) {
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        const bool active = v_dest_active(c, vd, ix, c.esz, masked, d);
+        if (up) {
+          if (active && ix >= amount) d = vrd(vs2, (u32)(ix - amount), c.esz);
+          if (ix >= c.vl || ix >= amount) vwr(vd, ix, c.esz, dg, d);
+        } else {
+          if (active) { d = 0; if (amount < 32ull * vlenb && v_valid_index(vs2, ix + amount, c.gx8, c.esz)) d = vrd(vs2, (u32)(ix + amount), c.esz); }
+          vwr(vd, ix, c.esz, dg, d);
+        }
+      }
+      if (one && up) { u64 d; if (v_dest_active(c, vd, 0, c.esz, masked, d)) d = scalar & ones_of(c.esz); vwr(vd, 0, c.esz, c.gx8, d); }
+      if (one && !up) { const u32 slot = c.vl - 1; if (!masked || v_mask_bit(slot)) vwr(vd, slot, c.esz, c.gx8, scalar & ones_of(c.esz)); }
+    }
+    vec_success();
+  }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
   WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
   WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
@@ -1813,6 +1878,9 @@ template <class MEM> struct Lane {
           v_mv_whole(r, cur_pc, rs1 + 1); return;
         case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
         case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x0c: v_gather(r, cur_pc, kind, kind == 2 ? uimm : a); return;
+        case 0x0e: if (kind == 0) break; v_slide(r, cur_pc, true, false, kind == 2 ? uimm : a); return;         // .vv is vrgatherei16
+        case 0x0f: if (kind == 0) break; v_slide(r, cur_pc, false, false, kind == 2 ? uimm : a); return;
         case 0x17:
           if (vm && rs2 != 0) { illegal(r, cur_pc); return; }                   // Decoder.cpp:336-343
           v_merge_mv(r, cur_pc, kind, sc); return;
@@ -1827,6 +1895,7 @@ template <class MEM> struct Lane {
     if (f3 == 2 || f3 == 6) {                                                   // OPMVV / OPMVX
       const bool vx = f3 == 6;
       if (f6 <= 7 && !vx) { const u8 rop[8] = { VI_ADD, VI_AND, VI_OR, VI_XOR, VI_MINU, VI_MIN, VI_MAXU, VI_MAX }; v_int_reduce(r, cur_pc, rop[f6]); return; }
+      if ((f6 == 0x0e || f6 == 0x0f) && vx) { v_slide(r, cur_pc, f6 == 0x0e, true, a); return; }             // vslide1up.vx / vslide1down.vx
       if (f6 == 0x10) {
         const VCfg c = vcfg();
         if (!vx) {
@@ -1857,7 +1926,10 @@ template <class MEM> struct Lane {
         vec_success(); return;
       }
       if (f6 >= 0x18 && f6 <= 0x1f && !vx) { v_mask_logical(r, cur_pc, f6 - 0x18); return; }
-      if (f6 == 0x25) { v_int_arith(r, cur_pc, VI_MUL, vx ? 1 : 0, a); return; }
+      if (f6 >= 0x20 && f6 <= 0x27) {
+        const u8 mop[8] = { VI_DIVU, VI_DIV, VI_REMU, VI_REM, VI_MULHU, VI_MUL, VI_MULHSU, VI_MULH };
+        v_int_arith(r, cur_pc, mop[f6 - 0x20], vx ? 1 : 0, a); return;
+      }
       if (f6 >= 0x30 && f6 <= 0x33) { v_int_widen(r, cur_pc, f6 >> 1 & 1, f6 & 1, f6 & 1, vx, a); return; }     // vwaddu vwadd vwsubu vwsub
       if (f6 == 0x38) { v_int_widen(r, cur_pc, 2, false, false, vx, a); return; }                              // vwmulu
       if (f6 == 0x3a) { v_int_widen(r, cur_pc, 2, true, false, vx, a); return; }                               // vwmulsu

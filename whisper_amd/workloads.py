@@ -1013,7 +1013,8 @@ def sv39_program(seed: int, n: int = 300) -> Program:
 # funct6 of the modelled OP-V instructions
 _V_INT_VVXI = {"vadd": 0x00, "vand": 0x09, "vor": 0x0A, "vxor": 0x0B, "vsll": 0x25, "vsrl": 0x28, "vsra": 0x29}   # vv vx vi
 _V_INT_VVX = {"vsub": 0x02, "vminu": 0x04, "vmin": 0x05, "vmaxu": 0x06, "vmax": 0x07}                              # vv vx
-_V_MUL = {"vmul": 0x25, "vmacc": 0x2D, "vnmsac": 0x2F, "vmadd": 0x29, "vnmsub": 0x2B}                              # OPMVV / OPMVX
+_V_MUL = {"vmul": 0x25, "vmacc": 0x2D, "vnmsac": 0x2F, "vmadd": 0x29, "vnmsub": 0x2B, "vdivu": 0x20, "vdiv": 0x21, "vremu": 0x22, "vrem": 0x23,
+          "vmulhu": 0x24, "vmulhsu": 0x26, "vmulh": 0x27}                              # OPMVV / OPMVX
 _V_RED = {"vredsum": 0, "vredand": 1, "vredor": 2, "vredxor": 3, "vredminu": 4, "vredmin": 5, "vredmaxu": 6, "vredmax": 7}
 _V_FP = {"vfadd": 0x00, "vfsub": 0x02, "vfmul": 0x24, "vfdiv": 0x20, "vfmadd": 0x28, "vfnmadd": 0x29, "vfmsub": 0x2A, "vfnmsub": 0x2B,
          "vfmacc": 0x2C, "vfnmacc": 0x2D, "vfmsac": 0x2E, "vfnmsac": 0x2F, "vfmin": 0x04, "vfmax": 0x06, "vfsgnj": 0x08, "vfsgnjn": 0x09,
@@ -1131,7 +1132,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
             else:                                                            # strided: positive, zero, negative and unaligned strides
                 a.li(7, rng.choice([eew // 8, 2 * (eew // 8), 24, 0, -(eew // 8), 3, 0x400]) & MASK64)
                 (a.vlse if rng.random() < 0.5 else a.vsse)(eew, vreg(), P, 7, vm)
-        elif k < 0.36:                                                   # whole-register moves, mask scans, extensions
+        elif k < 0.38:                                                   # whole-register moves, mask scans, extensions
             q = rng.random()
             if q < 0.2:
                 nr = rng.choice([1, 2, 4, 8, 3, 5])
@@ -1143,8 +1144,18 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 a.vop(0x14, 2, rng.choice([0, vreg(False), vreg(False)]), vreg(False), rng.choice([1, 2, 3, 1, 2, 3, 4]), vm)   # vmsbf / vmsof / vmsif
             elif q < 0.75:
                 a.vop(0x14, 2, vreg(), vreg(False), 0x10, vm)             # viota.m
-            else:
+            elif q < 0.85:
                 a.vop(0x12, 2, vreg(), vreg(False) if rng.random() < 0.7 else vreg(), rng.randrange(2, 8), vm)   # vzext / vsext .vf8 .vf4 .vf2
+            elif q < 0.92:                                                   # vrgather .vv / .vx / .vi
+                f3 = rng.choice([0, 4, 3])
+                if f3 == 4:
+                    a.li(7, rng.choice([0, 1, 5, 17, 63, 200, 600, MASK64]))
+                a.vop(0x0C, f3, vreg(), vreg(), vreg() if f3 == 0 else (7 if f3 == 4 else rng.randrange(32)), vm)
+            else:                                                            # vslideup / vslidedown .vx / .vi, vslide1up / vslide1down .vx
+                f3 = rng.choice([4, 3, 6])
+                if f3 == 4:
+                    a.li(7, rng.choice([0, 1, 2, 7, 16, 100, 3000, MASK64]))
+                a.vop(rng.choice([0x0E, 0x0F]), f3, vreg(), vreg(), 7 if f3 == 4 else (rng.choice(regs) if f3 == 6 else rng.randrange(32)), vm)
         elif k < 0.60:
             name = rng.choice(list(_V_INT_VVXI) + list(_V_INT_VVX) + ["vrsub"])
             if name == "vrsub":
@@ -1217,7 +1228,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x0C, 0, 4, 8, 12)         # vrgather.vv
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x17, 2, 4, 8, 12)         # vcompress.vm
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
