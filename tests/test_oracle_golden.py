@@ -384,3 +384,80 @@ def test_rvv_div_mulh_slide_gather_known_answers():
         assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)] == [int(A[5])] * n
         h = run(sew, lambda a: a.vop(0x0C, 0, 8, 8, 9), A, I)                                        # vd overlaps the table
         assert h.csr(0x342) == 2
+
+
+def test_rvv_narrowing_and_wide_operand_known_answers():
+    """vnsrl / vnsra .wv / .wi and vwadd[u].wv / vwsub[u].wx against numpy; a narrow destination may overlap only the lowest
+    register of its wide source."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, 192, dtype=np.uint8)
+
+    def run(sew, build, xs=0):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600); h.set_x(11, xs)
+        h.set_vreg(8, img[:64].tobytes()); h.set_vreg(9, img[64:128].tobytes()); h.set_vreg(12, img[128:].tobytes())
+        h.run(3)
+        return h
+    for sew, ut, st, wut, wst in [(8, np.uint8, np.int8, np.uint16, np.int16), (16, np.uint16, np.int16, np.uint32, np.int32),
+                                  (32, np.uint32, np.int32, np.uint64, np.int64)]:
+        wide_u = img[:128].view(wut); wide_s = img[:128].view(wst); sh = img[128:].view(ut)
+        m = 2 * sew - 1
+        h = run(sew, lambda a: a.vop(0x2C, 0, 4, 8, 12))
+        assert (np.frombuffer(h.vreg(4), dtype=ut) == (wide_u >> (sh & m).astype(wut)).astype(ut)).all(), sew
+        h = run(sew, lambda a: a.vop(0x2D, 0, 4, 8, 12))
+        assert (np.frombuffer(h.vreg(4), dtype=ut) == (wide_s >> (sh & m).astype(wst)).astype(ut)).all(), sew
+        h = run(sew, lambda a: a.vop(0x2C, 3, 4, 8, sew // 2))
+        assert (np.frombuffer(h.vreg(4), dtype=ut) == (wide_u >> wut(sew // 2)).astype(ut)).all(), sew
+        h = run(sew, lambda a: a.vop(0x2C, 3, 8, 8, 1))                                            # vd = low half of the source: legal
+        assert h.csr(0x342) == 0 and (np.frombuffer(h.vreg(8), dtype=ut) == (wide_u >> wut(1)).astype(ut)).all()
+        h = run(sew, lambda a: a.vop(0x2C, 3, 9, 8, 1))                                            # vd = high half: illegal
+        assert h.csr(0x342) == 2
+        h = run(sew, lambda a: a.vop(0x34, 2, 4, 8, 12))                                           # vwaddu.wv
+        assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=wut) == wide_u + sh.astype(wut)).all(), sew
+        h = run(sew, lambda a: a.vop(0x35, 2, 4, 8, 12))                                           # vwadd.wv
+        assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=wst) == wide_s + sh.view(st).astype(wst)).all(), sew
+        xs = int(rng.integers(0, 2**63))
+        h = run(sew, lambda a: a.vop(0x37, 6, 4, 8, 11), xs=xs)                                    # vwsub.wx
+        sx = np.array([xs & (2**sew - 1)], dtype=np.uint64).astype(ut).view(st).astype(wst)[0]
+        assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=wst) == wide_s - sx).all(), sew
+
+
+def test_rvv_fp_unary_known_answers():
+    """vfsqrt.v, vfcvt.{x,xu}.f.v (frm = RNE), vfcvt.rtz.x.f.v, vfcvt.f.{x,xu}.v and vfmerge.vfm against numpy."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(19)
+    for sew, ft, it, ut in [(32, np.float32, np.int32, np.uint32), (64, np.float64, np.int64, np.uint64)]:
+        n = 512 // sew
+        A = (rng.integers(-2000, 2000, n) / 8).astype(ft); A[0] = 2.5; A[1] = 3.5; A[2] = -2.5; A[3] = 1e30
+        I = rng.integers(-2**31, 2**31, n).astype(it)
+        mask = rng.integers(0, 256, 64, dtype=np.uint8)
+
+        def run(f6, f3, s1, vs2, vm=1):
+            a = Asm(0x80000000)
+            a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(f6, f3, 4, 8, s1, vm)
+            h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+            h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+            h.set_vreg(8, vs2.tobytes()); h.set_vreg(0, mask.tobytes()); h.set_f(3, int(np.array([7.25], dtype=ft).view(ut)[0]) | (0 if sew == 64 else 0xFFFFFFFF00000000))
+            h.run(3)
+            return h
+        P = np.abs(A)
+        assert (np.frombuffer(run(0x13, 1, 0, P).vreg(4), dtype=ft) == np.sqrt(P)).all()
+        lim_s, lim_u = 2**(sew - 1), 2**sew
+        rne = [int(np.rint(float(v))) for v in A]
+        got = np.frombuffer(run(0x12, 1, 1, A).vreg(4), dtype=it)
+        assert [int(g) for g in got] == [min(max(v, -lim_s), lim_s - 1) for v in rne]
+        got = np.frombuffer(run(0x12, 1, 0, A).vreg(4), dtype=ut)
+        assert [int(g) for g in got] == [min(max(v, 0), lim_u - 1) for v in rne]
+        got = np.frombuffer(run(0x12, 1, 7, A).vreg(4), dtype=it)
+        assert [int(g) for g in got] == [min(max(int(float(v)), -lim_s), lim_s - 1) for v in A]
+        assert (np.frombuffer(run(0x12, 1, 3, I).vreg(4), dtype=ft) == I.astype(ft)).all()
+        assert (np.frombuffer(run(0x12, 1, 2, I).vreg(4), dtype=ft) == I.view(ut).astype(ft)).all()
+        got = np.frombuffer(run(0x17, 5, 3, A, vm=0).vreg(4), dtype=ft)
+        bits = int.from_bytes(mask.tobytes(), "little")
+        assert [float(g) for g in got] == [7.25 if (bits >> i) & 1 else float(A[i]) for i in range(n)]

@@ -1475,8 +1475,31 @@ template <class MEM> struct Lane {
     if (0 < c.vl) { vwr(vd, 0, c.esz, 8, val & ones_of(c.esz)); if (c.ta) for (u32 i = 1; i < (vlenb >> c.esz); ++i) vwr(vd, i, c.esz, 8, ones_of(c.esz)); }
     vec_success();
   }
+  // checkDestSourceOverlap (vector.cpp:323-345)
+  WSP_HD static bool v_overlap_ok(u32 dest, u32 dw, u32 dgx8, u32 src, u32 sw, u32 sgx8)
+  {
+    if (sw == dw) return true;
+    const u32 sg = sgx8 >= 8 ? sgx8 / 8 : 1, dg = dgx8 >= 8 ? dgx8 / 8 : 1;
+    if (src >= dest + dg || dest >= src + sg) return true;
+    if (dw > sw) return sgx8 >= 8 && src == dest + dg - sg;
+    return src == dest;
+  }
+  // checkVecOpsVsEmul with per-operand wide flags (vector.cpp:461-527): op0 is the destination; n = 2 or 3 operands
+  WSP_HD bool v_check_ops_wide(const Rec& r, u64 cur_pc, u32 gx8, u32 esz, u32 n, u32 op0, bool w0, u32 op1, bool w1, u32 op2, bool w2)
+  {
+    const u32 eg = gx8 >= 8 ? gx8 / 8 : 1, wg = 2 * gx8, ewg = wg >= 8 ? wg / 8 : 1, sew = 8u << esz;
+    bool ok = !(op0 & ((w0 ? ewg : eg) - 1)) && !(op1 & ((w1 ? ewg : eg) - 1)) && (n < 3 || !(op2 & ((w2 ? ewg : eg) - 1)));
+    const u32 g0 = w0 ? wg : gx8, g1 = w1 ? wg : gx8, g2 = w2 ? wg : gx8, s0 = w0 ? 2 * sew : sew, s1 = w1 ? 2 * sew : sew, s2 = w2 ? 2 * sew : sew;
+    ok = ok && v_overlap_ok(op0, s0, g0, op1, s1, g1);
+    if (n > 2) {
+      ok = ok && v_overlap_ok(op0, s0, g0, op2, s2, g2);
+      if (s1 != s2) { const u32 c1 = g1 >= 8 ? g1 / 8 : 1, c2 = g2 >= 8 ? g2 / 8 : 1; ok = ok && (op1 >= op2 + c2 || op2 >= op1 + c1); }   // checkSourceOverlap (:351-363)
+    }
+    if (!ok) vec_fail(r, cur_pc);
+    return ok;
+  }
   // widening integer add / sub / mul (vector.cpp:1170-1560, 5270-5715).  op: 0 add 1 sub 2 mul; sa / sb: vs2 element / second operand signed
-  WSP_HD void v_int_widen(const Rec& r, u64 cur_pc, u32 op, bool sa, bool sb, bool vx, u64 xs)
+  WSP_HD void v_int_widen(const Rec& r, u64 cur_pc, u32 op, bool sa, bool sb, bool vx, u64 xs, bool wide_src)
   {
     const VCfg c = vcfg();
     if (!v_check_int(c, r, cur_pc, !vx)) return;
@@ -1484,24 +1507,38 @@ template <class MEM> struct Lane {
     const u32 wg = c.gx8 * 2;
     if (wg > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }                 // isDoubleWideLegal (VecRegs.hpp:261-274)
     const u32 dsz = c.esz + 1, vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
-    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1, ewg = wg >= 8 ? wg / 8 : 1;
-    bool ok = !(vd & (ewg - 1)) && !(vs2 & (eg - 1)) && (vx || !(vs1 & (eg - 1)));      // checkVecOpsVsEmul, wide destination (vector.cpp:461-527)
-    for (u32 k = 0; k < (vx ? 1u : 2u); ++k) {                                  // checkDestSourceOverlap (vector.cpp:323-345)
-      const u32 src = k == 0 ? vs2 : vs1;
-      if (!(src >= vd + ewg || vd >= src + eg)) ok = ok && c.gx8 >= 8 && src == vd + ewg - eg;
-    }
-    if (!ok) { vec_fail(r, cur_pc); return; }
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, vx ? 2 : 3, vd, true, vs2, wide_src, vs1, false)) return;
     const u32 dg = wg < 8 ? 8 : wg, sh = 64 - (8u << c.esz);
     if (0 < c.vl)
       for (u32 ix = 0; ix < elems; ++ix) {
         u64 d;
         if (v_dest_active(c, vd, ix, dsz, masked, d)) {
-          const u64 a = sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
+          const u64 a = wide_src ? vrd(vs2, ix, dsz) : sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
           const u64 braw = vx ? (xs & ones_of(c.esz)) : vrd(vs1, ix, c.esz);
           const u64 b = sb ? (u64)((i64)(braw << sh) >> sh) : braw;
           d = (op == 0 ? a + b : op == 1 ? a - b : a * b) & ones_of(dsz);
         }
         vwr(vd, ix, dsz, dg, d);
+      }
+    vec_success();
+  }
+  // narrowing shifts vnsrl / vnsra .wv / .wx / .wi (vector.cpp:3013-3300): vs2 is 2 * SEW wide, shift amount mod 2 * SEW
+  WSP_HD void v_narrow_shift(const Rec& r, u64 cur_pc, bool arith, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, kind == 0)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (c.gx8 * 2 > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, kind == 0 ? 3 : 2, vd, false, vs2, true, vs1, false)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8, wbits = 16u << c.esz;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u32 amt = (u32)((kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & (wbits - 1));
+          d = (arith ? (u64)(vrd_s(vs2, ix, c.esz + 1) >> amt) : vrd(vs2, ix, c.esz + 1) >> amt) & ones_of(c.esz);
+        }
+        vwr(vd, ix, c.esz, dg, d);
       }
     vec_success();
   }
@@ -1638,15 +1675,6 @@ template <class MEM> struct Lane {
         if (src) ++sum;
       }
     vec_success();
-  }
-  // checkDestSourceOverlap (vector.cpp:323-345)
-  WSP_HD static bool v_overlap_ok(u32 dest, u32 dw, u32 dgx8, u32 src, u32 sw, u32 sgx8)
-  {
-    if (sw == dw) return true;
-    const u32 sg = sgx8 >= 8 ? sgx8 / 8 : 1, dg = dgx8 >= 8 ? dgx8 / 8 : 1;
-    if (src >= dest + dg || dest >= src + sg) return true;
-    if (dw > sw) return sgx8 >= 8 && src == dest + dg - sg;
-    return src == dest;
   }
   // vzext / vsext .vf2 .vf4 .vf8 (vector.cpp:6673-7200)
   WSP_HD void v_ext(const Rec& r, u64 cur_pc, u32 factor, bool sign)
@@ -1822,6 +1850,47 @@ template <class MEM> struct Lane {
     or_fflags(fl);
     vec_success();
   }
+  // vfsqrt.v (vector-float.cpp:3998-4066) and the same-width conversions (:4990-5310).  op: 0 sqrt 1 xu.f 2 x.f 3 f.xu 4 f.x 5 rtz.xu.f 6 rtz.x.f
+  WSP_HD void v_fp_unary(const Rec& r, u64 cur_pc, u32 op)
+  {
+    using namespace wsf;
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    if (!v_check_fp(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    const bool w = c.esz == 2;
+    if (op >= 5) rm = RM_RTZ;
+    unsigned fl = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u64 a = vrd(vs2, ix, c.esz);
+          if (op == 0) d = w ? f_sqrt<F32>(a, rm, fl) : f_sqrt<F64>(a, rm, fl);
+          else if (op == 3 || op == 4) d = w ? int_to_f<F32>(a, op == 4, false, rm, fl) : int_to_f<F64>(a, op == 4, true, rm, fl);
+          else { const bool sg = op == 2 || op == 6; d = (w ? f_to_int<F32>(a, rm, sg, false, fl) : f_to_int<F64>(a, rm, sg, true, fl)) & ones_of(c.esz); }
+        }
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    or_fflags(fl);
+    vec_success();
+  }
+  // vfmerge.vfm (vector-float.cpp:4068-4130)
+  WSP_HD void v_fp_merge(const Rec& r, u64 cur_pc)
+  {
+    const VCfg c = vcfg(); int rm;
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, fs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31;
+    if (((inst >> 25) & 1) || vd == 0 || vs2 == 0 || !fp_rm(7, rm)) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
+    if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
+    const u64 sc = vf_scalar(fs1, c.esz); const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, vd, ix, c.esz, false, d)) d = v_mask_bit(ix) ? sc : vrd(vs2, ix, c.esz); vwr(vd, ix, c.esz, dg, d); }
+    vec_success();
+  }
   WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
   {
     const VCfg c = vcfg(); int rm = 0;
@@ -1878,6 +1947,8 @@ template <class MEM> struct Lane {
           v_mv_whole(r, cur_pc, rs1 + 1); return;
         case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
         case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x2c: v_narrow_shift(r, cur_pc, false, kind, kind == 2 ? uimm : sc); return;
+        case 0x2d: v_narrow_shift(r, cur_pc, true, kind, kind == 2 ? uimm : sc); return;
         case 0x0c: v_gather(r, cur_pc, kind, kind == 2 ? uimm : a); return;
         case 0x0e: if (kind == 0) break; v_slide(r, cur_pc, true, false, kind == 2 ? uimm : a); return;         // .vv is vrgatherei16
         case 0x0f: if (kind == 0) break; v_slide(r, cur_pc, false, false, kind == 2 ? uimm : a); return;
@@ -1930,10 +2001,10 @@ template <class MEM> struct Lane {
         const u8 mop[8] = { VI_DIVU, VI_DIV, VI_REMU, VI_REM, VI_MULHU, VI_MUL, VI_MULHSU, VI_MULH };
         v_int_arith(r, cur_pc, mop[f6 - 0x20], vx ? 1 : 0, a); return;
       }
-      if (f6 >= 0x30 && f6 <= 0x33) { v_int_widen(r, cur_pc, f6 >> 1 & 1, f6 & 1, f6 & 1, vx, a); return; }     // vwaddu vwadd vwsubu vwsub
-      if (f6 == 0x38) { v_int_widen(r, cur_pc, 2, false, false, vx, a); return; }                              // vwmulu
-      if (f6 == 0x3a) { v_int_widen(r, cur_pc, 2, true, false, vx, a); return; }                               // vwmulsu
-      if (f6 == 0x3b) { v_int_widen(r, cur_pc, 2, true, true, vx, a); return; }                                // vwmul
+      if (f6 >= 0x30 && f6 <= 0x37) { v_int_widen(r, cur_pc, f6 >> 1 & 1, f6 & 1, f6 & 1, vx, a, f6 >= 0x34); return; }   // vwaddu vwadd vwsubu vwsub, then the .w forms
+      if (f6 == 0x38) { v_int_widen(r, cur_pc, 2, false, false, vx, a, false); return; }                       // vwmulu
+      if (f6 == 0x3a) { v_int_widen(r, cur_pc, 2, true, false, vx, a, false); return; }                        // vwmulsu
+      if (f6 == 0x3b) { v_int_widen(r, cur_pc, 2, true, true, vx, a, false); return; }                         // vwmul
       if (f6 == 0x2d) { v_int_muladd(r, cur_pc, 0, vx, a); return; }
       if (f6 == 0x2f) { v_int_muladd(r, cur_pc, 1, vx, a); return; }
       if (f6 == 0x29) { v_int_muladd(r, cur_pc, 2, vx, a); return; }
@@ -1973,8 +2044,15 @@ template <class MEM> struct Lane {
         if (!v_fp_mv_check(c, r, cur_pc)) return;
         if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
         v_mv_s(c, rd, vf_scalar(rs1, c.esz)); return; }
+      case 0x12:                                                                // VFUNARY0 (Decoder.cpp:394-405): same-width conversions only
+        if (vf) break;
+        if (rs1 <= 3) { v_fp_unary(r, cur_pc, 1 + rs1); return; }
+        if (rs1 == 6 || rs1 == 7) { v_fp_unary(r, cur_pc, rs1 - 1); return; }
+        break;
+      case 0x13: if (vf || rs1 != 0) break; v_fp_unary(r, cur_pc, 0); return;   // vfsqrt.v (Decoder.cpp:427)
       case 0x17: {
-        if (!vf || !vm) break;                                                  // vfmerge: not in this slice
+        if (!vf) break;
+        if (!vm) { v_fp_merge(r, cur_pc); return; }                             // vfmerge.vfm (Decoder.cpp:811)
         if (rs2 != 0) { illegal(r, cur_pc); return; }                           // vfmv.v.f (:4134-4215)
         const VCfg c = vcfg();
         if (!v_fp_mv_check(c, r, cur_pc)) return;

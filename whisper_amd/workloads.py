@@ -1176,13 +1176,18 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 forms = [0, 4, 3] if f6 in (0x18, 0x19, 0x1C, 0x1D) else [0, 4] if f6 in (0x1A, 0x1B) else [4, 3]
                 f3 = rng.choice(forms)
                 a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
-            elif r < 0.88:
+            elif r < 0.8:
                 a.vop(rng.choice(range(0x18, 0x20)), 2, rng.choice([0, vreg(False)]), vreg(False), vreg(False), rng.choice([1, 1, 1, 0]))   # vmand.mm ...
             else:                                                            # widening add / sub / mul: destination group twice as wide
                 lm = cur["lmul"] if isinstance(cur["lmul"], int) else 1
                 vdw = rng.randrange(0, 32 // min(2 * lm, 16)) * min(2 * lm, 16) if rng.random() < 0.85 else rng.randrange(32)
                 f3 = rng.choice([2, 6])
-                a.vop(rng.choice([0x30, 0x31, 0x32, 0x33, 0x38, 0x3A, 0x3B]), f3, vdw % 32, vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+                if rng.random() < 0.7:
+                    f6 = rng.choice([0x30, 0x31, 0x32, 0x33, 0x34, 0x35, 0x36, 0x37, 0x38, 0x3A, 0x3B])
+                    a.vop(f6, f3, vdw % 32, vdw % 32 if 0x34 <= f6 <= 0x37 and rng.random() < 0.6 else vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+                else:                                                        # narrowing shifts: the source group is twice as wide
+                    f3 = rng.choice([0, 4, 3])
+                    a.vop(rng.choice([0x2C, 0x2D]), f3, vreg(), vdw % 32, vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
         elif k < 0.77:
             r = rng.random()
             if r < 0.35:
@@ -1202,7 +1207,15 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
             if r < 0.5:
                 name = rng.choice(list(_V_FP)); f3 = rng.choice([1, 5])
                 a.vop(_V_FP[name], f3, vreg(), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
-            elif r < 0.6:                                                    # vmfeq vmfle vmflt vmfne (.vv / .vf), vmfgt vmfge (.vf)
+            elif r < 0.56:                                                   # vfsqrt.v, same-width vfcvt.*, vfmerge.vfm
+                q = rng.random()
+                if q < 0.3:
+                    a.vop(0x13, 1, vreg(), vreg(), 0, vm)
+                elif q < 0.8:
+                    a.vop(0x12, 1, vreg(), vreg(), rng.choice([0, 1, 2, 3, 6, 7]), vm)
+                else:
+                    a.vop(0x17, 5, vreg(), vreg(), rng.randrange(32), 0)
+            elif r < 0.62:                                                   # vmfeq vmfle vmflt vmfne (.vv / .vf), vmfgt vmfge (.vf)
                 f6 = rng.choice([0x18, 0x19, 0x1B, 0x1C, 0x1D, 0x1F]); f3 = 5 if f6 in (0x1D, 0x1F) else rng.choice([1, 5])
                 a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
             elif r < 0.7:
