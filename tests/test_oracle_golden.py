@@ -461,3 +461,78 @@ def test_rvv_fp_unary_known_answers():
         got = np.frombuffer(run(0x17, 5, 3, A, vm=0).vreg(4), dtype=ft)
         bits = int.from_bytes(mask.tobytes(), "little")
         assert [float(g) for g in got] == [7.25 if (bits >> i) & 1 else float(A[i]) for i in range(n)]
+
+
+def test_rvv_indexed_ldst_known_answers():
+    """vluxei16.v gathers SEW = 32 elements at zero-extended 16-bit byte offsets; vsoxei16.v scatters them back; an index register
+    overlapping a wider destination group anywhere but its top is illegal."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(23)
+    table = rng.integers(0, 2**32, 256, dtype=np.uint32)
+    idx = (rng.permutation(256)[:16] * 4).astype(np.uint16)                                          # 16 elements at SEW 32, VLEN 512
+
+    def hart(build):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(32, 1))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.write_mem(0x80001000, table.tobytes()); h.pc = 0x80000000
+        h.set_x(5, 0x6600); h.set_x(10, 0x80001000); h.set_x(11, 0x80003000)
+        h.set_vreg(8, idx.tobytes() + bytes(32))
+        return h
+    h = hart(lambda a: (a.vls(False, 16, 4, 10, lumop=8, mop=1), a.vls(True, 16, 4, 11, lumop=8, mop=3)))
+    h.run(4)
+    got = np.frombuffer(h.vreg(4), dtype=np.uint32)
+    assert (got == table[idx // 4]).all()
+    out = np.frombuffer(h.read_mem(0x80003000, 1024), dtype=np.uint32)
+    want = np.zeros(256, dtype=np.uint32); want[idx // 4] = table[idx // 4]
+    assert (out == want).all()
+    h = hart(lambda a: (a.vsetvli(6, 0, Asm.vtype(32, 2)), a.vls(False, 16, 8, 10, lumop=8, mop=1)))  # vd group v8-v9, index v8 (EMUL 1): low overlap
+    h.run(4)
+    assert h.csr(0x342) == 2
+    h = hart(lambda a: (a.vsetvli(6, 0, Asm.vtype(32, 2)), a.vls(False, 16, 8, 10, lumop=9, mop=1)))  # index in the top register of the group: legal
+    h.run(4)
+    assert h.csr(0x342) in (0, 5)                                                                    # legal encoding (v9 holds zeros -> loads table[0])
+
+
+def test_rvv_segment_and_fault_first_known_answers():
+    """vlseg3e16.v de-interleaves, vsseg3e16.v re-interleaves, vlsseg2e32.v strides; vle32ff.v running off the end of memory trims
+    vl to the elements loaded (and traps when element 0 faults)."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(29)
+    blob = rng.integers(0, 2**16, 2048, dtype=np.uint16)
+    MEM = 1 << 16
+
+    def hart(build, sew=16, lmul=1, ta=False):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, lmul, ta=ta))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=MEM)
+        h.write_mem(0x80000000, a.assemble()); h.write_mem(0x80001000, blob.tobytes()); h.pc = 0x80000000
+        h.set_x(5, 0x6600); h.set_x(10, 0x80001000); h.set_x(11, 0x80003000); h.set_x(12, 24)
+        return h
+    h = hart(lambda a: (a.vls(False, 16, 4, 10, nf=2), a.vls(True, 16, 4, 11, nf=2)))
+    h.run(4)
+    seg = blob[:96].reshape(32, 3)
+    for f in range(3):
+        assert (np.frombuffer(h.vreg(4 + f), dtype=np.uint16) == seg[:, f]).all()
+    assert h.read_mem(0x80003000, 192) == blob[:96].tobytes()
+    h = hart(lambda a: a.vls(False, 32, 4, 10, lumop=12, nf=1, mop=2), sew=32)                      # vlsseg2e32.v, stride x12 = 24 bytes
+    h.run(3)
+    w = blob.view(np.uint32)
+    assert (np.frombuffer(h.vreg(4), dtype=np.uint32) == w[0:16 * 6:6]).all() and (np.frombuffer(h.vreg(5), dtype=np.uint32) == w[1:16 * 6:6]).all()
+    for v, nf in [(30, 4), (4, 8)]:                                                                  # past v31; EMUL * NFIELDS > 8 at LMUL 2
+        h = hart(lambda a: a.vls(False, 16, v, 10, nf=nf - 1), lmul=2 if nf == 8 else 1)
+        h.run(3)
+        assert h.csr(0x342) == 2
+    end = 0x80000000 + MEM
+    h = hart(lambda a: a.vls(False, 32, 4, 10, lumop=0x10), sew=32, ta=True)
+    h.set_x(10, end - 20); h.write_mem(end - 20, bytes(range(20)))
+    h.run(3)
+    assert h.csr(0xC20) == 5 and h.csr(0x342) == 0 and h.vreg(4) == bytes(range(20)) + b"\xff" * 44
+    h = hart(lambda a: a.vls(False, 32, 4, 10, lumop=0x10), sew=32)
+    h.set_x(10, end)
+    h.run(3)
+    assert h.csr(0x342) == 5 and h.csr(0xC20) == 16

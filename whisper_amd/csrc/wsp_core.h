@@ -1330,6 +1330,103 @@ template <class MEM> struct Lane {
     mem_write2(pa1, pa2, esz, elem);
     return true;
   }
+  // indexed loads / stores vluxei / vloxei / vsuxei / vsoxei (vector-ls.cpp:1268-1382, 1570-1720; checks :32-109, vector.cpp:301-320):
+  // data EEW = SEW, index EEW from the encoding, offsets zero-extended
+  WSP_HD void v_ldst_indexed(const Rec& r, u64 base, u64 cur_pc, u32 ieew, bool store)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vi = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 ogx8 = (8u << ieew) * c.gx8 / (8u << c.esz);
+    const bool sym = ogx8 == 1 || ogx8 == 2 || ogx8 == 4 || ogx8 == 8 || ogx8 == 16 || ogx8 == 32 || ogx8 == 64;
+    if (!vec_on() || !sym || c.vill) { vec_fail(r, cur_pc); return; }
+    const u32 eg0 = c.gx8 >= 8 ? c.gx8 / 8 : 1, eg2 = ogx8 >= 8 ? ogx8 / 8 : 1;
+    bool ok = !(vd & (eg0 - 1)) && !(vi & (eg2 - 1)) && !(masked && (vd == 0 || vi == 0));
+    if (store) ok = ok && (c.esz == ieew || vd >= vi + eg2 || vi >= vd + eg0);                                // checkSourceOverlap
+    else ok = ok && v_overlap_ok(vd, 8u << c.esz, c.gx8, vi, 8u << ieew, ogx8);
+    if (!ok) { vec_fail(r, cur_pc); return; }
+    const u32 size = 1u << c.esz, start = (u32)m.cold(CI_VSTART), dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (store) {
+      for (u32 ix = start; ix < c.vl; ++ix) {
+        if (masked && !v_mask_bit(ix)) continue;
+        const u64 vaddr = base + vrd(vi, ix, ieew);
+        u64 pa1, pa2, tval;
+        if (paging_unsupported()) return;
+        const u32 cause = ldst_addr(vaddr, size, 2, pa1, pa2, tval);
+        if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+        if (!v_store_elem(pa1, pa2, size, vrd(vd, ix, c.esz))) return;
+      }
+      vec_success(); return;
+    }
+    if (start < c.vl)
+      for (u32 ix = start; ix < c.elem_max; ++ix) {
+        u64 elem, pa1, pa2, tval;
+        if (!v_dest_active(c, vd, ix, c.esz, masked, elem)) { vwr(vd, ix, c.esz, dg, elem); continue; }
+        const u64 vaddr = base + vrd(vi, ix, ieew);
+        if (paging_unsupported()) return;
+        const u32 cause = ldst_addr(vaddr, size, 1, pa1, pa2, tval);
+        if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+        vwr(vd, ix, c.esz, dg, pa1 == tohost ? 0 : mem_read2(pa1, pa2, size));
+      }
+    vec_success();
+  }
+  // segment loads / stores, unit-stride and strided (vector-ls.cpp:1905-2070, 2153-2272), and the fault-only-first forms (:213-243,
+  // :2016-2048).  A segment is all or nothing: every field is checked before any is written.  seg = false: vle<eew>ff.v (fields = 1)
+  WSP_HD void v_ldst_seg(const Rec& r, u64 base, u64 cur_pc, u32 eew, u32 fields, u64 stride, bool store, bool ff, bool seg)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31; const bool masked = !((inst >> 25) & 1);
+    u32 gx8;
+    if (!v_ldst_legal(c, inst, eew, gx8) || gx8 * fields > 64) { vec_fail(r, cur_pc); return; }
+    if (!v_check_emul(r, cur_pc, gx8, vd, 0, 0)) return;
+    const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
+    const u32 single = vlenb >> eew, vlmax = c.gx8 * vlenb / (8u << c.esz), elem_max = vlmax > single ? vlmax : single;
+    if (gx8 < 8) gx8 = 8;
+    const u32 group = gx8 / 8, lg = gx8 * fields;                               // the log names group * fields registers (Hart.cpp:5753-5771)
+    if (vd + fields * group > 32) { vec_fail(r, cur_pc); return; }
+    u64 addr = base + (u64)start * stride;
+    u64 pa1[8], pa2[8], val[8];
+    if (store) {
+      for (u32 ix = start; ix < c.vl; ++ix, addr += stride) {
+        if (masked && !v_mask_bit(ix)) continue;
+        for (u32 f = 0; f < fields; ++f) {
+          u64 tval;
+          if (paging_unsupported()) return;
+          const u32 cause = ldst_addr(addr + (u64)f * esz, esz, 2, pa1[f], pa2[f], tval);
+          if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+        }
+        for (u32 f = 0; f < fields; ++f) if (!v_store_elem(pa1[f], pa2[f], esz, vrd(vd + f * group, ix, eew))) return;
+      }
+      vec_success(); return;
+    }
+    if (start < c.vl)
+      for (u32 ix = start; ix < elem_max; ++ix, addr += stride) {
+        u64 d;
+        if (!v_dest_active(c, vd, ix, eew, masked, d)) {
+          for (u32 f = 0; f < fields; ++f) { v_dest_active(c, vd + f * group, ix, eew, masked, d); vwr(vd + f * group, ix, eew, lg, d); }
+          continue;
+        }
+        for (u32 f = 0; f < fields; ++f) {
+          u64 tval;
+          if (paging_unsupported()) return;
+          const u32 cause = ldst_addr(addr + (u64)f * esz, esz, 1, pa1[f], pa2[f], tval);
+          if (cause) {
+            if (ix == 0 || !ff) {
+              if (!ff || seg) v_ldst_fault(cause, ix, tval, cur_pc); else { mark_vs_dirty(); take_exception(cause, cur_pc, tval, false); }
+              return;
+            }
+            mark_vs_dirty();
+            if (!seg || c.ta) {                                                 // trim vl; the segment form does so only when tail-agnostic
+              m.cold(CI_VL) = ix; s.chg |= CH_VL;
+              if (c.ta) for (u32 ti = ix; ti < elem_max; ++ti) for (u32 g = 0; g < fields; ++g) vwr(vd + g * group, ti, eew, lg, ones_of(eew));
+            }
+            vec_success(); return;
+          }
+          val[f] = pa1[f] == tohost ? 0 : mem_read2(pa1[f], pa2[f], esz);
+        }
+        for (u32 f = 0; f < fields; ++f) vwr(vd + f * group, ix, eew, lg, val[f]);
+      }
+    vec_success();
+  }
   // vl<nf>re<eew>.v (vectorLoadWholeReg, vector-ls.cpp:565-670) and vs<nf>r.v (vectorStoreWholeReg, :747-821): nf whole registers
   // from vstart, independent of vtype and vl
   WSP_HD void v_ldst_whole(const Rec& r, u64 base, u64 cur_pc, u32 eew, bool store)
@@ -1345,11 +1442,11 @@ template <class MEM> struct Lane {
       u64 pa1, pa2, tval;
       if (paging_unsupported()) return;
       const u32 cause = ldst_addr(addr, esz, store ? 2 : 1, pa1, pa2, tval);
-      if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); if (!store) { s.vgroup = 1; s.chg |= CH_VREG; } return; }
+      if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); if (!store) { s.vgroup = nf; s.chg |= CH_VREG; } return; }
       if (store) { if (!v_store_elem(pa1, pa2, 1, vrd(vd, ix, 0))) return; }
       else vwr(vd, ix, eew, nf * 8, pa1 == tohost ? 0 : mem_read2(pa1, pa2, esz));
     }
-    if (!store) { s.vgroup = 1; s.chg |= CH_VREG; }                             // touchReg(vd, groupX8 = 8): the log names vd alone
+    if (!store) { s.vgroup = nf; s.chg |= CH_VREG; }                            // touchReg(vd, 8), then lastVecReg scales by the field count (Hart.cpp:5753-5771)
     vec_success();
   }
   // integer element operation: a = vs2 element, b = vs1 element / scalar / immediate
@@ -2081,6 +2178,13 @@ template <class MEM> struct Lane {
       if (nf != 0 || mew != 0 || f3 != 0) { illegal(r, cur_pc); return; }
       if (store) v_store_unit(r, a, b, cur_pc, 0, false, true); else v_load_unit(r, a, b, cur_pc, 0, false, true);
       return;
+    }
+    if ((mop == 1 || mop == 3) && nf == 0 && mew == 0) { v_ldst_indexed(r, a, cur_pc, eew, store); return; }   // indexed, unordered and ordered alike
+    if (mew == 0 && ((mop == 0 && lumop == 0) || mop == 2) && nf != 0) {        // vlseg / vsseg / vlsseg / vssseg (Decoder.cpp:930-947, 1030-1050)
+      v_ldst_seg(r, a, cur_pc, eew, nf + 1, mop == 2 ? b : (u64)(nf + 1) << eew, store, false, true); return;
+    }
+    if (mew == 0 && mop == 0 && lumop == 0x10 && !store) {                      // vle<eew>ff.v / vlseg<nf>e<eew>ff.v (Decoder.cpp:973-1010)
+      v_ldst_seg(r, a, cur_pc, eew, nf + 1, (u64)(nf + 1) << eew, false, true, nf != 0); return;
     }
     if ((!(mop == 0 && lumop == 0) && mop != 2) || nf != 0 || mew != 0) { vec_unsupported(inst); return; }
     if (store) v_store_unit(r, a, b, cur_pc, eew, mop == 2); else v_load_unit(r, a, b, cur_pc, eew, mop == 2);

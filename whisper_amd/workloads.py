@@ -1127,6 +1127,27 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 nf = rng.choice([1, 1, 2, 2, 4, 8, 3]); st = rng.random() < 0.5
                 v = rng.randrange(0, 32 // nf) * nf if rng.random() < 0.9 else rng.randrange(32)
                 a.vls(st, 8 if st and rng.random() < 0.9 else eew, v, P, lumop=8, vm=rng.choice([1] * 9 + [0]), nf=nf - 1, mew=rng.choice([0] * 19 + [1]))
+            elif r < 0.8 and rng.random() < 0.6:                             # indexed: offsets built with vid * k (or random register contents), index EEW 8..64
+                ieew = rng.choice([8, 16, 32, 64, cur["sew"]])
+                vi = vreg()
+                if rng.random() < 0.8:
+                    a.vop(0x14, 2, vi, 0, 0x11, 1)                           # vid.v vi
+                    a.vop(0x25, 3, vi, vi, rng.choice([0, 1, 2, 3]), 1)      # vsll.vi vi, vi, k
+                a.li(P, ARENA + 8 * rng.randrange(0x100))
+                a.vls(rng.random() < 0.5, ieew, vreg(), P, lumop=vi, vm=vm, mop=rng.choice([1, 3]))
+            elif r < 0.8 and rng.random() < 0.5:                             # segments (unit-stride / strided) and fault-only-first loads
+                nf = rng.choice([2, 2, 3, 4, 8])
+                v = rng.randrange(0, 32)
+                q = rng.random()
+                if q < 0.45:
+                    a.vls(rng.random() < 0.5, eew, v, P, lumop=0, vm=vm, nf=nf - 1)
+                elif q < 0.7:
+                    a.li(7, rng.choice([nf * (eew // 8), 64, 0, 3, -(eew // 8)]) & MASK64)
+                    a.vls(rng.random() < 0.5, eew, v, P, lumop=7, vm=vm, nf=nf - 1, mop=2)
+                else:
+                    if rng.random() < 0.6:
+                        a.li(P, BASE + (1 << 16) - rng.randrange(1, 200))    # runs off the end of memory: vl is trimmed
+                    a.vls(False, eew, v, P, lumop=0x10, vm=vm, nf=rng.choice([0, 0, 0, nf - 1]))
             elif r < 0.76:                                                   # vlm.v / vsm.v
                 a.vls(rng.random() < 0.5, 8, rng.choice([0, vreg(False)]), P, lumop=0xB, vm=rng.choice([1] * 9 + [0]))
             else:                                                            # strided: positive, zero, negative and unaligned strides
