@@ -536,3 +536,64 @@ def test_rvv_segment_and_fault_first_known_answers():
     h.set_x(10, end)
     h.run(3)
     assert h.csr(0x342) == 5 and h.csr(0xC20) == 16
+
+
+def test_rvv_wmacc_wredsum_compress_ei16_known_answers():
+    """vwmacc[u|su|us], vwredsum[u].vs, vcompress.vm, vrgatherei16.vv, vfredmin / vfredmax, vfslide1up / vfslide1down vs numpy."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(31)
+    A = rng.integers(0, 256, 64, dtype=np.uint8); B = rng.integers(0, 256, 64, dtype=np.uint8); D = rng.integers(0, 256, 128, dtype=np.uint8)
+    mask = rng.integers(0, 256, 64, dtype=np.uint8)
+
+    def run(sew, build, xs=0, fval=0, v12=None):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600); h.set_x(11, xs); h.set_f(3, fval)
+        h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes()); h.set_vreg(4, D[:64].tobytes()); h.set_vreg(5, D[64:].tobytes())
+        h.set_vreg(2, mask.tobytes())
+        if v12 is not None:
+            h.set_vreg(12, v12.tobytes())
+        h.run(3)
+        return h
+    for sew, ut, st, wut in [(8, np.uint8, np.int8, np.uint16), (16, np.uint16, np.int16, np.uint32), (32, np.uint32, np.int32, np.uint64)]:
+        a2, a1, acc = A.view(ut), B.view(ut), D.view(wut).astype(object)
+        u2, u1 = a2.astype(object), a1.astype(object); s2, s1 = a2.view(st).astype(object), a1.view(st).astype(object)
+        m = (1 << (2 * sew)) - 1
+        for f6, x2, x1 in [(0x3C, u2, u1), (0x3D, s2, s1), (0x3F, u2, s1)]:                       # vwmaccu, vwmacc, vwmaccsu (signed vs1 x unsigned vs2)
+            h = run(sew, lambda a: a.vop(f6, 2, 4, 8, 9))
+            got = np.frombuffer(h.vreg(4) + h.vreg(5), dtype=wut)
+            assert [int(g) for g in got] == [int(c + p * q) & m for c, p, q in zip(acc, x2, x1)], (sew, hex(f6))
+        xs = int(rng.integers(0, 2**63)) | (1 << (sew - 1))
+        h = run(sew, lambda a: a.vop(0x3E, 6, 4, 8, 11), xs=xs)                                    # vwmaccus.vx: unsigned x11 x signed vs2
+        got = np.frombuffer(h.vreg(4) + h.vreg(5), dtype=wut)
+        assert [int(g) for g in got] == [int(c + p * (xs & ((1 << sew) - 1))) & m for c, p in zip(acc, s2)], sew
+        h = run(sew, lambda a: a.vop(0x3C, 2, 4, 4, 9))                                            # vd is read: a narrow source may not sit inside it
+        assert h.csr(0x342) == 2
+        for f6, x2 in [(0x30, u2), (0x31, s2)]:                                                    # vwredsumu.vs / vwredsum.vs: vd[0] = vs1[0] + sum(vs2)
+            h = run(sew, lambda a: a.vop(f6, 0, 12, 8, 9))
+            want = (int(B.view(wut)[0]) + sum(int(v) for v in x2)) & m
+            assert int(np.frombuffer(h.vreg(12), dtype=wut)[0]) == want, (sew, hex(f6))
+    n = 16
+    a32 = A.view(np.uint32)
+    h = run(32, lambda a: a.vop(0x17, 2, 12, 8, 2), v12=np.zeros(16, dtype=np.uint32))              # vcompress.vm v12, v8, v2
+    bits = int.from_bytes(mask.tobytes(), "little")
+    packed = [int(a32[i]) for i in range(n) if (bits >> i) & 1]
+    assert [int(v) for v in np.frombuffer(h.vreg(12), dtype=np.uint32)] == packed + [0] * (n - len(packed))
+    idx = rng.integers(0, 24, 32).astype(np.uint16)                                                # EEW 16 indices for SEW 32: EMUL 1/2, 16 used
+    h = run(32, lambda a: a.vop(0x0E, 0, 4, 8, 12), v12=idx)
+    assert [int(v) for v in np.frombuffer(h.vreg(4), dtype=np.uint32)] == [int(a32[i]) if i < 16 else 0 for i in idx[:16]]
+    F = (rng.integers(-500, 500, 16) / 4).astype(np.float32); F[3] = -0.0
+    A[:] = F.view(np.uint8); B[:] = np.full(16, 1000.0, dtype=np.float32).view(np.uint8)
+    h = run(32, lambda a: a.vop(0x05, 1, 12, 8, 9))
+    assert np.frombuffer(h.vreg(12), dtype=np.float32)[0] == F.min()
+    B[:] = np.full(16, -1000.0, dtype=np.float32).view(np.uint8)
+    h = run(32, lambda a: a.vop(0x07, 1, 12, 8, 9))
+    assert np.frombuffer(h.vreg(12), dtype=np.float32)[0] == F.max()
+    fbits = int(np.array([3.75], dtype=np.float32).view(np.uint32)[0]) | 0xFFFFFFFF00000000
+    h = run(32, lambda a: a.vop(0x0E, 5, 12, 8, 3), fval=fbits)
+    assert [float(v) for v in np.frombuffer(h.vreg(12), dtype=np.float32)] == [3.75] + [float(v) for v in F[:15]]
+    h = run(32, lambda a: a.vop(0x0F, 5, 12, 8, 3), fval=fbits)
+    assert [float(v) for v in np.frombuffer(h.vreg(12), dtype=np.float32)] == [float(v) for v in F[1:]] + [3.75]

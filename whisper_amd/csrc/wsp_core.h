@@ -1582,7 +1582,7 @@ template <class MEM> struct Lane {
     return src == dest;
   }
   // checkVecOpsVsEmul with per-operand wide flags (vector.cpp:461-527): op0 is the destination; n = 2 or 3 operands
-  WSP_HD bool v_check_ops_wide(const Rec& r, u64 cur_pc, u32 gx8, u32 esz, u32 n, u32 op0, bool w0, u32 op1, bool w1, u32 op2, bool w2)
+  WSP_HD bool v_check_ops_wide(const Rec& r, u64 cur_pc, u32 gx8, u32 esz, u32 n, u32 op0, bool w0, u32 op1, bool w1, u32 op2, bool w2, bool dest_src = false)
   {
     const u32 eg = gx8 >= 8 ? gx8 / 8 : 1, wg = 2 * gx8, ewg = wg >= 8 ? wg / 8 : 1, sew = 8u << esz;
     bool ok = !(op0 & ((w0 ? ewg : eg) - 1)) && !(op1 & ((w1 ? ewg : eg) - 1)) && (n < 3 || !(op2 & ((w2 ? ewg : eg) - 1)));
@@ -1591,6 +1591,11 @@ template <class MEM> struct Lane {
     if (n > 2) {
       ok = ok && v_overlap_ok(op0, s0, g0, op2, s2, g2);
       if (s1 != s2) { const u32 c1 = g1 >= 8 ? g1 / 8 : 1, c2 = g2 >= 8 ? g2 / 8 : 1; ok = ok && (op1 >= op2 + c2 || op2 >= op1 + c1); }   // checkSourceOverlap (:351-363)
+    }
+    if (dest_src) {                                                             // vd is read too: no overlap with a source of another EEW
+      const u32 c0 = g0 >= 8 ? g0 / 8 : 1, c1 = g1 >= 8 ? g1 / 8 : 1, c2 = g2 >= 8 ? g2 / 8 : 1;
+      if (s0 != s1) ok = ok && (op0 >= op1 + c1 || op1 >= op0 + c0);
+      if (n > 2 && s0 != s2) ok = ok && (op0 >= op2 + c2 || op2 >= op0 + c0);
     }
     if (!ok) vec_fail(r, cur_pc);
     return ok;
@@ -1604,7 +1609,7 @@ template <class MEM> struct Lane {
     const u32 wg = c.gx8 * 2;
     if (wg > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }                 // isDoubleWideLegal (VecRegs.hpp:261-274)
     const u32 dsz = c.esz + 1, vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
-    if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, vx ? 2 : 3, vd, true, vs2, wide_src, vs1, false)) return;
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, vx ? 2 : 3, vd, true, vs2, wide_src, vs1, false, op == 3)) return;
     const u32 dg = wg < 8 ? 8 : wg, sh = 64 - (8u << c.esz);
     if (0 < c.vl)
       for (u32 ix = 0; ix < elems; ++ix) {
@@ -1613,7 +1618,7 @@ template <class MEM> struct Lane {
           const u64 a = wide_src ? vrd(vs2, ix, dsz) : sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
           const u64 braw = vx ? (xs & ones_of(c.esz)) : vrd(vs1, ix, c.esz);
           const u64 b = sb ? (u64)((i64)(braw << sh) >> sh) : braw;
-          d = (op == 0 ? a + b : op == 1 ? a - b : a * b) & ones_of(dsz);
+          d = (op == 0 ? a + b : op == 1 ? a - b : op == 2 ? a * b : vrd(vd, ix, dsz) + a * b) & ones_of(dsz);   // op 3: vwmacc family (vector.cpp:5686-6170)
         }
         vwr(vd, ix, dsz, dg, d);
       }
@@ -1820,10 +1825,11 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
-  WSP_HD void v_slide(const Rec& r, u64 cur_pc, bool up, bool one, u64 scalar)
+  WSP_HD void v_slide(const Rec& r, u64 cur_pc, bool up, bool one, u64 scalar, bool fp = false)    // fp: vfslide1up / vfslide1down (vector.cpp:4313-4475)
   {
     const VCfg c = vcfg();
     if (!v_check_int(c, r, cur_pc, false)) return;
+    if (fp) { int rm; if (!v_check_fp(c, r, cur_pc, rm)) return; scalar = vf_scalar((r.raw >> 15) & 31, c.esz); }
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
     if (up && v_overlap_any(vd, vs2, c.gx8)) { vec_fail(r, cur_pc); return; }
@@ -1844,6 +1850,62 @@ template <class MEM> struct Lane {
       if (one && up) { u64 d; if (v_dest_active(c, vd, 0, c.esz, masked, d)) d = scalar & ones_of(c.esz); vwr(vd, 0, c.esz, c.gx8, d); }
       if (one && !up) { const u32 slot = c.vl - 1; if (!masked || v_mask_bit(slot)) vwr(vd, slot, c.esz, c.gx8, scalar & ones_of(c.esz)); }
     }
+    vec_success();
+  }
+  // vwredsumu.vs / vwredsum.vs (vector.cpp: vwredsum_vs; checkWideRedOpVsEmul :261-298)
+  WSP_HD void v_int_wreduce(const Rec& r, u64 cur_pc, bool sign)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 lm = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    if ((vs2 & (lm - 1)) || (masked && (vs2 == 0 || vs1 == 0)) || (vs1 >= vs2 && vs1 < vs2 + lm) || c.esz > 2) { vec_fail(r, cur_pc); return; }
+    if (c.vl != 0) {
+      const u32 dsz = c.esz + 1;
+      u64 res = vrd(vs1, 0, dsz);
+      for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res += sign ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz); }
+      vwr(vd, 0, dsz, 8, res & ones_of(dsz));
+      if (c.ta) for (u32 ix = 1; ix < (vlenb >> dsz); ++ix) vwr(vd, ix, dsz, 8, ones_of(dsz));
+    }
+    vec_success();
+  }
+  // vcompress.vm (vector.cpp: vcompress_vm, execVcompress_vm)
+  WSP_HD void v_compress(const Rec& r, u64 cur_pc)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vm_reg = (inst >> 15) & 31, vs2 = (inst >> 20) & 31;
+    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
+    if (v_overlap_any(vd, vs2, c.gx8) || (vm_reg >= vd && vm_reg < vd + eg) || !((inst >> 25) & 1)) { vec_fail(r, cur_pc); return; }
+    if (0 < c.vl) {
+      u32 di = 0;
+      for (u32 ix = 0; ix < c.vl; ++ix) if (v_rd_mask_bit(vm_reg, ix)) vwr(vd, di++, c.esz, c.gx8, vrd(vs2, ix, c.esz));
+      if (c.ta) for (u32 ix = di; ix < c.elem_max; ++ix) vwr(vd, ix, c.esz, c.gx8 < 8 ? 8 : c.gx8, ones_of(c.esz));
+      if (s.vgroup == 0) { s.vgroup = eg; s.chg |= CH_VREG; }                   // touchReg(vd, group)
+    }
+    vec_success();
+  }
+  // vrgatherei16.vv (vector.cpp:3510-3645): 16-bit indices in vs1 with EMUL = 2 * LMUL / SEW-bytes
+  WSP_HD void v_gather_ei16(const Rec& r, u64 cur_pc)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 ig8 = (2 * c.gx8) >> c.esz;
+    const bool sym = ig8 == 1 || ig8 == 2 || ig8 == 4 || ig8 == 8 || ig8 == 16 || ig8 == 32 || ig8 == 64;
+    if (!sym || (masked && (vd == 0 || vs1 == 0 || vs2 == 0))) { vec_fail(r, cur_pc); return; }
+    const u32 eg = c.gx8 >= 8 ? c.gx8 / 8 : 1, ig = ig8 >= 8 ? ig8 / 8 : 1;
+    if ((vd % eg) || (vs2 % eg) || (vs1 % ig)) { vec_fail(r, cur_pc); return; }
+    const bool ov_src = c.esz != 1 && !(vs2 >= vs1 + ig || vs1 >= vs2 + eg);    // checkSourceOverlap(table, idx)
+    if (v_overlap_any(vd, vs2, c.gx8) || (vs1 < vd + eg && vd < vs1 + ig) || ov_src) { vec_fail(r, cur_pc); return; }
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) { const u64 from = vrd(vs1, ix, 1); d = v_valid_index(vs2, from, c.gx8, c.esz) ? vrd(vs2, (u32)from, c.esz) : 0; }
+        vwr(vd, ix, c.esz, dg, d);
+      }
     vec_success();
   }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
@@ -1988,7 +2050,7 @@ template <class MEM> struct Lane {
       for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, vd, ix, c.esz, false, d)) d = v_mask_bit(ix) ? sc : vrd(vs2, ix, c.esz); vwr(vd, ix, c.esz, dg, d); }
     vec_success();
   }
-  WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
+  WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc, u32 op)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
   {
     const VCfg c = vcfg(); int rm = 0;
     if (!v_check_fp(c, r, cur_pc, rm)) return;
@@ -1996,7 +2058,8 @@ template <class MEM> struct Lane {
     if (c.vl == 0) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     u64 res = vrd(vs1, 0, c.esz); unsigned fl = 0;
-    for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vf_op(0, res, vrd(vs2, ix, c.esz), c.esz, rm, fl); }
+    for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; const u64 x = vrd(vs2, ix, c.esz);
+      res = op == 0 ? vf_op(0, res, x, c.esz, rm, fl) : c.esz == 2 ? vf_minmax<wsf::F32>(op == 2, res, x, fl) : vf_minmax<wsf::F64>(op == 2, res, x, fl); }   // op 1 vfredmin, 2 vfredmax (:6985-7170)
     v_red_finish(c, vd, res);
     or_fflags(fl);
     vec_success();
@@ -2047,7 +2110,8 @@ template <class MEM> struct Lane {
         case 0x2c: v_narrow_shift(r, cur_pc, false, kind, kind == 2 ? uimm : sc); return;
         case 0x2d: v_narrow_shift(r, cur_pc, true, kind, kind == 2 ? uimm : sc); return;
         case 0x0c: v_gather(r, cur_pc, kind, kind == 2 ? uimm : a); return;
-        case 0x0e: if (kind == 0) break; v_slide(r, cur_pc, true, false, kind == 2 ? uimm : a); return;         // .vv is vrgatherei16
+        case 0x0e: if (kind == 0) { v_gather_ei16(r, cur_pc); return; } v_slide(r, cur_pc, true, false, kind == 2 ? uimm : a); return;
+        case 0x30: case 0x31: if (kind != 0) break; v_int_wreduce(r, cur_pc, f6 & 1); return;                  // vwredsumu.vs / vwredsum.vs
         case 0x0f: if (kind == 0) break; v_slide(r, cur_pc, false, false, kind == 2 ? uimm : a); return;
         case 0x17:
           if (vm && rs2 != 0) { illegal(r, cur_pc); return; }                   // Decoder.cpp:336-343
@@ -2063,6 +2127,7 @@ template <class MEM> struct Lane {
     if (f3 == 2 || f3 == 6) {                                                   // OPMVV / OPMVX
       const bool vx = f3 == 6;
       if (f6 <= 7 && !vx) { const u8 rop[8] = { VI_ADD, VI_AND, VI_OR, VI_XOR, VI_MINU, VI_MIN, VI_MAXU, VI_MAX }; v_int_reduce(r, cur_pc, rop[f6]); return; }
+      if (f6 == 0x17 && !vx) { v_compress(r, cur_pc); return; }
       if ((f6 == 0x0e || f6 == 0x0f) && vx) { v_slide(r, cur_pc, f6 == 0x0e, true, a); return; }             // vslide1up.vx / vslide1down.vx
       if (f6 == 0x10) {
         const VCfg c = vcfg();
@@ -2102,6 +2167,10 @@ template <class MEM> struct Lane {
       if (f6 == 0x38) { v_int_widen(r, cur_pc, 2, false, false, vx, a, false); return; }                       // vwmulu
       if (f6 == 0x3a) { v_int_widen(r, cur_pc, 2, true, false, vx, a, false); return; }                        // vwmulsu
       if (f6 == 0x3b) { v_int_widen(r, cur_pc, 2, true, true, vx, a, false); return; }                         // vwmul
+      if (f6 == 0x3c) { v_int_widen(r, cur_pc, 3, false, false, vx, a, false); return; }                       // vwmaccu
+      if (f6 == 0x3d) { v_int_widen(r, cur_pc, 3, true, true, vx, a, false); return; }                         // vwmacc
+      if (f6 == 0x3e && vx) { v_int_widen(r, cur_pc, 3, true, false, true, a, false); return; }                // vwmaccus.vx
+      if (f6 == 0x3f) { v_int_widen(r, cur_pc, 3, false, true, vx, a, false); return; }                        // vwmaccsu
       if (f6 == 0x2d) { v_int_muladd(r, cur_pc, 0, vx, a); return; }
       if (f6 == 0x2f) { v_int_muladd(r, cur_pc, 1, vx, a); return; }
       if (f6 == 0x29) { v_int_muladd(r, cur_pc, 2, vx, a); return; }
@@ -2127,7 +2196,9 @@ template <class MEM> struct Lane {
       case 0x1c: v_fp_compare(r, cur_pc, 3, vf); return;
       case 0x1d: if (!vf) break; v_fp_compare(r, cur_pc, 4, true); return;
       case 0x1f: if (!vf) break; v_fp_compare(r, cur_pc, 5, true); return;
-      case 0x01: case 0x03: if (vf) break; v_fp_redsum(r, cur_pc); return;
+      case 0x01: case 0x03: if (vf) break; v_fp_redsum(r, cur_pc, 0); return;
+      case 0x05: case 0x07: if (vf) break; v_fp_redsum(r, cur_pc, f6 == 0x05 ? 1 : 2); return;
+      case 0x0e: case 0x0f: if (!vf) break; v_slide(r, cur_pc, f6 == 0x0e, true, 0, true); return;   // vfslide1up.vf / vfslide1down.vf
       case 0x10: {
         const VCfg c = vcfg();
         if (!vf) {                                                              // vfmv.f.s (vector-float.cpp:503-583)

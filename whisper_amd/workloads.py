@@ -1167,11 +1167,19 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 a.vop(0x14, 2, vreg(), vreg(False), 0x10, vm)             # viota.m
             elif q < 0.85:
                 a.vop(0x12, 2, vreg(), vreg(False) if rng.random() < 0.7 else vreg(), rng.randrange(2, 8), vm)   # vzext / vsext .vf8 .vf4 .vf2
-            elif q < 0.92:                                                   # vrgather .vv / .vx / .vi
+            elif q < 0.90:                                                   # vrgather .vv / .vx / .vi
                 f3 = rng.choice([0, 4, 3])
                 if f3 == 4:
                     a.li(7, rng.choice([0, 1, 5, 17, 63, 200, 600, MASK64]))
                 a.vop(0x0C, f3, vreg(), vreg(), vreg() if f3 == 0 else (7 if f3 == 4 else rng.randrange(32)), vm)
+            elif q < 0.94:                                                   # vrgatherei16.vv, vcompress.vm, vwredsum[u].vs
+                t = rng.random()
+                if t < 0.4:
+                    a.vop(0x0E, 0, vreg(), vreg(), vreg(), vm)
+                elif t < 0.7:
+                    a.vop(0x17, 2, vreg(), vreg(), rng.choice([0, vreg(False)]), rng.choice([1] * 9 + [0]))
+                else:
+                    a.vop(rng.choice([0x30, 0x31]), 0, vreg(False), vreg(), vreg(False), vm)
             else:                                                            # vslideup / vslidedown .vx / .vi, vslide1up / vslide1down .vx
                 f3 = rng.choice([4, 3, 6])
                 if f3 == 4:
@@ -1204,7 +1212,8 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 vdw = rng.randrange(0, 32 // min(2 * lm, 16)) * min(2 * lm, 16) if rng.random() < 0.85 else rng.randrange(32)
                 f3 = rng.choice([2, 6])
                 if rng.random() < 0.7:
-                    f6 = rng.choice([0x30, 0x31, 0x32, 0x33, 0x34, 0x35, 0x36, 0x37, 0x38, 0x3A, 0x3B])
+                    f6 = rng.choice([0x30, 0x31, 0x32, 0x33, 0x34, 0x35, 0x36, 0x37, 0x38, 0x3A, 0x3B, 0x3C, 0x3D, 0x3E, 0x3F])
+                    f3 = 6 if f6 == 0x3E else f3                             # vwmaccus exists as .vx only
                     a.vop(f6, f3, vdw % 32, vdw % 32 if 0x34 <= f6 <= 0x37 and rng.random() < 0.6 else vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
                 else:                                                        # narrowing shifts: the source group is twice as wide
                     f3 = rng.choice([0, 4, 3])
@@ -1240,9 +1249,9 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 f6 = rng.choice([0x18, 0x19, 0x1B, 0x1C, 0x1D, 0x1F]); f3 = 5 if f6 in (0x1D, 0x1F) else rng.choice([1, 5])
                 a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
             elif r < 0.7:
-                a.vop(rng.choice([0x27, 0x21]), 5, vreg(), vreg(), rng.randrange(32), vm)        # vfrsub / vfrdiv
+                a.vop(rng.choice([0x27, 0x21, 0x0E, 0x0F]), 5, vreg(), vreg(), rng.randrange(32), vm)   # vfrsub / vfrdiv / vfslide1up / vfslide1down
             elif r < 0.8:
-                a.vop(rng.choice([0x01, 0x03]), 1, vreg(False), vreg(), vreg(False), vm)          # vfredusum / vfredosum
+                a.vop(rng.choice([0x01, 0x03, 0x05, 0x07]), 1, vreg(False), vreg(), vreg(False), vm)   # vfredusum / vfredosum / vfredmin / vfredmax
             elif r < 0.87:
                 a.vop(0x17, 5, vreg(), 0, rng.randrange(32), 1)                                   # vfmv.v.f
             elif r < 0.94:
@@ -1262,7 +1271,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x17, 2, 4, 8, 12)         # vcompress.vm
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x20, 0, 4, 8, 12)         # vsaddu.vv
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
