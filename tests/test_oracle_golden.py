@@ -597,3 +597,59 @@ def test_rvv_wmacc_wredsum_compress_ei16_known_answers():
     assert [float(v) for v in np.frombuffer(h.vreg(12), dtype=np.float32)] == [3.75] + [float(v) for v in F[:15]]
     h = run(32, lambda a: a.vop(0x0F, 5, 12, 8, 3), fval=fbits)
     assert [float(v) for v in np.frombuffer(h.vreg(12), dtype=np.float32)] == [float(v) for v in F[1:]] + [3.75]
+
+
+def test_rvv_fixed_point_known_answers():
+    """vsadd[u] / vssub[u] / vaadd[u] / vasub[u] / vsmul / vssrl / vssra / vnclip[u] against exact Python integers, under each of the
+    four vxrm rounding modes; vxsat is set exactly when some element saturated."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(37)
+
+    def rnd(v, d, rm):                                   # the V spec's roundoff on an exact integer
+        if d == 0:
+            return v
+        low = v & ((1 << d) - 1); half = 1 << (d - 1); q = v >> d
+        inc = {0: low >= half, 1: low > half or (low == half and q & 1), 2: False, 3: low != 0 and not q & 1}[rm]
+        return q + int(inc)
+    for sew, ut, st in [(8, np.uint8, np.int8), (32, np.uint32, np.int32), (64, np.uint64, np.int64)]:
+        n = 512 // sew
+        A = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy(); B = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy()
+        A[0] = B[0] = 1 << (sew - 1); A[1] = (1 << sew) - 1; B[1] = 1; A[2] = (1 << (sew - 1)) - 1; B[2] = 1
+        W = rng.integers(0, 256, 128, dtype=np.uint8)
+        ua, ub = [int(v) for v in A], [int(v) for v in B]
+        sa, sb = [int(v) for v in A.view(st)], [int(v) for v in B.view(st)]
+        m, smax, smin = (1 << sew) - 1, (1 << (sew - 1)) - 1, -(1 << (sew - 1))
+        clamp_s = lambda v: max(smin, min(smax, v))
+        for rm in range(4):
+            def run(f6, f3, vs2=8):
+                a = Asm(0x80000000)
+                a.csrs(0x300, 5); a.li(7, rm); a.csrw(0x00A, 7); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(f6, f3, 4, vs2, 9)
+                h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+                h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+                h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes()); h.set_vreg(12, W[:64].tobytes()); h.set_vreg(13, W[64:].tobytes())
+                h.run(6)
+                return [int(v) for v in np.frombuffer(h.vreg(4), dtype=ut)], h.csr(0x009)
+            cases = {
+                0x20: [min(x + y, m) for x, y in zip(ua, ub)], 0x22: [max(x - y, 0) for x, y in zip(ua, ub)],
+                0x21: [clamp_s(x + y) & m for x, y in zip(sa, sb)], 0x23: [clamp_s(x - y) & m for x, y in zip(sa, sb)],
+                0x27: [clamp_s(rnd(x * y, sew - 1, rm)) & m for x, y in zip(sa, sb)],
+                0x2A: [rnd(x, y & (sew - 1), rm) & m for x, y in zip(ua, ub)], 0x2B: [rnd(x, y & (sew - 1), rm) & m for x, y in zip(sa, ub)],
+            }
+            sat_expected = {0x20: any(x + y > m for x, y in zip(ua, ub)), 0x22: any(x < y for x, y in zip(ua, ub)),
+                            0x21: any(clamp_s(x + y) != x + y for x, y in zip(sa, sb)), 0x23: any(clamp_s(x - y) != x - y for x, y in zip(sa, sb)),
+                            0x27: True, 0x2A: False, 0x2B: False}
+            for f6, want in cases.items():
+                got, vxsat = run(f6, 0)
+                assert got == want and vxsat == int(sat_expected[f6]), (sew, rm, hex(f6))
+            for f6, want in {0x08: [rnd(x + y, 1, rm) & m for x, y in zip(ua, ub)], 0x09: [rnd(x + y, 1, rm) & m for x, y in zip(sa, sb)],
+                             0x0A: [rnd(x - y, 1, rm) & m for x, y in zip(ua, ub)], 0x0B: [rnd(x - y, 1, rm) & m for x, y in zip(sa, sb)]}.items():
+                got, vxsat = run(f6, 2)
+                assert got == want and vxsat == 0, (sew, rm, hex(f6))
+            if sew < 64:
+                wu = [int.from_bytes(W[i * sew // 4:(i + 1) * sew // 4].tobytes(), "little") for i in range(n)]
+                ws = [v - (1 << (2 * sew)) if v >> (2 * sew - 1) else v for v in wu]
+                got, _ = run(0x2E, 0, vs2=12)
+                assert got == [min(rnd(x, y & (2 * sew - 1), rm), m) for x, y in zip(wu, ub)], (sew, rm, "vnclipu")
+                got, _ = run(0x2F, 0, vs2=12)
+                assert got == [clamp_s(rnd(x, y & (2 * sew - 1), rm)) & m for x, y in zip(ws, ub)], (sew, rm, "vnclip")

@@ -1908,6 +1908,93 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
+  // ---- fixed point (vector-fixed.cpp): vsadd[u] vssub[u] (:28-640), roundoff (:645-680), vaadd[u] vasub[u] (:685-1070), vsmul (:1072-1230),
+  // vssrl vssra (:1232-1480), vnclip[u] (:1483-1800).  64-bit arithmetic only: the SEW = 64 double-wide cases are split into halves.
+  // rounding increment of roundoff(): vd / vd1 = bits d and d-1 of the value, low_nz = any of the bits below d-1 set
+  WSP_HD static u32 fx_bit(u32 rm, u32 vd, u32 vd1, bool low_nz)
+  { return rm == 0 ? vd1 : rm == 1 ? (vd1 & ((low_nz ? 1u : 0u) | vd)) : rm == 3 ? ((~vd & 1) & (vd1 | (low_nz ? 1u : 0u))) : 0; }
+  WSP_HD static u64 fx_round_u64(u32 rm, u64 v, u32 d)                          // roundoff on an unsigned 64-bit value, d in [0, 63]
+  {
+    if (d == 0) return v;
+    return (v >> d) + fx_bit(rm, (u32)(v >> d) & 1, (u32)(v >> (d - 1)) & 1, (v & ((1ull << (d - 1)) - 1)) != 0);
+  }
+  WSP_HD static i64 fx_round_s64(u32 rm, i64 v, u32 d)
+  {
+    if (d == 0) return v;
+    return (v >> d) + (i64)fx_bit(rm, (u32)(v >> d) & 1, (u32)(v >> (d - 1)) & 1, ((u64)v & ((1ull << (d - 1)) - 1)) != 0);
+  }
+  enum { FX_SADDU, FX_SADD, FX_SSUBU, FX_SSUB, FX_AADDU, FX_AADD, FX_ASUBU, FX_ASUB, FX_SMUL, FX_SSRL, FX_SSRA, FX_NCLIPU, FX_NCLIP };
+  WSP_HD u64 fx_op(u32 op, u32 rm, u64 a, u64 braw, u32 esz, bool& sat)         // a: vs2 element (raw bits), braw: second operand truncated to SEW
+  {
+    const u32 bits = 8u << esz, sh = 64 - bits;
+    const u64 on = ones_of(esz), ua = a & on, ub = braw;
+    const i64 sa = (i64)(a << sh) >> sh, sb = (i64)(braw << sh) >> sh;
+    const i64 smax = (i64)(on >> 1), smin = -smax - 1;
+    switch (op) {
+      case FX_SADDU: { const u64 t = (ua + ub) & on; if (t < ua) { sat = true; return on; } return t; }
+      case FX_SSUBU: if (ua < ub) { sat = true; return 0; } return ua - ub;
+      case FX_SADD: { const u64 t = (u64)sa + (u64)sb; const i64 r = (i64)(t << sh) >> sh;
+        if ((sa < 0) == (sb < 0) && (sa < 0) != (r < 0)) { sat = true; return (u64)(sa < 0 ? smin : smax) & on; } return (u64)r & on; }
+      case FX_SSUB: { const u64 t = (u64)sa - (u64)sb; const i64 r = (i64)(t << sh) >> sh;
+        if ((sa < 0) != (sb < 0) && (sa < 0) != (r < 0)) { sat = true; return (u64)(sa < 0 ? smin : smax) & on; } return (u64)r & on; }
+      case FX_AADDU: case FX_ASUBU: case FX_AADD: case FX_ASUB: {
+        if (esz < 3) {
+          if (op == FX_AADDU) return fx_round_u64(rm, ua + ub, 1) & on;
+          if (op == FX_ASUBU) return fx_round_u64(rm, ua - ub, 1) & on;       // wraps mod 2^64; bits 1..SEW are those of the double-wide difference
+          return (u64)fx_round_s64(rm, op == FX_AADD ? sa + sb : sa - sb, 1) & on;
+        }
+        // SEW 64: a 65-bit sum / difference (top, lo)
+        const bool sub = op == FX_ASUBU || op == FX_ASUB;
+        const u64 lo = sub ? a - braw : a + braw;
+        u64 top;
+        if (op == FX_AADDU) top = lo < a;
+        else if (op == FX_ASUBU) top = a < braw;
+        else { const bool ovf = sub ? (((a ^ braw) & (a ^ lo)) >> 63) : ((~(a ^ braw) & (a ^ lo)) >> 63); top = ovf ? (a >> 63) : (lo >> 63); }
+        return ((lo >> 1) | (top << 63)) + fx_bit(rm, (u32)(lo >> 1) & 1, (u32)lo & 1, false);
+      }
+      case FX_SMUL: {
+        if (sa == smin && sb == smin) { sat = true; return (u64)smax; }
+        if (esz < 3) return (u64)fx_round_s64(rm, sa * sb, bits - 1) & on;
+        wsf::U128 p = wsf::mul64x64(a, braw); if ((i64)a < 0) p.hi -= braw; if ((i64)braw < 0) p.hi -= a;      // signed 128-bit product
+        return ((p.hi << 1) | (p.lo >> 63)) + fx_bit(rm, (u32)(p.lo >> 63), (u32)(p.lo >> 62) & 1, (p.lo & ((1ull << 62) - 1)) != 0);
+      }
+      case FX_SSRL: return fx_round_u64(rm, ua, (u32)(braw & (bits - 1))) & on;
+      default: return (u64)fx_round_s64(rm, sa, (u32)(braw & (bits - 1))) & on;    // FX_SSRA
+    }
+  }
+  WSP_HD void v_fixed(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    if (!v_check_int(c, r, cur_pc, kind == 0)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const bool narrow = op == FX_NCLIPU || op == FX_NCLIP;
+    if (narrow) {
+      if (c.gx8 * 2 > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }
+      if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, kind == 0 ? 3 : 2, vd, false, vs2, true, vs1, false)) return;
+    } else if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8, rm = (u32)(m.cold(CI_VCSR) >> 1) & 3, bits = 8u << c.esz;
+    const u64 on = ones_of(c.esz);
+    bool sat = false;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
+          const u64 braw = (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & on;
+          if (!narrow) d = fx_op(op, rm, vrd(vs2, ix, c.esz), braw, c.esz, sat);
+          else {                                                                // source 2 * SEW <= 64 bits wide
+            const u32 amt = (u32)(braw & (2 * bits - 1));
+            if (op == FX_NCLIPU) { const u64 t = fx_round_u64(rm, vrd(vs2, ix, c.esz + 1), amt); if (t > on) { sat = true; d = on; } else d = t; }
+            else {
+              const i64 smax = (i64)(on >> 1), smin = -smax - 1, t = fx_round_s64(rm, vrd_s(vs2, ix, c.esz + 1), amt);
+              if (t > smax) { sat = true; d = (u64)smax; } else if (t < smin) { sat = true; d = (u64)smin & on; } else d = (u64)t & on;
+            }
+          }
+        }
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    if (sat) { m.cold(CI_VCSR) |= 1; s.chg |= CH_GEN; s.gen_csr = C_VXSAT; }    // csRegs_.write(VXSAT, 1): only vxsat is logged (CsRegs.cpp:4553-4570)
+    vec_success();
+  }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
   WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
   WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
@@ -2101,12 +2188,20 @@ template <class MEM> struct Lane {
         case 0x07: if (kind != 2) op = VI_MAX; break;
         case 0x09: op = VI_AND; break; case 0x0a: op = VI_OR; break; case 0x0b: op = VI_XOR; break;
         case 0x25: v_int_arith(r, cur_pc, VI_SLL, kind, kind == 2 ? uimm : sc); return;
-        case 0x27:                                                              // vmv<nr>r.v (Decoder.cpp:633-638)
-          if (kind != 2) break;
+        case 0x27:                                                              // vsmul.vv / .vx; .vi encodes vmv<nr>r.v (Decoder.cpp:633-638)
+          if (kind != 2) { v_fixed(r, cur_pc, FX_SMUL, kind, sc); return; }
           if (rs1 != 0 && rs1 != 1 && rs1 != 3 && rs1 != 7) { illegal(r, cur_pc); return; }
           v_mv_whole(r, cur_pc, rs1 + 1); return;
         case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
         case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x20: v_fixed(r, cur_pc, FX_SADDU, kind, sc); return;
+        case 0x21: v_fixed(r, cur_pc, FX_SADD, kind, sc); return;
+        case 0x22: if (kind == 2) break; v_fixed(r, cur_pc, FX_SSUBU, kind, sc); return;
+        case 0x23: if (kind == 2) break; v_fixed(r, cur_pc, FX_SSUB, kind, sc); return;
+        case 0x2a: v_fixed(r, cur_pc, FX_SSRL, kind, kind == 2 ? uimm : sc); return;
+        case 0x2b: v_fixed(r, cur_pc, FX_SSRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x2e: v_fixed(r, cur_pc, FX_NCLIPU, kind, kind == 2 ? uimm : sc); return;
+        case 0x2f: v_fixed(r, cur_pc, FX_NCLIP, kind, kind == 2 ? uimm : sc); return;
         case 0x2c: v_narrow_shift(r, cur_pc, false, kind, kind == 2 ? uimm : sc); return;
         case 0x2d: v_narrow_shift(r, cur_pc, true, kind, kind == 2 ? uimm : sc); return;
         case 0x0c: v_gather(r, cur_pc, kind, kind == 2 ? uimm : a); return;
@@ -2127,6 +2222,7 @@ template <class MEM> struct Lane {
     if (f3 == 2 || f3 == 6) {                                                   // OPMVV / OPMVX
       const bool vx = f3 == 6;
       if (f6 <= 7 && !vx) { const u8 rop[8] = { VI_ADD, VI_AND, VI_OR, VI_XOR, VI_MINU, VI_MIN, VI_MAXU, VI_MAX }; v_int_reduce(r, cur_pc, rop[f6]); return; }
+      if (f6 >= 0x08 && f6 <= 0x0b) { v_fixed(r, cur_pc, FX_AADDU + (f6 - 0x08), vx ? 1 : 0, a); return; }    // vaaddu vaadd vasubu vasub
       if (f6 == 0x17 && !vx) { v_compress(r, cur_pc); return; }
       if ((f6 == 0x0e || f6 == 0x0f) && vx) { v_slide(r, cur_pc, f6 == 0x0e, true, a); return; }             // vslide1up.vx / vslide1down.vx
       if (f6 == 0x10) {

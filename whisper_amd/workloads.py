@@ -1195,6 +1195,23 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 f6, forms = _V_INT_VVX[name], [0, 4]
             f3 = rng.choice(forms)
             a.vop(f6, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
+        elif k < 0.62:                                                   # fixed point: vxrm set now and then, saturating / averaging / scaling ops
+            if rng.random() < 0.25:
+                a.li(7, rng.randrange(4)); a.csrw(0x00A, 7)
+            q = rng.random()
+            if q < 0.35:
+                f6 = rng.choice([0x20, 0x21, 0x22, 0x23, 0x27, 0x2A, 0x2B]); forms = [0, 4] if f6 in (0x22, 0x23, 0x27) else [0, 4, 3]
+                f3 = rng.choice(forms)
+                a.vop(f6, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
+            elif q < 0.6:
+                f3 = rng.choice([2, 6]); a.vop(rng.choice([0x08, 0x09, 0x0A, 0x0B]), f3, vreg(), vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+            elif q < 0.8:                                                    # same-register operands reach the min * min and x - x corners
+                v = vreg(); a.vop(rng.choice([0x27, 0x21, 0x23, 0x20]), 0, vreg(), v, v, vm)
+            else:
+                lm = cur["lmul"] if isinstance(cur["lmul"], int) else 1
+                vsw = rng.randrange(0, 32 // min(2 * lm, 16)) * min(2 * lm, 16)
+                f3 = rng.choice([0, 4, 3])
+                a.vop(rng.choice([0x2E, 0x2F]), f3, vreg(), vsw, vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
         elif k < 0.66:
             name = rng.choice(list(_V_MUL)); f3 = rng.choice([2, 6])
             a.vop(_V_MUL[name], f3, vreg(), vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
@@ -1271,7 +1288,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x20, 0, 4, 8, 12)         # vsaddu.vv
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x10, 0, 4, 8, 12, 0)      # vadc.vvm
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
