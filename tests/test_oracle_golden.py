@@ -653,3 +653,35 @@ def test_rvv_fixed_point_known_answers():
                 assert got == [min(rnd(x, y & (2 * sew - 1), rm), m) for x, y in zip(wu, ub)], (sew, rm, "vnclipu")
                 got, _ = run(0x2F, 0, vs2=12)
                 assert got == [clamp_s(rnd(x, y & (2 * sew - 1), rm)) & m for x, y in zip(ws, ub)], (sew, rm, "vnclip")
+
+
+def test_rvv_carry_ops_known_answers():
+    """vadc / vsbc / vmadc / vmsbc: multi-word addition the way the V spec's example chains them, against Python integers."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(41)
+    for sew, ut in [(8, np.uint8), (64, np.uint64)]:
+        n = 512 // sew
+        A = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy(); B = rng.integers(0, 256, 64, dtype=np.uint8).view(ut).copy()
+        A[0] = (1 << sew) - 1; B[0] = 0; A[1] = 5; B[1] = 5
+        cin = rng.integers(0, 256, 64, dtype=np.uint8); cin[0] |= 3
+        m = (1 << sew) - 1
+        ua, ub = [int(v) for v in A], [int(v) for v in B]
+        c = [(int.from_bytes(cin.tobytes(), "little") >> i) & 1 for i in range(n)]
+
+        def run(f6, vm, vd=4):
+            a = Asm(0x80000000)
+            a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(f6, 0, vd, 8, 9, vm)
+            h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+            h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+            h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes()); h.set_vreg(0, cin.tobytes())
+            h.run(3)
+            return h
+        assert [int(v) for v in np.frombuffer(run(0x10, 0).vreg(4), dtype=ut)] == [(x + y + k) & m for x, y, k in zip(ua, ub, c)]
+        assert [int(v) for v in np.frombuffer(run(0x12, 0).vreg(4), dtype=ut)] == [(x - y - k) & m for x, y, k in zip(ua, ub, c)]
+        bits = lambda h: [(int.from_bytes(h.vreg(4), "little") >> i) & 1 for i in range(n)]
+        assert bits(run(0x11, 0)) == [int(x + y + k > m) for x, y, k in zip(ua, ub, c)]
+        assert bits(run(0x11, 1)) == [int(x + y > m) for x, y in zip(ua, ub)]
+        assert bits(run(0x13, 0)) == [int(x - y - k < 0) for x, y, k in zip(ua, ub, c)]
+        assert bits(run(0x13, 1)) == [int(x < y) for x, y in zip(ua, ub)]
+        assert run(0x10, 1).csr(0x342) == 2 and run(0x10, 0, vd=0).csr(0x342) == 2              # reserved: vm = 1, vd = v0

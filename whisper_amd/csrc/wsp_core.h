@@ -1995,6 +1995,44 @@ template <class MEM> struct Lane {
     if (sat) { m.cold(CI_VCSR) |= 1; s.chg |= CH_GEN; s.gen_csr = C_VXSAT; }    // csRegs_.write(VXSAT, 1): only vxsat is logged (CsRegs.cpp:4553-4570)
     vec_success();
   }
+  // carry / borrow: vadc vsbc (carry-in from v0; the vm = 1 encodings are reserved) and vmadc vmsbc (carry-out into a mask register;
+  // vm = 0 takes the carry-in from v0) (vector.cpp:7196-7815).  op: 0 vadc 1 vmadc 2 vsbc 3 vmsbc
+  WSP_HD void v_carry(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
+  {
+    const VCfg c = vcfg();
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u64 on = ones_of(c.esz);
+    if (op == 0 || op == 2) {
+      if (!v_check_sew_lmul_vstart(c, r, cur_pc)) return;
+      if (vd == 0 || vs2 == 0 || (kind == 0 && vs1 == 0) || !masked) { vec_fail(r, cur_pc); return; }
+      if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
+      const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+      if (0 < c.vl)
+        for (u32 ix = 0; ix < c.elem_max; ++ix) {
+          u64 d;
+          if (v_dest_active(c, vd, ix, c.esz, false, d)) {
+            const u64 a = vrd(vs2, ix, c.esz), b = kind == 0 ? vrd(vs1, ix, c.esz) : scalar, ci = v_mask_bit(ix) ? 1 : 0;
+            d = (op == 0 ? a + b + ci : a - b - ci) & on;
+          }
+          vwr(vd, ix, c.esz, dg, d);
+        }
+      vec_success(); return;
+    }
+    if (masked && (vs2 == 0 || (kind == 0 && vs1 == 0))) { vec_fail(r, cur_pc); return; }
+    if (!v_check_mask_inst(c, r, cur_pc, kind == 0)) return;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {                                 // up to elemMax: tail bits get ones
+        bool flag = true;
+        if (ix < c.vl) {
+          const u64 a = vrd(vs2, ix, c.esz), b = (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & on;
+          const bool cin = masked && v_mask_bit(ix);
+          if (op == 1) { const u64 t = (a + b + (cin ? 1 : 0)) & on; flag = cin ? t <= a : t < a; }
+          else flag = cin ? a <= b : a < b;
+        }
+        v_wr_mask_bit(vd, ix, flag);
+      }
+    vec_success();
+  }
   // ---- FP (vector-float.cpp): checkFpSewLmulVstart (:398-500)
   WSP_HD bool v_fp_legal(u32 esz) const { return fp_on() && (esz == 2 ? ext(ISA_F) : esz == 3 ? ext(ISA_D) : false); }
   WSP_HD bool v_check_fp(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
@@ -2194,6 +2232,8 @@ template <class MEM> struct Lane {
           v_mv_whole(r, cur_pc, rs1 + 1); return;
         case 0x28: v_int_arith(r, cur_pc, VI_SRL, kind, kind == 2 ? uimm : sc); return;
         case 0x29: v_int_arith(r, cur_pc, VI_SRA, kind, kind == 2 ? uimm : sc); return;
+        case 0x10: case 0x11: v_carry(r, cur_pc, f6 - 0x10, kind, sc); return;                                   // vadc / vmadc
+        case 0x12: case 0x13: if (kind == 2) break; v_carry(r, cur_pc, f6 - 0x10, kind, sc); return;             // vsbc / vmsbc
         case 0x20: v_fixed(r, cur_pc, FX_SADDU, kind, sc); return;
         case 0x21: v_fixed(r, cur_pc, FX_SADD, kind, sc); return;
         case 0x22: if (kind == 2) break; v_fixed(r, cur_pc, FX_SSUBU, kind, sc); return;

@@ -1205,6 +1205,10 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 a.vop(f6, f3, vreg(), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vm)
             elif q < 0.6:
                 f3 = rng.choice([2, 6]); a.vop(rng.choice([0x08, 0x09, 0x0A, 0x0B]), f3, vreg(), vreg(), vreg() if f3 == 2 else rng.choice(regs), vm)
+            elif q < 0.7:                                                    # vadc / vmadc / vsbc / vmsbc
+                f6 = rng.choice([0x10, 0x11, 0x12, 0x13]); f3 = rng.choice([0, 4] if f6 >= 0x12 else [0, 4, 3])
+                vmc = 0 if f6 in (0x10, 0x12) and rng.random() < 0.9 else rng.choice([0, 1])
+                a.vop(f6, f3, vreg() if f6 in (0x10, 0x12) else rng.choice([vreg(False), vreg(False), 0]), vreg(), vreg() if f3 == 0 else (rng.choice(regs) if f3 == 4 else rng.randrange(32)), vmc)
             elif q < 0.8:                                                    # same-register operands reach the min * min and x - x corners
                 v = vreg(); a.vop(rng.choice([0x27, 0x21, 0x23, 0x20]), 0, vreg(), v, v, vm)
             else:
@@ -1288,7 +1292,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x10, 0, 4, 8, 12, 0)      # vadc.vvm
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x30, 1, 4, 8, 12)         # vfwadd.vv
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
