@@ -685,3 +685,45 @@ def test_rvv_carry_ops_known_answers():
         assert bits(run(0x13, 0)) == [int(x - y - k < 0) for x, y, k in zip(ua, ub, c)]
         assert bits(run(0x13, 1)) == [int(x < y) for x, y in zip(ua, ub)]
         assert run(0x10, 1).csr(0x342) == 2 and run(0x10, 0, vd=0).csr(0x342) == 2              # reserved: vm = 1, vd = v0
+
+
+def test_rvv_fp_widening_known_answers():
+    """vfwadd / vfwsub (.vv, .wv), vfwmul, the four widening multiply-adds, vfwcvt.f.f.v / vfncvt.f.f.w, vfwredosum, vfclass at
+    SEW 32 against numpy in float64 (exact for these operands); SEW 16 and SEW 64 are illegal without Zvfh / a 128-bit type."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(43)
+    A = (rng.integers(-4000, 4000, 16) / 16).astype(np.float32); B = (rng.integers(-4000, 4000, 16) / 16).astype(np.float32)
+    D = (rng.integers(-4000, 4000, 16) / 16).astype(np.float64)
+    A[0] = np.inf; B[0] = 1.0; A[1] = np.nan
+
+    def run(f6, s1=9, f3=1, sew=32, vs2=8, vd=4, wide2=None):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(f6, f3, vd, vs2, s1)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+        h.set_vreg(8, A.tobytes()); h.set_vreg(9, B.tobytes()); h.set_vreg(4, D[:8].tobytes()); h.set_vreg(5, D[8:].tobytes())
+        if wide2 is not None:
+            h.set_vreg(12, wide2[:8].tobytes()); h.set_vreg(13, wide2[8:].tobytes())
+        h.run(3)
+        return h
+    wide = lambda h, v=4: np.frombuffer(h.vreg(v) + h.vreg(v + 1), dtype=np.float64)
+    same = lambda g, w: bool(((g == w) | (np.isnan(g) & np.isnan(w))).all())
+    a64, b64 = A.astype(np.float64), B.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        assert same(wide(run(0x30)), a64 + b64) and same(wide(run(0x32)), a64 - b64) and same(wide(run(0x38)), a64 * b64)
+        assert same(wide(run(0x34, vs2=12, wide2=D)), D + b64) and same(wide(run(0x36, vs2=12, wide2=D)), D - b64)
+        for f6, want in {0x3C: b64 * a64 + D, 0x3D: -(b64 * a64) - D, 0x3E: b64 * a64 - D, 0x3F: -(b64 * a64) + D}.items():
+            assert same(wide(run(f6)), want), hex(f6)
+        assert same(wide(run(0x12, s1=0x0C)), a64)
+        h = run(0x12, s1=0x14, vs2=12, wide2=D)
+        assert (np.frombuffer(h.vreg(4), dtype=np.float32)[:16] == D.astype(np.float32)).all()
+        h = run(0x33, vd=12, wide2=D)                                                              # vfwredosum.vs v12, v8, v9: v12[0] = v9[0] (f64) + sum
+        acc = np.frombuffer(B.tobytes(), dtype=np.float64)[0]
+        for v in a64:
+            acc = acc + v
+        got = np.frombuffer(h.vreg(12), dtype=np.float64)[0]
+        assert (np.isnan(got) and np.isnan(acc)) or got == acc
+    cls = [int(v) for v in np.frombuffer(run(0x13, s1=0x10).vreg(4), dtype=np.uint32)]
+    assert cls[0] == 0x80 and cls[1] == 0x200 and all(c in (0x02, 0x40, 0x08, 0x10) for c in cls[2:])
+    assert run(0x30, sew=16).csr(0x342) == 2 and run(0x30, sew=64).csr(0x342) == 2

@@ -2189,6 +2189,103 @@ template <class MEM> struct Lane {
     or_fflags(fl);
     vec_success();
   }
+  // ---- widening / narrowing FP at SEW 32 <-> 64 (vector-float.cpp: vfwadd / vfwsub .vv .vf .wv .wf :1000-1760, vfwmul :1930-2125, vfwmacc
+  // family :3300-3990, vfwcvt.f.f.v :5730-5810, vfncvt.f.f.w :6520-6610, vfwredusum / vfwredosum :7170-7420, vfclass.v :4925-4990).
+  // checkFpSewLmulVstart with wide = true (:398-500): SEW 32 needs F and D; SEW 16 would need Zvfh (not modelled -> illegal)
+  WSP_HD bool v_check_fp_wide(const VCfg& c, const Rec& r, u64 cur_pc, int& rm)
+  {
+    if (!vec_on() || c.vill || m.cold(CI_VSTART) > 0) { vec_fail(r, cur_pc); return false; }
+    if (!(c.esz == 2 && fp_on() && ext(ISA_F) && ext(ISA_D)) || !fp_rm(7, rm)) { vec_fail(r, cur_pc); return false; }
+    return true;
+  }
+  // op: 0 add 1 sub 2 mul, 8 + k multiply-add (k: 4 macc 5 nmacc 6 msac 7 nmsac)
+  WSP_HD void v_fp_widen(const Rec& r, u64 cur_pc, u32 op, bool vf, bool wide_src)
+  {
+    using namespace wsf;
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_int(c, r, cur_pc, !vf)) return;
+    if (!v_check_fp_wide(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 wg = c.gx8 * 2;
+    if (wg > 64) { vec_fail(r, cur_pc); return; }
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, 2, vf ? 2 : 3, vd, true, vs2, wide_src, vs1, false, op >= 8)) return;
+    const u32 vlmax = c.gx8 * vlenb / 32, single = vlenb >> 3, elems = vlmax > single ? vlmax : single, dg = wg < 8 ? 8 : wg;
+    const u64 sc = vf ? vf_scalar(vs1, 2) : 0;
+    unsigned fl = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < elems; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, 3, masked, d)) {
+          u64 e1 = f32_to_f64(vf ? sc : vrd(vs1, ix, 2), fl);
+          const u64 e2 = wide_src ? vrd(vs2, ix, 3) : f32_to_f64(vrd(vs2, ix, 2), fl);
+          if (op < 8) d = vf_op(op, e2, e1, 3, rm, fl);
+          else {
+            const u32 k = op - 8; u64 dd = vrd(vd, ix, 3);
+            if (k & 1) e1 = fneg<F64>(e1, fl);
+            if (k == 5 || k == 6) dd = fneg<F64>(dd, fl);
+            d = f_fma<F64>(e1, e2, dd, rm, fl);
+          }
+        }
+        vwr(vd, ix, 3, dg, d);
+      }
+    or_fflags(fl);
+    vec_success();
+  }
+  WSP_HD void v_fp_cvt_ff(const Rec& r, u64 cur_pc, bool narrow)                // vfwcvt.f.f.v / vfncvt.f.f.w
+  {
+    using namespace wsf;
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    if (!v_check_fp_wide(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 wg = c.gx8 * 2;
+    if (wg > 64) { vec_fail(r, cur_pc); return; }
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, 2, 2, vd, !narrow, vs2, narrow, 0, false)) return;
+    const u32 dsz = narrow ? 2 : 3, vlmax = c.gx8 * vlenb / 32, single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
+    const u32 dg8 = narrow ? c.gx8 : wg, dg = dg8 < 8 ? 8 : dg8;
+    unsigned fl = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < elems; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, dsz, masked, d)) d = narrow ? f64_to_f32(vrd(vs2, ix, 3), rm, fl) : f32_to_f64(vrd(vs2, ix, 2), fl);
+        vwr(vd, ix, dsz, dg, d);
+      }
+    or_fflags(fl);
+    vec_success();
+  }
+  WSP_HD void v_fp_wredsum(const Rec& r, u64 cur_pc)                            // vfwredusum / vfwredosum: sequential at the defaults
+  {
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_fp_wide(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    const u32 lm = c.gx8 >= 8 ? c.gx8 / 8 : 1;
+    if ((vs2 & (lm - 1)) || (masked && (vs2 == 0 || vs1 == 0)) || (vs1 >= vs2 && vs1 < vs2 + lm)) { vec_fail(r, cur_pc); return; }   // checkWideRedOpVsEmul
+    unsigned fl = 0;
+    if (c.vl != 0) {
+      u64 res = vrd(vs1, 0, 3);
+      for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vf_op(0, res, wsf::f32_to_f64(vrd(vs2, ix, 2), fl), 3, rm, fl); }
+      vwr(vd, 0, 3, 8, res);
+      if (c.ta) for (u32 ix = 1; ix < (vlenb >> 3); ++ix) vwr(vd, ix, 3, 8, ~0ull);
+    }
+    or_fflags(fl);
+    vec_success();
+  }
+  WSP_HD void v_fp_class(const Rec& r, u64 cur_pc)
+  {
+    const VCfg c = vcfg(); int rm = 0;
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    if (!v_check_fp(c, r, cur_pc, rm)) return;
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
+    const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = c.esz == 2 ? wsf::fclass<wsf::F32>(vrd(vs2, ix, 2)) : wsf::fclass<wsf::F64>(vrd(vs2, ix, 3));
+        vwr(vd, ix, c.esz, dg, d);
+      }
+    vec_success();
+  }
   WSP_HD bool v_fp_mv_check(const VCfg& c, const Rec& r, u64 cur_pc)            // vfmv.* prologue (:503-515, 585-595, 4169-4180)
   {
     int rm;
@@ -2348,12 +2445,25 @@ template <class MEM> struct Lane {
         if (!v_fp_mv_check(c, r, cur_pc)) return;
         if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
         v_mv_s(c, rd, vf_scalar(rs1, c.esz)); return; }
-      case 0x12:                                                                // VFUNARY0 (Decoder.cpp:394-405): same-width conversions only
+      case 0x12:                                                                // VFUNARY0 (Decoder.cpp:394-425)
         if (vf) break;
         if (rs1 <= 3) { v_fp_unary(r, cur_pc, 1 + rs1); return; }
         if (rs1 == 6 || rs1 == 7) { v_fp_unary(r, cur_pc, rs1 - 1); return; }
+        if (rs1 == 0x0c) { v_fp_cvt_ff(r, cur_pc, false); return; }             // vfwcvt.f.f.v
+        if (rs1 == 0x14) { v_fp_cvt_ff(r, cur_pc, true); return; }              // vfncvt.f.f.w
         break;
-      case 0x13: if (vf || rs1 != 0) break; v_fp_unary(r, cur_pc, 0); return;   // vfsqrt.v (Decoder.cpp:427)
+      case 0x13:                                                                // VFUNARY1 (Decoder.cpp:427-433)
+        if (vf) break;
+        if (rs1 == 0) { v_fp_unary(r, cur_pc, 0); return; }                     // vfsqrt.v
+        if (rs1 == 0x10) { v_fp_class(r, cur_pc); return; }                     // vfclass.v
+        break;
+      case 0x30: v_fp_widen(r, cur_pc, 0, vf, false); return;                   // vfwadd
+      case 0x32: v_fp_widen(r, cur_pc, 1, vf, false); return;                   // vfwsub
+      case 0x34: v_fp_widen(r, cur_pc, 0, vf, true); return;                    // vfwadd.w
+      case 0x36: v_fp_widen(r, cur_pc, 1, vf, true); return;                    // vfwsub.w
+      case 0x38: v_fp_widen(r, cur_pc, 2, vf, false); return;                   // vfwmul
+      case 0x3c: case 0x3d: case 0x3e: case 0x3f: v_fp_widen(r, cur_pc, 8 + 4 + (f6 - 0x3c), vf, false); return;   // vfwmacc vfwnmacc vfwmsac vfwnmsac
+      case 0x31: case 0x33: if (vf) break; v_fp_wredsum(r, cur_pc); return;     // vfwredusum / vfwredosum
       case 0x17: {
         if (!vf) break;
         if (!vm) { v_fp_merge(r, cur_pc); return; }                             // vfmerge.vfm (Decoder.cpp:811)

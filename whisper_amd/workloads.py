@@ -1266,6 +1266,21 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                     a.vop(0x12, 1, vreg(), vreg(), rng.choice([0, 1, 2, 3, 6, 7]), vm)
                 else:
                     a.vop(0x17, 5, vreg(), vreg(), rng.randrange(32), 0)
+            elif r < 0.60:                                                   # widening FP (SEW 32 -> 64), f <-> f width changes, vfclass
+                lm = cur["lmul"] if isinstance(cur["lmul"], int) else 1
+                vdw = (rng.randrange(0, 32 // min(2 * lm, 16)) * min(2 * lm, 16)) % 32 if rng.random() < 0.85 else rng.randrange(32)
+                q = rng.random(); f3 = rng.choice([1, 5])
+                if q < 0.55:
+                    f6 = rng.choice([0x30, 0x32, 0x34, 0x36, 0x38, 0x3C, 0x3D, 0x3E, 0x3F])
+                    a.vop(f6, f3, vdw, vdw if f6 in (0x34, 0x36) and rng.random() < 0.6 else vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
+                elif q < 0.7:
+                    a.vop(0x12, 1, vdw, vreg(), 0x0C, vm)
+                elif q < 0.8:
+                    a.vop(0x12, 1, vreg(), vdw, 0x14, vm)
+                elif q < 0.9:
+                    a.vop(rng.choice([0x31, 0x33]), 1, vreg(False), vreg(), vreg(False), vm)
+                else:
+                    a.vop(0x13, 1, vreg(), vreg(), 0x10, vm)
             elif r < 0.62:                                                   # vmfeq vmfle vmflt vmfne (.vv / .vf), vmfgt vmfge (.vf)
                 f6 = rng.choice([0x18, 0x19, 0x1B, 0x1C, 0x1D, 0x1F]); f3 = 5 if f6 in (0x1D, 0x1F) else rng.choice([1, 5])
                 a.vop(f6, f3, rng.choice([0, 0, vreg(False)]), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
@@ -1292,7 +1307,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x30, 1, 4, 8, 12)         # vfwadd.vv
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x13, 1, 4, 8, 5)          # vfrec7.v
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
