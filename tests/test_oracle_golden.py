@@ -727,3 +727,33 @@ def test_rvv_fp_widening_known_answers():
     cls = [int(v) for v in np.frombuffer(run(0x13, s1=0x10).vreg(4), dtype=np.uint32)]
     assert cls[0] == 0x80 and cls[1] == 0x200 and all(c in (0x02, 0x40, 0x08, 0x10) for c in cls[2:])
     assert run(0x30, sew=16).csr(0x342) == 2 and run(0x30, sew=64).csr(0x342) == 2
+
+
+def test_rvv_indexed_segment_known_answers():
+    """vluxseg2ei16.v gathers two-field records at 16-bit byte offsets; vsoxseg2ei16.v scatters them; the index register may not
+    overlap the destination registers at all."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(47)
+    table = rng.integers(0, 2**32, 512, dtype=np.uint32)
+    idx = (rng.permutation(256)[:16] * 8).astype(np.uint16)
+
+    def hart(build):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(32, 1))
+        build(a)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.write_mem(0x80001000, table.tobytes()); h.pc = 0x80000000
+        h.set_x(5, 0x6600); h.set_x(10, 0x80001000); h.set_x(11, 0x80004000)
+        h.set_vreg(8, idx.tobytes() + bytes(32))
+        return h
+    h = hart(lambda a: (a.vls(False, 16, 4, 10, lumop=8, mop=1, nf=1), a.vls(True, 16, 4, 11, lumop=8, mop=3, nf=1)))
+    h.run(4)
+    rec = table.reshape(256, 2)
+    assert (np.frombuffer(h.vreg(4), dtype=np.uint32) == rec[idx // 8, 0]).all() and (np.frombuffer(h.vreg(5), dtype=np.uint32) == rec[idx // 8, 1]).all()
+    out = np.frombuffer(h.read_mem(0x80004000, 2048), dtype=np.uint32).reshape(256, 2)
+    want = np.zeros((256, 2), dtype=np.uint32); want[idx // 8] = rec[idx // 8]
+    assert (out == want).all()
+    h = hart(lambda a: a.vls(False, 16, 7, 10, lumop=8, mop=1, nf=1))          # fields land in v7, v8: v8 holds the indices
+    h.run(3)
+    assert h.csr(0x342) == 2

@@ -1332,40 +1332,53 @@ template <class MEM> struct Lane {
   }
   // indexed loads / stores vluxei / vloxei / vsuxei / vsoxei (vector-ls.cpp:1268-1382, 1570-1720; checks :32-109, vector.cpp:301-320):
   // data EEW = SEW, index EEW from the encoding, offsets zero-extended
-  WSP_HD void v_ldst_indexed(const Rec& r, u64 base, u64 cur_pc, u32 ieew, bool store)
+  WSP_HD void v_ldst_indexed(const Rec& r, u64 base, u64 cur_pc, u32 ieew, bool store, u32 fields)
   {
+    // fields > 1: vluxseg / vloxseg / vsuxseg / vsoxseg (vector-ls.cpp:2519-2960): all or nothing per element, like the other segment forms
     const VCfg c = vcfg();
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vi = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     const u32 ogx8 = (8u << ieew) * c.gx8 / (8u << c.esz);
     const bool sym = ogx8 == 1 || ogx8 == 2 || ogx8 == 4 || ogx8 == 8 || ogx8 == 16 || ogx8 == 32 || ogx8 == 64;
-    if (!vec_on() || !sym || c.vill) { vec_fail(r, cur_pc); return; }
-    const u32 eg0 = c.gx8 >= 8 ? c.gx8 / 8 : 1, eg2 = ogx8 >= 8 ? ogx8 / 8 : 1;
+    if (!vec_on() || !sym || c.gx8 * fields > 64 || c.vill) { vec_fail(r, cur_pc); return; }
+    const u32 eg0 = c.gx8 >= 8 ? c.gx8 / 8 : 1, eg2 = ogx8 >= 8 ? ogx8 / 8 : 1, seg = eg0 * fields;
     bool ok = !(vd & (eg0 - 1)) && !(vi & (eg2 - 1)) && !(masked && (vd == 0 || vi == 0));
-    if (store) ok = ok && (c.esz == ieew || vd >= vi + eg2 || vi >= vd + eg0);                                // checkSourceOverlap
+    if (fields > 1) {                                                           // checkVecLdStIndexedInst, segment case (:80-104)
+      const bool apart = vi >= vd + seg || vd >= vi + eg2;
+      ok = ok && (store ? (c.esz == ieew || apart) : apart) && vd + seg <= 32;
+    }
+    else if (store) ok = ok && (c.esz == ieew || vd >= vi + eg2 || vi >= vd + eg0);                           // checkSourceOverlap
     else ok = ok && v_overlap_ok(vd, 8u << c.esz, c.gx8, vi, 8u << ieew, ogx8);
     if (!ok) { vec_fail(r, cur_pc); return; }
-    const u32 size = 1u << c.esz, start = (u32)m.cold(CI_VSTART), dg = c.gx8 < 8 ? 8 : c.gx8;
+    const u32 size = 1u << c.esz, start = (u32)m.cold(CI_VSTART), dg = (c.gx8 < 8 ? 8 : c.gx8) * fields;
+    u64 pa1[8], pa2[8], val[8], tval;
     if (store) {
       for (u32 ix = start; ix < c.vl; ++ix) {
         if (masked && !v_mask_bit(ix)) continue;
         const u64 vaddr = base + vrd(vi, ix, ieew);
-        u64 pa1, pa2, tval;
-        if (paging_unsupported()) return;
-        const u32 cause = ldst_addr(vaddr, size, 2, pa1, pa2, tval);
-        if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
-        if (!v_store_elem(pa1, pa2, size, vrd(vd, ix, c.esz))) return;
+        for (u32 f = 0; f < fields; ++f) {
+          if (paging_unsupported()) return;
+          const u32 cause = ldst_addr(vaddr + (u64)f * size, size, 2, pa1[f], pa2[f], tval);
+          if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+        }
+        for (u32 f = 0; f < fields; ++f) if (!v_store_elem(pa1[f], pa2[f], size, vrd(vd + f * eg0, ix, c.esz))) return;
       }
       vec_success(); return;
     }
     if (start < c.vl)
       for (u32 ix = start; ix < c.elem_max; ++ix) {
-        u64 elem, pa1, pa2, tval;
-        if (!v_dest_active(c, vd, ix, c.esz, masked, elem)) { vwr(vd, ix, c.esz, dg, elem); continue; }
+        u64 elem;
+        if (!v_dest_active(c, vd, ix, c.esz, masked, elem)) {
+          for (u32 f = 0; f < fields; ++f) { v_dest_active(c, vd + f * eg0, ix, c.esz, masked, elem); vwr(vd + f * eg0, ix, c.esz, dg, elem); }
+          continue;
+        }
         const u64 vaddr = base + vrd(vi, ix, ieew);
-        if (paging_unsupported()) return;
-        const u32 cause = ldst_addr(vaddr, size, 1, pa1, pa2, tval);
-        if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
-        vwr(vd, ix, c.esz, dg, pa1 == tohost ? 0 : mem_read2(pa1, pa2, size));
+        for (u32 f = 0; f < fields; ++f) {
+          if (paging_unsupported()) return;
+          const u32 cause = ldst_addr(vaddr + (u64)f * size, size, 1, pa1[f], pa2[f], tval);
+          if (cause) { v_ldst_fault(cause, ix, tval, cur_pc); return; }
+          val[f] = pa1[f] == tohost ? 0 : mem_read2(pa1[f], pa2[f], size);
+        }
+        for (u32 f = 0; f < fields; ++f) vwr(vd + f * eg0, ix, c.esz, dg, val[f]);
       }
     vec_success();
   }
@@ -2496,7 +2509,7 @@ template <class MEM> struct Lane {
       if (store) v_store_unit(r, a, b, cur_pc, 0, false, true); else v_load_unit(r, a, b, cur_pc, 0, false, true);
       return;
     }
-    if ((mop == 1 || mop == 3) && nf == 0 && mew == 0) { v_ldst_indexed(r, a, cur_pc, eew, store); return; }   // indexed, unordered and ordered alike
+    if ((mop == 1 || mop == 3) && mew == 0) { v_ldst_indexed(r, a, cur_pc, eew, store, nf + 1); return; }      // indexed (and indexed segment), unordered and ordered alike
     if (mew == 0 && ((mop == 0 && lumop == 0) || mop == 2) && nf != 0) {        // vlseg / vsseg / vlsseg / vssseg (Decoder.cpp:930-947, 1030-1050)
       v_ldst_seg(r, a, cur_pc, eew, nf + 1, mop == 2 ? b : (u64)(nf + 1) << eew, store, false, true); return;
     }

@@ -1134,7 +1134,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                     a.vop(0x14, 2, vi, 0, 0x11, 1)                           # vid.v vi
                     a.vop(0x25, 3, vi, vi, rng.choice([0, 1, 2, 3]), 1)      # vsll.vi vi, vi, k
                 a.li(P, ARENA + 8 * rng.randrange(0x100))
-                a.vls(rng.random() < 0.5, ieew, vreg(), P, lumop=vi, vm=vm, mop=rng.choice([1, 3]))
+                a.vls(rng.random() < 0.5, ieew, vreg(), P, lumop=vi, vm=vm, mop=rng.choice([1, 3]), nf=rng.choice([0, 0, 0, 1, 2, 3]))
             elif r < 0.8 and rng.random() < 0.5:                             # segments (unit-stride / strided) and fault-only-first loads
                 nf = rng.choice([2, 2, 3, 4, 8])
                 v = rng.randrange(0, 32)
