@@ -757,3 +757,51 @@ def test_rvv_indexed_segment_known_answers():
     h = hart(lambda a: a.vls(False, 16, 7, 10, lumop=8, mop=1, nf=1))          # fields land in v7, v8: v8 holds the indices
     h.run(3)
     assert h.csr(0x342) == 2
+
+
+def test_rvv_fp_int_width_conversions_known_answers():
+    """vfwcvt.x.f.v (f32 -> i64), vfwcvt.f.x.v (i16 -> f32, i32 -> f64), vfncvt.x.f.w (f32 -> i16 with clamping, f64 -> i32),
+    vfncvt.rtz.xu.f.w, vfncvt.f.x.w (i64 -> f32) against numpy."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(53)
+
+    def run(sew, code, v8, v9=None, vs2=8):
+        a = Asm(0x80000000)
+        a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(0x12, 1, 4, vs2, code)
+        h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+        h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+        h.set_vreg(8, v8.tobytes())
+        if v9 is not None:
+            h.set_vreg(9, v9.tobytes())
+        h.run(3)
+        return h
+    F = (rng.integers(-80000, 80000, 16) / 4).astype(np.float32); F[0] = 2.5; F[1] = -3.5; F[2] = 1e10; F[3] = np.nan
+    rne = lambda v: int(np.rint(np.float64(v)))
+    h = run(32, 0x09, F)                                                                           # vfwcvt.x.f.v
+    got = np.frombuffer(h.vreg(4) + h.vreg(5), dtype=np.int64)
+    assert [int(g) for g in got] == [2**63 - 1 if np.isnan(v) else rne(v) for v in F]
+    I16 = rng.integers(-2**15, 2**15, 32).astype(np.int16)
+    h = run(16, 0x0B, I16)                                                                         # vfwcvt.f.x.v at SEW 16: i16 -> f32
+    assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=np.float32) == I16.astype(np.float32)).all()
+    h = run(16, 0x0A, I16)                                                                         # vfwcvt.f.xu.v
+    assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=np.float32) == I16.view(np.uint16).astype(np.float32)).all()
+    I32 = rng.integers(-2**31, 2**31, 16).astype(np.int32)
+    h = run(32, 0x0B, I32)
+    assert (np.frombuffer(h.vreg(4) + h.vreg(5), dtype=np.float64) == I32.astype(np.float64)).all()
+    W = np.concatenate([F, (rng.integers(-80000, 80000, 16) / 4).astype(np.float32)])              # 32 f32 = the wide source at SEW 16
+    h = run(16, 0x11, W[:16], W[16:])                                                              # vfncvt.x.f.w: f32 -> i16, clamped, NV on overflow
+    got = np.frombuffer(h.vreg(4), dtype=np.int16)
+    assert [int(g) for g in got] == [32767 if np.isnan(v) else max(-32768, min(32767, rne(v))) for v in W]
+    assert h.csr(0x003) & 0x10
+    h = run(16, 0x16, W[:16], W[16:])                                                              # vfncvt.rtz.xu.f.w: f32 -> u16, truncating
+    got = np.frombuffer(h.vreg(4), dtype=np.uint16)
+    assert [int(g) for g in got] == [65535 if np.isnan(v) else max(0, min(65535, int(np.float64(v)))) for v in W]
+    D = (rng.integers(-2**40, 2**40, 16) / 8).astype(np.float64)
+    h = run(32, 0x11, D[:8], D[8:])                                                                # f64 -> i32
+    got = np.frombuffer(h.vreg(4), dtype=np.int32)
+    assert [int(g) for g in got] == [max(-2**31, min(2**31 - 1, rne(v))) for v in D]
+    I64 = rng.integers(-2**62, 2**62, 16).astype(np.int64)
+    h = run(32, 0x13, I64[:8], I64[8:])                                                            # vfncvt.f.x.w: i64 -> f32
+    assert (np.frombuffer(h.vreg(4), dtype=np.float32) == I64.astype(np.float32)).all()
+    assert run(8, 0x0B, I16).csr(0x342) == 2 and run(64, 0x09, D[:8]).csr(0x342) == 2              # f16 side without Zvfh; no 128-bit side

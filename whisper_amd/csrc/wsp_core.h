@@ -2299,6 +2299,53 @@ template <class MEM> struct Lane {
       }
     vec_success();
   }
+  // widening / narrowing int <-> float conversions (vector-float.cpp:5330-5730, 5815-6520; fpConvertTo, float-util.hpp:225-400).
+  // code = the vs1 field of VFUNARY0: 8 vfwcvt.xu.f 9 .x.f 0xa .f.xu 0xb .f.x 0xe .rtz.xu.f 0xf .rtz.x.f;
+  // 0x10 vfncvt.xu.f.w 0x11 .x.f.w 0x12 .f.xu.w 0x13 .f.x.w 0x16 .rtz.xu.f.w 0x17 .rtz.x.f.w
+  WSP_HD void v_fp_cvt_wn(const Rec& r, u64 cur_pc, u32 code)
+  {
+    using namespace wsf;
+    const VCfg c = vcfg(); int rm = 0;
+    const bool narrow = code >= 0x10, to_int = !(code == 0xa || code == 0xb || code == 0x12 || code == 0x13), sg = code & 1, rtz = (code & 7) >= 6;
+    if (!v_check_int(c, r, cur_pc, false)) return;
+    const bool fp_is_sew = (!narrow && to_int) || (narrow && !to_int);          // the float side has SEW bits: checkVecFpInst applies
+    if (fp_is_sew) { if (!v_check_fp(c, r, cur_pc, rm)) return; }
+    else if (!fp_rm(7, rm)) { vec_fail(r, cur_pc); return; }
+    const u32 wg = c.gx8 * 2;
+    if (wg > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }
+    const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
+    if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, 2, vd, !narrow, vs2, narrow, 0, false)) return;
+    if (!fp_is_sew && (c.esz == 0 || !v_fp_legal(c.esz + 1))) { vec_fail(r, cur_pc); return; }   // the float side is 2 * SEW wide
+    const u32 dsz = narrow ? c.esz : c.esz + 1, ssz = narrow ? c.esz + 1 : c.esz;
+    const u32 vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
+    const u32 dg8 = narrow ? c.gx8 : wg, dg = dg8 < 8 ? 8 : dg8;
+    if (rtz) rm = RM_RTZ;
+    unsigned fl = 0;
+    if (0 < c.vl)
+      for (u32 ix = 0; ix < elems; ++ix) {
+        u64 d;
+        if (v_dest_active(c, vd, ix, dsz, masked, d)) {
+          const u64 a = vrd(vs2, ix, ssz);
+          if (to_int) {
+            if (ssz == 2 && dsz == 3) d = f_to_int<F32>(a, rm, sg, true, fl);
+            else if (ssz == 3) d = f_to_int<F64>(a, rm, sg, false, fl) & 0xffffffffull;
+            else {                                                              // f32 -> 16 bits through the 32-bit conversion (float-util.hpp:309-327)
+              unsigned f2 = 0; const u64 v = f_to_int<F32>(a, rm, sg, false, f2);
+              if (sg) { i64 t = (i64)(i32)v; if (t > 32767) { t = 32767; f2 = FL_NV; } else if (t < -32768) { t = -32768; f2 = FL_NV; } d = (u64)t & 0xffff; }
+              else { u64 t = v & 0xffffffffull; if (t > 65535) { t = 65535; f2 = FL_NV; } d = t; }
+              fl |= f2;
+            }
+          } else {
+            if (ssz == 1) d = int_to_f<F32>(sg ? (u64)(i64)(int16_t)a : (a & 0xffff), sg, false, rm, fl);
+            else if (ssz == 2) d = int_to_f<F64>(a, sg, false, rm, fl);
+            else d = int_to_f<F32>(a, sg, true, rm, fl);
+          }
+        }
+        vwr(vd, ix, dsz, dg, d);
+      }
+    or_fflags(fl);
+    vec_success();
+  }
   WSP_HD bool v_fp_mv_check(const VCfg& c, const Rec& r, u64 cur_pc)            // vfmv.* prologue (:503-515, 585-595, 4169-4180)
   {
     int rm;
@@ -2464,6 +2511,7 @@ template <class MEM> struct Lane {
         if (rs1 == 6 || rs1 == 7) { v_fp_unary(r, cur_pc, rs1 - 1); return; }
         if (rs1 == 0x0c) { v_fp_cvt_ff(r, cur_pc, false); return; }             // vfwcvt.f.f.v
         if (rs1 == 0x14) { v_fp_cvt_ff(r, cur_pc, true); return; }              // vfncvt.f.f.w
+        if ((rs1 >= 0x08 && rs1 <= 0x0b) || rs1 == 0x0e || rs1 == 0x0f || (rs1 >= 0x10 && rs1 <= 0x13) || rs1 == 0x16 || rs1 == 0x17) { v_fp_cvt_wn(r, cur_pc, rs1); return; }
         break;
       case 0x13:                                                                // VFUNARY1 (Decoder.cpp:427-433)
         if (vf) break;

@@ -1255,10 +1255,10 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
             a.vop(_V_RED[rng.choice(list(_V_RED))], 2, vreg(False), vreg(), vreg(False), vm)
         elif k < 0.93:
             r = rng.random()
-            if r < 0.5:
+            if r < 0.35:
                 name = rng.choice(list(_V_FP)); f3 = rng.choice([1, 5])
                 a.vop(_V_FP[name], f3, vreg(), vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
-            elif r < 0.56:                                                   # vfsqrt.v, same-width vfcvt.*, vfmerge.vfm
+            elif r < 0.44:                                                   # vfsqrt.v, same-width vfcvt.*, vfmerge.vfm
                 q = rng.random()
                 if q < 0.3:
                     a.vop(0x13, 1, vreg(), vreg(), 0, vm)
@@ -1273,11 +1273,14 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 if q < 0.55:
                     f6 = rng.choice([0x30, 0x32, 0x34, 0x36, 0x38, 0x3C, 0x3D, 0x3E, 0x3F])
                     a.vop(f6, f3, vdw, vdw if f6 in (0x34, 0x36) and rng.random() < 0.6 else vreg(), vreg() if f3 == 1 else rng.randrange(32), vm)
-                elif q < 0.7:
+                elif q < 0.7:                                                # widening / narrowing int <-> float conversions
+                    code = rng.choice([0x08, 0x09, 0x0A, 0x0B, 0x0E, 0x0F, 0x10, 0x11, 0x12, 0x13, 0x16, 0x17])
+                    a.vop(0x12, 1, vdw if code < 0x10 else vreg(), vreg() if code < 0x10 else vdw, code, vm)
+                elif q < 0.78:
                     a.vop(0x12, 1, vdw, vreg(), 0x0C, vm)
-                elif q < 0.8:
+                elif q < 0.86:
                     a.vop(0x12, 1, vreg(), vdw, 0x14, vm)
-                elif q < 0.9:
+                elif q < 0.94:
                     a.vop(rng.choice([0x31, 0x33]), 1, vreg(False), vreg(), vreg(False), vm)
                 else:
                     a.vop(0x13, 1, vreg(), vreg(), 0x10, vm)
