@@ -805,3 +805,36 @@ def test_rvv_fp_int_width_conversions_known_answers():
     h = run(32, 0x13, I64[:8], I64[8:])                                                            # vfncvt.f.x.w: i64 -> f32
     assert (np.frombuffer(h.vreg(4), dtype=np.float32) == I64.astype(np.float32)).all()
     assert run(8, 0x0B, I16).csr(0x342) == 2 and run(64, 0x09, D[:8]).csr(0x342) == 2              # f16 side without Zvfh; no 128-bit side
+
+
+def test_rvv_estimates_known_answers():
+    """vfrsqrt7.v / vfrec7.v: 7-bit estimates (relative error < 2^-7 on normal inputs, exact values at 1.0), and the special cases of
+    the V spec: zeros -> infinities with DZ, infinities -> zeros, negative / NaN inputs, 1 / subnormal overflowing per frm."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(59)
+    for sew, ft, ut in [(32, np.float32, np.uint32), (64, np.float64, np.uint64)]:
+        n = 512 // sew
+        X = np.exp(rng.uniform(-60, 60, n)).astype(ft)
+        X[0] = 1.0; X[1] = 0.0; X[2] = -0.0; X[3] = np.inf; X[4] = -np.inf; X[5] = -2.0; X[6] = np.nan
+        X[7] = np.finfo(ft).tiny / 16                                                              # subnormal with more than two leading zeros
+
+        def run(code, frm=0):
+            a = Asm(0x80000000)
+            a.csrs(0x300, 5); a.li(7, frm << 5); a.csrw(0x003, 7); a.vsetvli(6, 0, Asm.vtype(sew, 1)); a.vop(0x13, 1, 4, 8, code)
+            h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+            h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600); h.set_vreg(8, X.tobytes())
+            h.run(6)
+            return np.frombuffer(h.vreg(4), dtype=ft), h.csr(0x001)
+        with np.errstate(all="ignore"):
+            r, fl = run(5)                                                                         # vfrec7.v, RNE
+            assert r[0] == 0.99609375 and r[1] == np.inf and np.isneginf(r[2]) and r[3] == 0 and r[4] == 0 and np.signbit(r[4])
+            assert abs(r[5] * -2.0 - 1) < 2.0**-7 and np.isnan(r[6]) and r[7] == np.inf and fl == 0x08 | 0x05
+            assert (np.abs(r[8:].astype(np.float64) * X[8:].astype(np.float64) - 1) < 2.0**-7).all()
+            r, fl = run(5, frm=1)                                                                  # RTZ: overflow gives the largest finite value
+            assert r[7] == np.finfo(ft).max
+            r, fl = run(4)                                                                         # vfrsqrt7.v
+            assert r[0] == 0.99609375 and r[1] == np.inf and np.isneginf(r[2]) and r[3] == 0 and np.isnan(r[4]) and np.isnan(r[5]) and np.isnan(r[6])
+            assert fl == 0x08 | 0x10
+            x = X[7:].astype(np.float64)
+            rr = r[7:].astype(np.float64); assert (np.abs(rr * x * rr - 1) < 2.0**-5.9).all()

@@ -2147,6 +2147,33 @@ template <class MEM> struct Lane {
     or_fflags(fl);
     vec_success();
   }
+  // vfrsqrt7.v / vfrec7.v (vector-float.cpp:175-329): the 7-bit estimates of the V spec (its two 128-entry lookup tables), written over the
+  // bit fields.  rec = false: 1 / sqrt(x), true: 1 / x
+  WSP_HD static u64 v_est7(bool rec, u64 a, u32 esz, u32 rm, unsigned& fl)
+  {
+    using namespace wsf;
+    const u8 rsq[128] = { 52, 51, 50, 48, 47, 46, 44, 43, 42, 41, 40, 39, 38, 36, 35, 34, 33, 32, 31, 30, 30, 29, 28, 27, 26, 25, 24, 23, 23, 22, 21, 20, 19, 19, 18, 17, 16, 16, 15, 14, 14, 13, 12, 12, 11, 10, 10, 9, 9, 8, 7, 7, 6, 6, 5, 4, 4, 3, 3, 2, 2, 1, 1, 0, 127, 125, 123, 121, 119, 118, 116, 114, 113, 111, 109, 108, 106, 105, 103, 102, 100, 99, 97, 96, 95, 93, 92, 91, 90, 88, 87, 86, 85, 84, 83, 82, 80, 79, 78, 77, 76, 75, 74, 73, 72, 71, 70, 70, 69, 68, 67, 66, 65, 64, 63, 63, 62, 61, 60, 59, 59, 58, 57, 56, 56, 55, 54, 53 };
+    const u8 rcp[128] = { 127, 125, 123, 121, 119, 117, 116, 114, 112, 110, 109, 107, 105, 104, 102, 100, 99, 97, 96, 94, 93, 91, 90, 88, 87, 85, 84, 83, 81, 80, 79, 77, 76, 75, 74, 72, 71, 70, 69, 68, 66, 65, 64, 63, 62, 61, 60, 59, 58, 57, 56, 55, 54, 53, 52, 51, 50, 49, 48, 47, 46, 45, 44, 43, 42, 41, 40, 40, 39, 38, 37, 36, 35, 35, 34, 33, 32, 31, 31, 30, 29, 28, 28, 27, 26, 25, 25, 24, 23, 23, 22, 21, 21, 20, 19, 19, 18, 17, 17, 16, 15, 15, 14, 14, 13, 12, 12, 11, 11, 10, 9, 9, 8, 8, 7, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 0 };
+    const u32 MB = esz == 2 ? 23 : 52, EB = esz == 2 ? 8 : 11; const int B = (1 << (EB - 1)) - 1, maxE = (1 << EB) - 1;
+    const u64 sign = 1ull << (MB + EB), mant = (1ull << MB) - 1, inf = (u64)maxE << MB, qnan = inf | (1ull << (MB - 1));
+    const u64 sg = a & sign; u64 M = a & mant; const int E = (int)((a >> MB) & (u64)maxE);
+    if (E == 0 && M == 0) { fl |= FL_DZ; return sg | inf; }
+    if (E == maxE && M == 0 && (rec || !sg)) return rec ? sg : 0;
+    if (E == maxE && M != 0) { if (!(M >> (MB - 1))) fl |= FL_NV; return qnan; }
+    if (!rec && sg) { fl |= FL_NV; return qnan; }
+    int in_exp = E;
+    if (E == 0) { int sft = 0; while (!(M & (1ull << MB))) { M <<= 1; ++sft; } M &= mant; in_exp = 1 - sft; }   // frexp normalises subnormals
+    if (!rec) {
+      const u32 idx = ((u32)(in_exp & 1) << 6) | (u32)(M >> (MB - 6));
+      const u64 out_exp = (u64)((3 * B - 1 - in_exp) / 2);
+      return ((u64)rsq[idx] << (MB - 7)) | (out_exp << MB);
+    }
+    if (in_exp < -1 || in_exp > 2 * B) { fl |= FL_NX | FL_OF; return (rm == (sg ? 3u : 2u) || rm == 1) ? (sg | (inf - 1)) : (sg | inf); }
+    int out_exp = 2 * B - 1 - in_exp;
+    u64 out_sig = (u64)rcp[M >> (MB - 7)] << (MB - 7);
+    if (out_exp < 1) { out_sig = ((1ull << MB) | out_sig) >> (1 - out_exp); out_exp = 0; }
+    return sg | ((u64)out_exp << MB) | out_sig;
+  }
   // vfsqrt.v (vector-float.cpp:3998-4066) and the same-width conversions (:4990-5310).  op: 0 sqrt 1 xu.f 2 x.f 3 f.xu 4 f.x 5 rtz.xu.f 6 rtz.x.f
   WSP_HD void v_fp_unary(const Rec& r, u64 cur_pc, u32 op)
   {
@@ -2158,14 +2185,15 @@ template <class MEM> struct Lane {
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
     const bool w = c.esz == 2;
-    if (op >= 5) rm = RM_RTZ;
+    if (op == 5 || op == 6) rm = RM_RTZ;
     unsigned fl = 0;
     if (0 < c.vl)
       for (u32 ix = 0; ix < c.elem_max; ++ix) {
         u64 d;
         if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
           const u64 a = vrd(vs2, ix, c.esz);
-          if (op == 0) d = w ? f_sqrt<F32>(a, rm, fl) : f_sqrt<F64>(a, rm, fl);
+          if (op >= 7) d = v_est7(op == 8, a, c.esz, (u32)rm, fl);                 // 7 vfrsqrt7.v, 8 vfrec7.v
+          else if (op == 0) d = w ? f_sqrt<F32>(a, rm, fl) : f_sqrt<F64>(a, rm, fl);
           else if (op == 3 || op == 4) d = w ? int_to_f<F32>(a, op == 4, false, rm, fl) : int_to_f<F64>(a, op == 4, true, rm, fl);
           else { const bool sg = op == 2 || op == 6; d = (w ? f_to_int<F32>(a, rm, sg, false, fl) : f_to_int<F64>(a, rm, sg, true, fl)) & ones_of(c.esz); }
         }
@@ -2517,6 +2545,7 @@ template <class MEM> struct Lane {
         if (vf) break;
         if (rs1 == 0) { v_fp_unary(r, cur_pc, 0); return; }                     // vfsqrt.v
         if (rs1 == 0x10) { v_fp_class(r, cur_pc); return; }                     // vfclass.v
+        if (rs1 == 4 || rs1 == 5) { v_fp_unary(r, cur_pc, rs1 + 3); return; }   // vfrsqrt7.v / vfrec7.v
         break;
       case 0x30: v_fp_widen(r, cur_pc, 0, vf, false); return;                   // vfwadd
       case 0x32: v_fp_widen(r, cur_pc, 1, vf, false); return;                   // vfwsub

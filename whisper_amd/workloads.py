@@ -1261,7 +1261,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
             elif r < 0.44:                                                   # vfsqrt.v, same-width vfcvt.*, vfmerge.vfm
                 q = rng.random()
                 if q < 0.3:
-                    a.vop(0x13, 1, vreg(), vreg(), 0, vm)
+                    a.vop(0x13, 1, vreg(), vreg(), rng.choice([0, 0, 4, 5]), vm)
                 elif q < 0.8:
                     a.vop(0x12, 1, vreg(), vreg(), rng.choice([0, 1, 2, 3, 6, 7]), vm)
                 else:
@@ -1310,7 +1310,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x13, 1, 4, 8, 5)          # vfrec7.v
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x12, 1, 4, 8, 0x15)       # vfncvt.rod.f.f.w
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
