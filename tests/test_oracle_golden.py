@@ -838,3 +838,28 @@ def test_rvv_estimates_known_answers():
             assert fl == 0x08 | 0x10
             x = X[7:].astype(np.float64)
             rr = r[7:].astype(np.float64); assert (np.abs(rr * x * rr - 1) < 2.0**-5.9).all()
+
+
+def test_rvv_round_to_odd_narrowing():
+    """vfncvt.rod.f.f.w: f64 -> f32 truncated toward zero with the last bit set when inexact (overflow gives the largest finite
+    value), checked against a numpy construction on normal, subnormal-result, overflowing and exact operands."""
+    import numpy as np
+    from whisper_amd.rvasm import Asm
+    rng = np.random.default_rng(61)
+    D = np.concatenate([np.exp(rng.uniform(-110, 95, 10)) * rng.choice([-1, 1], 10), [1.5, -2.0**-140, 1e39, -1e300, 2.0**-149 * 1.25, 0.1]]).astype(np.float64)
+    a = Asm(0x80000000)
+    a.csrs(0x300, 5); a.vsetvli(6, 0, Asm.vtype(32, 1)); a.vop(0x12, 1, 4, 8, 0x15)
+    h = rvoracle.Hart(isa="rv64imafdcv_zicsr", mem_base=0x80000000, mem_size=1 << 16)
+    h.write_mem(0x80000000, a.assemble()); h.pc = 0x80000000; h.set_x(5, 0x6600)
+    h.set_vreg(8, D[:8].tobytes()); h.set_vreg(9, D[8:].tobytes())
+    h.run(3)
+    got = np.frombuffer(h.vreg(4), dtype=np.uint32)
+    want = []
+    with np.errstate(all="ignore"):
+        for x in D:
+            y = np.float32(x)
+            if np.float64(y) == x:
+                want.append(int(y.view(np.uint32))); continue
+            t = np.nextafter(y, np.float32(0)) if abs(np.float64(y)) > abs(x) else y
+            want.append(int(t.view(np.uint32)) | 1)
+    assert [int(g) for g in got] == want

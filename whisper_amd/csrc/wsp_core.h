@@ -2272,12 +2272,13 @@ template <class MEM> struct Lane {
     or_fflags(fl);
     vec_success();
   }
-  WSP_HD void v_fp_cvt_ff(const Rec& r, u64 cur_pc, bool narrow)                // vfwcvt.f.f.v / vfncvt.f.f.w
+  WSP_HD void v_fp_cvt_ff(const Rec& r, u64 cur_pc, bool narrow, bool rod = false)   // vfwcvt.f.f.v / vfncvt.f.f.w / vfncvt.rod.f.f.w (:6608-6660)
   {
     using namespace wsf;
     const VCfg c = vcfg(); int rm = 0;
     if (!v_check_int(c, r, cur_pc, false)) return;
-    if (!v_check_fp_wide(c, r, cur_pc, rm)) return;
+    if (rod) { if (!v_check_fp(c, r, cur_pc, rm)) return; if (c.esz != 2) { vec_fail(r, cur_pc); return; } rm = RM_ODD; }   // checkVecFpInst without the wide flag: F suffices
+    else if (!v_check_fp_wide(c, r, cur_pc, rm)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     const u32 wg = c.gx8 * 2;
     if (wg > 64) { vec_fail(r, cur_pc); return; }
@@ -2539,6 +2540,7 @@ template <class MEM> struct Lane {
         if (rs1 == 6 || rs1 == 7) { v_fp_unary(r, cur_pc, rs1 - 1); return; }
         if (rs1 == 0x0c) { v_fp_cvt_ff(r, cur_pc, false); return; }             // vfwcvt.f.f.v
         if (rs1 == 0x14) { v_fp_cvt_ff(r, cur_pc, true); return; }              // vfncvt.f.f.w
+        if (rs1 == 0x15) { v_fp_cvt_ff(r, cur_pc, true, true); return; }        // vfncvt.rod.f.f.w
         if ((rs1 >= 0x08 && rs1 <= 0x0b) || rs1 == 0x0e || rs1 == 0x0f || (rs1 >= 0x10 && rs1 <= 0x13) || rs1 == 0x16 || rs1 == 0x17) { v_fp_cvt_wn(r, cur_pc, rs1); return; }
         break;
       case 0x13:                                                                // VFUNARY1 (Decoder.cpp:427-433)

@@ -31,7 +31,7 @@ typedef int64_t  i64;
 typedef int32_t  i32;
 
 enum { FL_NX = 1, FL_UF = 2, FL_OF = 4, FL_DZ = 8, FL_NV = 16 };
-enum { RM_RNE = 0, RM_RTZ = 1, RM_RDN = 2, RM_RUP = 3, RM_RMM = 4 };
+enum { RM_RNE = 0, RM_RTZ = 1, RM_RDN = 2, RM_RUP = 3, RM_RMM = 4, RM_ODD = 6 };   // RM_ODD: SoftFloat's round_odd (jam), used by vfncvt.rod only
 
 struct U128 { u64 hi, lo; };
 
@@ -158,7 +158,7 @@ template <class F> WSP_HD u64 round_pack(bool sign, int exp, U128 sig, int rm, u
   const int RB = 62 - F::MB;                // number of bits to round away
   const u64 rmask = (1ULL << RB) - 1, half = 1ULL << (RB - 1);
   u64 inc = (rm == RM_RNE || rm == RM_RMM) ? half
-          : (rm == RM_RTZ) ? 0
+          : (rm == RM_RTZ || rm == RM_ODD) ? 0
           : ((rm == RM_RDN) == sign) ? rmask : 0;   // RDN rounds negative magnitudes up, RUP positive
   i64 e = (i64)exp + F::BIAS;               // biased exponent of the unrounded value
   if (e <= 0) {
@@ -178,6 +178,7 @@ template <class F> WSP_HD u64 round_pack(bool sign, int exp, U128 sig, int rm, u
   if (rb) fl |= FL_NX;
   u64 r = (s + inc) >> RB;
   if (rm == RM_RNE && rb == half) r &= ~1ULL;
+  if (rm == RM_ODD && rb) r |= 1;           // round to odd: an inexact result gets its last bit set
   // r holds the hidden bit at position MB for normals; adding it to the exponent field below
   // accounts for it (and for a carry out of the significand).
   u64 ef = e > 0 ? (u64)(e - 1) : 0;

@@ -1279,7 +1279,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
                 elif q < 0.78:
                     a.vop(0x12, 1, vdw, vreg(), 0x0C, vm)
                 elif q < 0.86:
-                    a.vop(0x12, 1, vreg(), vdw, 0x14, vm)
+                    a.vop(0x12, 1, vreg(), vdw, rng.choice([0x14, 0x14, 0x15]), vm)
                 elif q < 0.94:
                     a.vop(rng.choice([0x31, 0x33]), 1, vreg(False), vreg(), vreg(False), vm)
                 else:
@@ -1310,7 +1310,7 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
         else:
             getattr(a, rng.choice(_RR))(rng.choice(regs), rng.choice(regs), rng.choice(regs))
     if seed % 7 == 6:                                                        # an encoding outside the modelled slice: UNSUPPORTED stop on both sides
-        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x12, 1, 4, 8, 0x15)       # vfncvt.rod.f.f.w
+        a.vsetivli(6, 4, Asm.vtype(32, 1)); a.vop(0x12, 2, 4, 8, 8)          # vbrev8.v (Zvbb)
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
