@@ -211,12 +211,12 @@ def test_hostsim_sv39_programs():
 
 
 def test_hostsim_rvv_programs():
-    """Rows a14-a16 (first slice): vsetvl*, unit-stride loads / stores, integer and F/D vector arithmetic, reductions, moves,
-    masks, LMUL mf8..8, ta / ma, illegal configurations, faults inside vector loads (vstart) -- device core (host build) ==
-    oracle for VLEN 512 and 256."""
+    """Rows a14-a16: the random vector programs (configuration, every memory-op form, integer / fixed-point / mask / permutation /
+    FP instructions, LMUL mf8..8, ta / ma, illegal configurations, faults inside vector loads) -- device core (host build) ==
+    oracle for VLEN 512, 256 and 128."""
     vw = traps = uns = 0
     for s in range(40):
-        for vlenb in (64, 32):
+        for vlenb in (64, 32, 16):
             p = WL.rvv_program(s, vlenb=vlenb)
             if s < 12:
                 b, _, log = S.run_oracle(p, log_cap=40000)

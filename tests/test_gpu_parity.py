@@ -173,10 +173,10 @@ def test_sv39_default_tlb_and_snapshot():
         b.close()
 
 
-@pytest.mark.parametrize("vlenb", [64, 32])
+@pytest.mark.parametrize("vlenb", [64, 32, 16])
 def test_rvv_programs(vlenb):
-    """Rows a14-a16 (first slice): strip-mined saxpy / daxpy and random vector code (vsetvl*, unit-stride loads / stores,
-    integer and F/D arithmetic, reductions, moves, masks, LMUL mf8..8, ta / ma, illegal configurations, vector load faults);
+    """Rows a14-a16: strip-mined saxpy / daxpy and random vector code (vsetvl*, every memory-op form, integer / fixed-point /
+    mask / permutation / FP instructions, LMUL mf8..8, ta / ma, illegal configurations, vector load faults);
     the state digest covers all 32 vector registers and the vector CSRs, the trace digest every vector register group written."""
     progs = [WL.rvv_program(s, vlenb=vlenb) for s in range(96)]
     for lanes in (0, 16):
