@@ -111,6 +111,17 @@ int  wsp_batch_results(wsp_batch* b, wsp_result* out);
 /* Seconds spent in the memory-digest kernel during the last wsp_batch_results and its HBM bytes. */
 int  wsp_batch_last_hash_stats(wsp_batch* b, double* kernel_seconds, uint64_t* bytes);
 
+/* Commit ring (the binary side of the reference's --logfile, printTrace.cpp:380-495; Hart::printInstTrace).  With
+ * words_per_hart > 0 every run started with WSP_RUN_TRACE_HASH also appends each hart's commit records to a ring of that
+ * many 64-bit words (recording stops when it is full; the digest goes on; every step takes the general path while a ring
+ * is on).  Record: pc, meta = inst | priv << 32 | trap << 40 | size << 48 | npairs << 56, then npairs x (key, value) with
+ * key = id ^ kind << 60, kind 1 x-reg, 2 f-reg, 3 v-reg (value = digest of the register), 4 memory (id = address), 5 CSR,
+ * in the order the reference's log prints them.  0 switches it off.  Calling it again clears the ring.  Not part of
+ * snapshot / restore. */
+int wsp_batch_trace_ring(wsp_batch* b, uint32_t words_per_hart);
+/* Copies the words recorded for one hart (at most cap); returns their count, or a negative error. */
+int64_t wsp_batch_trace_read(wsp_batch* b, uint32_t hart, uint64_t* words, size_t cap);
+
 /* System::produceTestSignatureFile (System.cpp:1586-1633): 32-bit words from begin_signature to
  * end_signature of `hart`; writes up to cap words, returns the word count or a negative error. */
 int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap);

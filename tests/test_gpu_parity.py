@@ -289,3 +289,42 @@ def test_device_decoder_matches_host_build():
     h = W.decode_words("rv64imafdc_zicsr", words, host=True)
     for i in range(len(words)):
         assert (d[i].w0, d[i].imm, d[i].raw) == (h[i].w0, h[i].imm, h[i].raw), hex(words[i])
+
+
+@pytest.mark.parametrize("kind", ["fuzz", "sv39", "rvv"])
+def test_commit_ring_matches_oracle_log(kind):
+    """Row a17 / 8(f): the device's commit ring (pc, instruction, trap, then the register / memory / CSR changes in the order the
+    reference's log prints them) equals the oracle's commit log record for record - the oracle's log is what the reference's
+    captured traces pin (tests/golden/appendix_d.json).  A ring that is too small holds a prefix; the digests do not depend on
+    the ring; switching it off restores the fast path."""
+    progs = {"fuzz": [WL.fuzz_program(s, 300) for s in range(6)], "sv39": [WL.sv39_program(s) for s in range(6)],
+             "rvv": [WL.rvv_program(s) for s in range(6)]}[kind]
+    p0 = progs[0]
+    b = W.Batch(len(progs), isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, tlb_entries=p0.meta.get("tlb_entries", 0),
+                vlen_bytes=p0.meta.get("vlenb", 0))
+    try:
+        for i, p in enumerate(progs):
+            b.load_elf_bytes(p.elf, i, i + 1)
+            b.set_stop(max_inst=p.max_inst, lo=i, hi=i + 1)
+        b.snapshot()
+        assert b.run(trace_hash=True) == 0
+        plain = [r.as_dict() for r in b.results()]
+        for cap in (1 << 16, 100):
+            b.restore()
+            b.trace_ring(cap)
+            assert b.run(trace_hash=True) == 0
+            assert [r.as_dict() for r in b.results()] == plain
+            for i, p in enumerate(progs):
+                _, _, log = S.run_oracle(p, hart_id=i, log_cap=100000)
+                want = [(c.pc, c.inst, c.size, c.trap, [(k, key, val) for k, key, val in c.changes()] or [(1, 0, 0)]) for c in log]
+                got = [(pc, inst, size, trap, pairs) for pc, inst, size, priv, trap, pairs in b.trace(i)]
+                if cap >= 1 << 16:
+                    assert got == want, (kind, i, next((g, w) for g, w in zip(got, want) if g != w) if len(got) == len(want) else (len(got), len(want)))
+                else:
+                    assert 0 < len(got) < len(want) and got == want[:len(got)]
+        b.restore()
+        b.trace_ring(0)
+        assert b.run(trace_hash=True) == 0
+        assert [r.as_dict() for r in b.results()] == plain
+    finally:
+        b.close()

@@ -88,6 +88,9 @@ def lib():
         L.wsp_batch_last_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
         L.wsp_batch_signature.restype = C.c_int64
         L.wsp_batch_signature.argtypes = [vp, u32, C.POINTER(u32), C.c_size_t]
+        L.wsp_batch_trace_ring.argtypes = [vp, u32]
+        L.wsp_batch_trace_read.restype = C.c_int64
+        L.wsp_batch_trace_read.argtypes = [vp, u32, C.POINTER(u64), C.c_size_t]
         L.wsp_batch_snapshot.argtypes = [vp]
         L.wsp_batch_restore.argtypes = [vp]
         L.wsp_decode_words.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
@@ -192,6 +195,27 @@ class Batch:
         s = C.c_double(); n = C.c_uint64()
         _check(self.L.wsp_batch_last_hash_stats(self.h, C.byref(s), C.byref(n)))
         return s.value, n.value
+
+    def trace_ring(self, words_per_hart):
+        """Switch the commit ring on (words per hart) or off (0); see include/whisper_amd.h."""
+        _check(self.L.wsp_batch_trace_ring(self.h, words_per_hart))
+        self._ring_cap = words_per_hart
+
+    def trace(self, hart):
+        """Commit records of one hart: [(pc, inst, size, priv, trap, [(kind, id, value), ...]), ...]; a record cut off by the
+        end of the ring is dropped."""
+        buf = (C.c_uint64 * self._ring_cap)()
+        n = _check(self.L.wsp_batch_trace_read(self.h, hart, buf, self._ring_cap))
+        out, i = [], 0
+        while i + 2 <= n:
+            pc, meta = buf[i], buf[i + 1]
+            npairs = meta >> 56
+            if i + 2 + 2 * npairs > n:
+                break
+            pairs = [((buf[i + 2 + 2 * k] >> 60) & 7, buf[i + 2 + 2 * k] & ((1 << 60) - 1), buf[i + 3 + 2 * k]) for k in range(npairs)]
+            out.append((pc, meta & 0xFFFFFFFF, (meta >> 48) & 0xFF, (meta >> 32) & 0xFF, (meta >> 40) & 0xFF, pairs))
+            i += 2 + 2 * npairs
+        return out
 
     def snapshot(self):
         _check(self.L.wsp_batch_snapshot(self.h))

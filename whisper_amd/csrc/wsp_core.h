@@ -310,7 +310,8 @@ enum ColdIx {
 // retired by exactly one).  Recomputed by update_hot_flag() after anything that can change it.
 enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16,
              HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */,
-             HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */ };
+             HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */,
+             HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -374,6 +375,7 @@ template <class MEM> struct Lane {
   u32 isa, hart_id;
   u32 tlb_n;                                           // TLB entries (power of two; 0 when the ISA has no S)
   u32 vlenb;                                           // bytes per vector register (0 when the ISA has no V)
+  u64* ring_ = nullptr; u32* ring_pos_ = nullptr; u32 ring_cap = 0;   // commit ring of this hart (null: not recording), see commit()
 
   WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
   WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
@@ -2607,7 +2609,7 @@ template <class MEM> struct Lane {
   {
     // an interrupt that is pending and enabled (whatever its delegation / global enable) keeps the hart on the cold path,
     // which polls isInterruptPossible every step
-    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR | HF_PMP_MLOCK)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
+    bool hot = !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR | HF_PMP_MLOCK | HF_RING)) && h.priv == PRV_M && !(h.mstatus & MST_MPRV) &&
                (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
     h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
     h.flags = (((h.mstatus >> MST_FS_SH) & 3) == 3) ? (h.flags | HF_FS_DIRTY) : (h.flags & ~(u32)HF_FS_DIRTY);
@@ -2909,39 +2911,48 @@ template <class MEM> struct Lane {
   }
 
   // ---- fold one commit record into the running trace hash
+  // Commit record of one step.  The digest folds a word stream: pc, meta, then one (key, value) pair per change in the order the
+  // reference's log prints them (printTrace.cpp:380-495).  With a commit ring configured (wsp_batch_trace_ring) the same words are
+  // also appended to this hart's ring, the pair count patched into bits 56.. of the stored meta word; recording stops when the
+  // ring is full, the digest goes on.
   template <bool TRACE> WSP_HD void commit(u64 cur_pc, u32 raw, u32 size, u32 priv0, u32 trap)
   {
     if (!TRACE) return;
     u64 t = h.thash;
-    t = fold(t, cur_pc);
-    t = fold(t, (u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48));
-    u32 c = s.chg; bool any = false;
-    if ((c & CH_IREG) && s.ireg) { t = fold(t, (u64)s.ireg ^ (1ULL << 60)); t = fold(t, s.ival); any = true; }
-    if (c & CH_FREG) { t = fold(t, (u64)s.freg ^ (2ULL << 60)); t = fold(t, s.fval); any = true; }
+    u64* const rg = ring_; u32 pos = rg ? *ring_pos_ : 0; const u32 cap = ring_cap, meta_at = pos + 1; u32 np = 0;
+#define WSP_PUT(w) do { const u64 w_ = (w); t = fold(t, w_); if (rg && pos < cap) rg[pos++] = w_; } while (0)
+#define WSP_PAIR(k, v) do { WSP_PUT(k); WSP_PUT(v); ++np; } while (0)
+    WSP_PUT(cur_pc);
+    WSP_PUT((u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48));
+    const u32 c = s.chg;
+    if ((c & CH_IREG) && s.ireg) WSP_PAIR((u64)s.ireg ^ (1ULL << 60), s.ival);
+    if (c & CH_FREG) WSP_PAIR((u64)s.freg ^ (2ULL << 60), s.fval);
     if (s.vgroup) {          // one v line per register of the group (printTrace.cpp:424-441): the record carries a digest of its bytes
       for (u32 g = 0; g < s.vgroup; ++g) {
         const u32 reg = (s.vreg + g) & 31; u64 d = 0;
         for (u32 w = 0; w < vlenb / 8; ++w) d = fold(d, m.vld(reg * vlenb + 8 * w, 3));
-        t = fold(t, (u64)reg ^ (3ULL << 60)); t = fold(t, d);
+        WSP_PAIR((u64)reg ^ (3ULL << 60), d);
       }
-      any = true;
     }
-    if (c & CH_MEM) { t = fold(t, s.maddr ^ (4ULL << 60)); t = fold(t, s.mval); any = true; }
+    if (c & CH_MEM) WSP_PAIR(s.maddr ^ (4ULL << 60), s.mval);
     const u64 K = 5ULL << 60;
-    bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
-    if (gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
-    if (c & CH_SSTATUS) { t = fold(t, (u64)C_SSTATUS ^ K); t = fold(t, csr_peek(C_SSTATUS)); any = true; }
-    if (c & CH_SEPC) { t = fold(t, (u64)C_SEPC ^ K); t = fold(t, m.cold(CI_SEPC) & epc_rmask()); any = true; }
-    if (c & CH_SCAUSE) { t = fold(t, (u64)C_SCAUSE ^ K); t = fold(t, m.cold(CI_SCAUSE)); any = true; }
-    if (c & CH_STVAL) { t = fold(t, (u64)C_STVAL ^ K); t = fold(t, m.cold(CI_STVAL)); any = true; }
-    if (c & CH_MSTATUS) { t = fold(t, (u64)C_MSTATUS ^ K); t = fold(t, csr_peek(C_MSTATUS)); any = true; }
-    if ((c & CH_GEN) && !gen_lo) { t = fold(t, (u64)s.gen_csr ^ K); t = fold(t, csr_peek(s.gen_csr)); any = true; }
-    if (c & CH_MEPC) { t = fold(t, (u64)C_MEPC ^ K); t = fold(t, m.cold(CI_MEPC) & epc_rmask()); any = true; }
-    if (c & CH_MCAUSE) { t = fold(t, (u64)C_MCAUSE ^ K); t = fold(t, m.cold(CI_MCAUSE)); any = true; }
-    if (c & CH_MTVAL) { t = fold(t, (u64)C_MTVAL ^ K); t = fold(t, m.cold(CI_MTVAL)); any = true; }
-    if (c & CH_VL) { t = fold(t, (u64)C_VL ^ K); t = fold(t, m.cold(CI_VL)); any = true; }
-    if (c & CH_VTYPE) { t = fold(t, (u64)C_VTYPE ^ K); t = fold(t, m.cold(CI_VTYPE)); any = true; }
-    if (!any) { t = fold(t, 1ULL << 60); t = fold(t, 0); }                                   // printTrace.cpp:491-493
+    const bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
+    if (gen_lo) WSP_PAIR((u64)s.gen_csr ^ K, csr_peek(s.gen_csr));
+    if (c & CH_SSTATUS) WSP_PAIR((u64)C_SSTATUS ^ K, csr_peek(C_SSTATUS));
+    if (c & CH_SEPC) WSP_PAIR((u64)C_SEPC ^ K, m.cold(CI_SEPC) & epc_rmask());
+    if (c & CH_SCAUSE) WSP_PAIR((u64)C_SCAUSE ^ K, m.cold(CI_SCAUSE));
+    if (c & CH_STVAL) WSP_PAIR((u64)C_STVAL ^ K, m.cold(CI_STVAL));
+    if (c & CH_MSTATUS) WSP_PAIR((u64)C_MSTATUS ^ K, csr_peek(C_MSTATUS));
+    if ((c & CH_GEN) && !gen_lo) WSP_PAIR((u64)s.gen_csr ^ K, csr_peek(s.gen_csr));
+    if (c & CH_MEPC) WSP_PAIR((u64)C_MEPC ^ K, m.cold(CI_MEPC) & epc_rmask());
+    if (c & CH_MCAUSE) WSP_PAIR((u64)C_MCAUSE ^ K, m.cold(CI_MCAUSE));
+    if (c & CH_MTVAL) WSP_PAIR((u64)C_MTVAL ^ K, m.cold(CI_MTVAL));
+    if (c & CH_VL) WSP_PAIR((u64)C_VL ^ K, m.cold(CI_VL));
+    if (c & CH_VTYPE) WSP_PAIR((u64)C_VTYPE ^ K, m.cold(CI_VTYPE));
+    if (np == 0) WSP_PAIR(1ULL << 60, 0);                                                         // printTrace.cpp:491-493: an "r x0 0" line
+#undef WSP_PAIR
+#undef WSP_PUT
+    if (rg) { if (meta_at < pos) rg[meta_at] |= (u64)np << 56; *ring_pos_ = pos; }
     h.thash = t;
   }
 };

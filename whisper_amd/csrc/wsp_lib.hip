@@ -33,7 +33,8 @@ struct DevState {
   u64* x; u64* f; u64* hot64; u32* hot32; u64* cold;
   u64* tlb;            // [n_harts][tlb_n][2] packed TLB entries (wsp_core.h); null when the ISA has no S
   u8* vreg;            // [n_harts][32][vlenb] vector registers, element 0 first; null when the ISA has no V
-  u32 vlenb, pad2;
+  u32 vlenb, ring_cap;
+  u64* ring; u32* ring_pos;   // commit ring: [n_harts][ring_cap] words and the words written per hart; null when off
   u64* tohost; u64* max_exec; u32* prog;
   u8* arena;
   const ProgDev* progs;
@@ -97,6 +98,7 @@ __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& 
   L.m.cold_ = d.cold + slot;
   L.m.tlb_ = d.tlb + (size_t)(wave * d.lpw + ln) * 2 * d.tlb_n; L.tlb_n = d.tlb_n;
   L.m.vreg_ = d.vreg + (size_t)(wave * d.lpw + ln) * 32 * d.vlenb; L.vlenb = d.vlenb;
+  if (d.ring) { L.ring_ = d.ring + (size_t)(wave * d.lpw + ln) * d.ring_cap; L.ring_pos_ = d.ring_pos + wave * d.lpw + ln; L.ring_cap = d.ring_cap; }
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
   L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + wave * d.lpw + ln;
@@ -217,6 +219,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.fcsr = d.hot32[H32_FCSR * S + slot];
   L.update_pmp_flags();                                  // host pokes may have changed priv / mstatus / mip / mie / pmpcfg / flags
+  L.h.flags = d.ring ? (L.h.flags | HF_RING) : (L.h.flags & ~(u32)HF_RING);
   L.update_hot_flag();
   u64 stop_at;
   {
@@ -849,7 +852,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
   if (!b) return;
   hipSetDevice(b->device);
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
-  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state };
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state, b->d.ring, b->d.ring_pos };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -1330,6 +1333,40 @@ extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
 
 extern "C" int wsp_batch_last_hash_stats(wsp_batch* b, double* s, uint64_t* bytes)
 { if (!b) return fail(WSP_EINVAL, "null batch"); if (s) *s = b->last_hash_s; if (bytes) *bytes = b->last_hash_bytes; return WSP_OK; }
+
+extern "C" int wsp_batch_trace_ring(wsp_batch* b, uint32_t words_per_hart)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  HIPOK(hipSetDevice(b->device));
+  HIPOK(hipStreamSynchronize(b->stream));
+  DevState& d = b->d;
+  if (d.ring) { HIPOK(hipFree(d.ring)); d.ring = nullptr; }
+  if (d.ring_pos) { HIPOK(hipFree(d.ring_pos)); d.ring_pos = nullptr; }
+  d.ring_cap = 0;
+  if (words_per_hart == 0) return WSP_OK;
+  if (words_per_hart < 4) return fail(WSP_EINVAL, "trace ring: at least 4 words per hart (one record is pc, meta and one pair)");
+  const size_t bytes = (size_t)d.n_harts * words_per_hart * 8;
+  if (hipMalloc((void**)&d.ring, bytes) != hipSuccess) { d.ring = nullptr; return fail(WSP_ENOMEM, "trace ring: hipMalloc failed"); }
+  if (hipMalloc((void**)&d.ring_pos, (size_t)d.n_harts * 4) != hipSuccess) { hipFree(d.ring); d.ring = nullptr; d.ring_pos = nullptr; return fail(WSP_ENOMEM, "trace ring: hipMalloc failed"); }
+  HIPOK(hipMemset(d.ring_pos, 0, (size_t)d.n_harts * 4));
+  d.ring_cap = words_per_hart;
+  return WSP_OK;
+}
+
+extern "C" int64_t wsp_batch_trace_read(wsp_batch* b, uint32_t hart, uint64_t* words, size_t cap)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  const DevState& d = b->d;
+  if (!d.ring) return fail(WSP_EINVAL, "trace ring is off");
+  if (hart >= d.n_harts) return fail(WSP_ERANGE, "hart out of range");
+  HIPOK(hipSetDevice(b->device));
+  HIPOK(hipStreamSynchronize(b->stream));
+  u32 n = 0;
+  HIPOK(hipMemcpy(&n, d.ring_pos + hart, 4, hipMemcpyDeviceToHost));
+  if (n > cap) return fail(WSP_ERANGE, "trace buffer too small");
+  if (n) HIPOK(hipMemcpy(words, d.ring + (size_t)hart * d.ring_cap, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return (int64_t)n;
+}
 
 extern "C" int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap)
 {
