@@ -328,3 +328,34 @@ def test_commit_ring_matches_oracle_log(kind):
         assert [r.as_dict() for r in b.results()] == plain
     finally:
         b.close()
+
+
+def test_commit_ring_against_reference_rvv_capture():
+    """The survey's RVV capture of the reference (tests/golden/appendix_d.json `rvv`) replayed on the device with the commit ring
+    on: the vsetvli record (x6, mstatus, vl, vtype with the reference's values, in its order) and the vid.v / vadd.vv register
+    lines come out of the ring, formatted by whisper_amd.tracefmt into the reference's log columns."""
+    import json
+    import os
+    from whisper_amd import tracefmt
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_d.json")))["rvv"]
+    words = [0x3002a073, int(g["records"][0]["op"], 16)] + [int(v["op"], 16) for v in g["vlines"]]
+    b = W.Batch(1, isa=g["isa"], mem_base=0x80000000, mem_size=1 << 16)
+    try:
+        b.load_image(g["first_pc"], b"".join(w.to_bytes(4, "little") for w in words), executable=True)
+        b.poke(0, W.RES_PC, 0, g["first_pc"]); b.poke(0, W.RES_X, 5, g["x5"])
+        b.set_stop(max_inst=len(words))
+        b.trace_ring(4096)
+        b.run(trace_hash=True)
+        recs = b.trace(0)
+        assert len(recs) == len(words)
+        gold = [r for r in g["records"] if r["tag"] == g["records"][0]["tag"]]
+        lines = tracefmt.format_record(gold[0]["tag"], 0, recs[1])
+        want = [f"#{r['tag']} {r['hart']}  {r['priv']} {r['pc']:016x} {r['op']} {r['kind']} {r['key']:016x} {r['val']:016x}" + ("  +" if k + 1 < len(gold) else "")
+                for k, r in enumerate(gold)]
+        assert lines == want
+        for rec, v in zip(recs[2:], g["vlines"]):
+            assert (rec[0], f"{rec[1]:08x}") == (v["pc"], v["op"]) and [(k, key) for k, key, _ in rec[5]] == [(3, v["reg"])]
+            img = b.peek(0, W.RES_V, v["reg"])[::-1].hex()
+            assert img.startswith(v["head"]) and img.endswith(v["tail"])
+    finally:
+        b.close()
