@@ -352,7 +352,7 @@ def test_commit_ring_against_reference_rvv_capture():
         lines = tracefmt.format_record(gold[0]["tag"], 0, recs[1])
         want = [f"#{r['tag']} {r['hart']}  {r['priv']} {r['pc']:016x} {r['op']} {r['kind']} {r['key']:016x} {r['val']:016x}" + ("  +" if k + 1 < len(gold) else "")
                 for k, r in enumerate(gold)]
-        assert lines == want
+        assert [ln.split() for ln in lines] == [w.split() for w in want]
         for rec, v in zip(recs[2:], g["vlines"]):
             assert (rec[0], f"{rec[1]:08x}") == (v["pc"], v["op"]) and [(k, key) for k, key, _ in rec[5]] == [(3, v["reg"])]
             img = b.peek(0, W.RES_V, v["reg"])[::-1].hex()
