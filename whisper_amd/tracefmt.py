@@ -15,10 +15,16 @@ def format_record(tag, hart, rec, disasm=None):
     pc, inst, size, priv, trap, pairs = rec
     op = f"{inst:08x}" if size == 4 else f"{inst & 0xffff:04x}"
     text = disasm(inst) if disasm else ""
+    # printTrace.cpp:338-346 appends the data address of scalar loads / stores; the ring carries it for stores (the m change)
+    # only, so load lines lack the suffix.  Traps and interrupts are marked as the reference marks them.
+    for kind, key, _ in pairs:
+        if kind == 4:
+            text += f" [0x{key:x}]"
+    text += " (exception)" if trap == 1 else " (interrupted)" if trap == 2 else ""
     lines = []
     for k, (kind, key, val) in enumerate(pairs):
         more = "  +" if k + 1 < len(pairs) else ""
-        lines.append(f"#{tag} {hart}  {PRIV_CHAR.get(priv, '?')} {pc:016x} {op} {KIND_CHAR[kind]} {key:016x} {val:016x} {text}{more}".rstrip())
+        lines.append(f"#{tag} {hart}  {PRIV_CHAR.get(priv, '?')} {pc:016x} {op:>8s} {KIND_CHAR[kind]} {key:016x} {val:016x} {text}".rstrip() + more)
     return lines
 
 
