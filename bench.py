@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_INST = 8.0        # 4 B fetch + ~0.3 x 8 B data + slice state swap, rounded up
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_e_pmc_per_launch.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_f_pmc_per_launch.json")
 
 
 def pmc_traffic(insts_per_launch):
@@ -31,7 +31,7 @@ def pmc_traffic(insts_per_launch):
     profiled per-instruction traffic scaled to this launch; None when no profile is committed."""
     try:
         rec = json.load(open(PMC_FILE))["void wsp_step_kernel<false, true>"]
-        ref = json.load(open(os.path.join(ROOT, "profiles", "r01_e_bench.json")))["config"]["instructions_per_step_per_gpu"]
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench.json")))["config"]["instructions_per_step_per_gpu"]
         return (rec["FETCH_SIZE_per_launch"] + rec["WRITE_SIZE_per_launch"]) * 1024.0 * insts_per_launch / ref
     except Exception:
         return None
@@ -186,7 +186,7 @@ def main():
                        "all_harts_pass": ok, "oracle_spot_check": parity},
             "roofline": {"bound": "hbm", "kernel": "wsp_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(per_step_insts),
-                         "traffic_note": "bytes per launch from profiles/r01_e_pmc_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                         "traffic_note": "bytes per launch from profiles/r01_f_pmc_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "algorithmic_bytes_per_launch": per_step_insts * ALGO_BYTES_PER_INST,
                          "kernel_ms": kavg * 1e3, "kernel_gips": per_step_insts / kavg / 1e9 if kavg > 0 else 0.0,
                          "note": "interpreter is VALU-issue/latency bound, not HBM bound (DESIGN.md); algorithmic bytes = 8 B/instruction",
