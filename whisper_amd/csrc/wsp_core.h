@@ -1138,12 +1138,12 @@ template <class MEM> struct Lane {
     wx(rd, ld);
   }
 
-  // ---- RVV (vector.cpp, vector-ls.cpp, vector-float.cpp, vector-mask.cpp, VecRegs.hpp), first slice: vsetvl*, unit-stride
-  // loads / stores, the generic integer vv/vx/vi group, multiply-add, merge / move, scalar moves, vid, integer reductions,
-  // F/D add/sub/mul/div, vfmacc, sum reductions and FP moves, at the reference's defaults (VLEN = 8 * vlenb, ELEN 64, every
-  // LMUL legal, agnostic = all ones, vill instead of a trap, non-zero vstart traps on arithmetic).  One lane runs its hart's
-  // element loop serially (lanes-per-element mapping is the next step).  Anything else in the vector encodings
-  // stops the hart UNSUPPORTED (UNS_VECTOR | instruction << 20).
+  // ---- RVV (vector.cpp, vector-ls.cpp, vector-fixed.cpp, vector-float.cpp, vector-mask.cpp, VecRegs.hpp): configuration, every load /
+  // store form, the integer / fixed-point / mask / permutation chapters of V 1.0, and F/D arithmetic, fused forms, compares, sqrt,
+  // estimates, conversions, widening arithmetic, reductions and slides (DESIGN.md rows a14-a16 list them), at the reference's
+  // defaults (VLEN = 8 * vlenb, ELEN 64, every LMUL legal, agnostic = all ones, vill instead of a trap, non-zero vstart traps
+  // on arithmetic).  One lane runs its hart's element loop serially (lanes-per-element mapping is the next step).
+  // Anything else in the vector encodings stops the hart UNSUPPORTED (UNS_VECTOR | instruction << 20).
   WSP_HD u64 vtype() { return m.cold(CI_VTYPE); }
   WSP_HD static u32 gm_x8(u32 gm) { return gm < 4 ? 8u << gm : gm > 4 ? 8u >> (8 - gm) : 0; }                 // VecRegs.hpp:354-361
   WSP_HD static u64 ones_of(u32 esz) { return esz == 3 ? ~0ULL : (1ULL << (8u << esz)) - 1; }
