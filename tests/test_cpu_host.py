@@ -426,13 +426,14 @@ def test_sharding_gather_world_size_2_gloo(tmp_path):
     script.write_text(_WORKER.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     import socket
-    for attempt in range(2):                         # the rendezvous port is picked, released, then bound by the launcher: retry once if it was taken meanwhile
+    for attempt in range(3):                         # the rendezvous port is picked, released, then bound by the launcher: retry once if it was taken meanwhile
         with socket.socket() as sk:                  # a free rendezvous port (a fixed one can linger in TIME_WAIT)
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                               "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300, env=env)
-        if out.returncode == 0 or "RANK" in out.stdout:
+        if out.returncode == 0 and "RANK 0 OK" in out.stdout and "RANK 1 OK" in out.stdout:
             break
+        print(f"attempt {attempt}: rc={out.returncode}\n{out.stdout[-1500:]}\n{out.stderr[-3000:]}", file=sys.stderr)   # seen to fail once in a while right after a rebuild
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
     assert "RANK 0 OK" in out.stdout and "RANK 1 OK" in out.stdout, out.stdout + out.stderr[-2000:]
