@@ -21,18 +21,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-ALGO_BYTES_PER_INST = 8.0        # 4 B fetch + ~0.3 x 8 B data + slice state swap, rounded up
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_f_pmc_per_launch.json")
+ALGO_BYTES_PER_INST = 8.0        # SURVEY.md 8(d) model: 4 B fetch + ~0.3 x 8 B data + slice state swap, rounded up
+N_SIMD, CLK_HZ = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 clocks
+PROFILE_TAG = "r02_a"            # profiles/<tag>_pmc_per_launch.json + <tag>_bench.json: rocprofv3 --pmc passes of this same command
+PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_per_launch.json")
 
 
-def pmc_traffic(insts_per_launch):
-    """HBM bytes per launch of wsp_step_kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE,
-    separate runs of this same command, KB x 1024).  Counters cannot be read from inside the bench, so the figure is the
-    profiled per-instruction traffic scaled to this launch; None when no profile is committed."""
+def pmc_profile(insts_per_launch):
+    """Per-launch figures of wsp_step_kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ
+    instruction counts: separate runs of this same command).  Counters cannot be read from inside the bench, so the
+    profiled per-simulated-instruction figures are scaled to this launch; None when no profile is committed.  The
+    profile names the commit it was taken at."""
     try:
-        rec = json.load(open(PMC_FILE))["void wsp_step_kernel<false, true>"]
-        ref = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench.json")))["config"]["instructions_per_step_per_gpu"]
-        return (rec["FETCH_SIZE_per_launch"] + rec["WRITE_SIZE_per_launch"]) * 1024.0 * insts_per_launch / ref
+        allk = json.load(open(PMC_FILE))
+        rec = allk["void wsp_step_kernel<false, true>"]
+        ref = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench.json")))["config"]["instructions_per_step_per_gpu"]
+        k = insts_per_launch / ref
+        return {"traffic": (rec["FETCH_SIZE_per_launch"] + rec["WRITE_SIZE_per_launch"]) * 1024.0 * k,
+                "valu_per_inst": rec["SQ_INSTS_VALU_per_launch"] / ref, "salu_per_inst": rec["SQ_INSTS_SALU_per_launch"] / ref,
+                "branch_per_inst": rec["SQ_INSTS_BRANCH_per_launch"] / ref, "lds_per_inst": rec["SQ_INSTS_LDS_per_launch"] / ref,
+                "vmem_per_inst": rec["SQ_INSTS_VMEM_per_launch"] / ref, "commit": allk.get("_commit")}
     except Exception:
         return None
 
@@ -60,18 +68,51 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0, k
 
 
+def host_cores():
+    """(workers to start, CPUs the machine shows).  The GPU box shows the whole machine's CPUs to every tenant but
+    gives a one-GPU job a share of them, exported as OMP_NUM_THREADS; without that variable every CPU this process
+    may run on is used."""
+    shown = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = shown
+    share = os.environ.get("OMP_NUM_THREADS")
+    return max(1, min(allowed, int(share)) if share and share.isdigit() else allowed), shown
+
+
 def cpu_baseline(iters, budget_s=12.0):
     """The CPU oracle (a scalar port of the reference's run loop, reference SoftFloat inside) on the
     host cores of this box: one process per core, same compute-kernel instances.  Must run before
     this process touches HIP (it forks)."""
     import multiprocessing as mp
-    cores = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+    cores, shown = host_cores()
     with mp.get_context("fork").Pool(cores) as pool:
         out = pool.map(_cpu_worker, [(i, iters, budget_s) for i in range(cores)])
     rate = sum(n / s for n, s, _ in out)
     return {"value": rate / 1e9, "unit": "GIPS", "cores": cores, "kind": "port",
+            "host_cpus_shown": shown, "per_core_mips": rate / cores / 1e6,
+            "whole_host_linear_extrapolation_gips": rate / cores * shown / 1e9,
+            "reference_note": "the reference's own Hart::run cannot be built here (Boost headers absent, DESIGN.md section 4), so no "
+                              "reference/port ratio is measured; SURVEY.md section 6 measured the reference at 61.8 M inst/s/core "
+                              "(integer loop) and 11.4 M (50 % SoftFloat) in the survey container",
             "sample": f"{sum(k for _, _, k in out)} compute-kernel instances (iters={iters}) in {budget_s:.0f} s, "
-                      f"{sum(n for n, _, _ in out)} instructions, one oracle process per core, untraced-equivalent"}
+                      f"{sum(n for n, _, _ in out)} instructions, one oracle process per worker ({cores} workers = this job's CPU share; "
+                      f"the machine shows {shown} CPUs), untraced-equivalent"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run before this
+    process touches a GPU, pass their output through and leave with their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -87,11 +128,12 @@ def main():
     ap.add_argument("--nofp", action="store_true", help="diagnostic: integer-only variant of the kernel (not the BASELINE config)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))              # n_gpus in the line below is always the number of live ranks
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    args.gpus = world
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
@@ -174,8 +216,27 @@ def main():
             parity = f"not checked: {e}"
         kavg = sum(kernel_s) / max(1, len(kernel_s))
         gips = total_insts / dt / 1e9
-        achieved = per_step_insts * ALGO_BYTES_PER_INST / kavg / 1e9 if kavg > 0 else 0.0
+        krate = per_step_insts / kavg if kavg > 0 else 0.0
+        achieved = krate * ALGO_BYTES_PER_INST / 1e9
         hs, hb = b.hash_stats()
+        pmc = pmc_profile(per_step_insts)
+        roof = {"bound": "hbm", "kernel": "wsp_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"] if pmc else None,
+                "algorithmic_bytes_per_launch": per_step_insts * ALGO_BYTES_PER_INST,
+                "algorithmic_model": "8 B per simulated instruction (SURVEY.md 8d): a model figure, small against HBM by construction",
+                "kernel_ms": kavg * 1e3, "kernel_gips": krate / 1e9,
+                "limiter": "VALU + SALU instruction issue of the interpreter loop (DESIGN.md section 7), not HBM",
+                "memhash_kernel": {"achieved": hb / hs / 1e9 if hs > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": (hb / hs / 1e9 / HBM_PEAK_GBS) if hs > 0 else 0.0, "bytes": hb, "ms": hs * 1e3}}
+        if pmc:
+            # the primary efficiency figure.  Wave-level VALU instructions issued per second against the chip's
+            # VALU issue slots (1024 SIMDs, one wave64 VALU instruction per 4 clocks each); SALU against one per clock per CU.
+            roof.update({"measured_traffic_GBps": pmc["traffic"] / kavg / 1e9 if kavg > 0 else None,
+                         "valu_issue_frac": pmc["valu_per_inst"] * krate / (N_SIMD * CLK_HZ / 4),
+                         "salu_issue_frac": (pmc["salu_per_inst"] + pmc["branch_per_inst"]) * krate / (256 * CLK_HZ),
+                         "wave_instructions_per_simulated_instruction": {k: pmc[k + "_per_inst"] for k in ("valu", "salu", "branch", "lds", "vmem")},
+                         "traffic_note": f"per-launch HBM bytes and instruction mix scaled from profiles/{PROFILE_TAG}_pmc_per_launch.json "
+                                         f"(rocprofv3 --pmc passes of this command at commit {pmc['commit']})"})
         line = {
             "metric": "aggregate simulated instructions/sec (GIPS)", "value": gips, "unit": "GIPS",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -184,14 +245,7 @@ def main():
                                    "run to tohost, state+memory digests", "harts_per_gpu": n, "iters": args.iters,
                        "instructions_per_step_per_gpu": per_step_insts, "trace_hash": bool(args.trace), "lanes_per_wave": args.lanes,
                        "all_harts_pass": ok, "oracle_spot_check": parity},
-            "roofline": {"bound": "hbm", "kernel": "wsp_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(per_step_insts),
-                         "traffic_note": "bytes per launch from profiles/r01_f_pmc_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                         "algorithmic_bytes_per_launch": per_step_insts * ALGO_BYTES_PER_INST,
-                         "kernel_ms": kavg * 1e3, "kernel_gips": per_step_insts / kavg / 1e9 if kavg > 0 else 0.0,
-                         "note": "interpreter is VALU-issue/latency bound, not HBM bound (DESIGN.md); algorithmic bytes = 8 B/instruction",
-                         "memhash_kernel": {"achieved": hb / hs / 1e9 if hs > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": (hb / hs / 1e9 / HBM_PEAK_GBS) if hs > 0 else 0.0, "bytes": hb, "ms": hs * 1e3}},
+            "roofline": roof,
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -114,10 +114,10 @@ int  wsp_batch_last_hash_stats(wsp_batch* b, double* kernel_seconds, uint64_t* b
 /* Commit ring (the binary side of the reference's --logfile, printTrace.cpp:380-495; Hart::printInstTrace).  With
  * words_per_hart > 0 every run started with WSP_RUN_TRACE_HASH also appends each hart's commit records to a ring of that
  * many 64-bit words (recording stops when it is full; the digest goes on; every step takes the general path while a ring
- * is on).  Record: pc, meta = inst | priv << 32 | trap << 40 | size << 48 | npairs << 56, then npairs x (key, value) with
- * key = id ^ kind << 60, kind 1 x-reg, 2 f-reg, 3 v-reg (value = digest of the register), 4 memory (id = address), 5 CSR,
- * in the order the reference's log prints them.  0 switches it off.  Calling it again clears the ring.  Not part of
- * snapshot / restore. */
+ * is on).  Record: pc, meta = inst | priv << 32 | trap << 40 | size << 48 | npairs << 56, kinds, then npairs x (id, value):
+ * pair k has kind = (kinds >> 4k) & 15: 1 x-reg, 2 f-reg, 3 v-reg (value = digest of the register), 4 memory (id = the
+ * whole 64-bit address), 5 CSR, in the order the reference's log prints them.  0 switches it off.  Calling it again clears
+ * the ring.  Not part of snapshot / restore. */
 int wsp_batch_trace_ring(wsp_batch* b, uint32_t words_per_hart);
 /* Copies the words recorded for one hart (at most cap); returns their count, or a negative error. */
 int64_t wsp_batch_trace_read(wsp_batch* b, uint32_t hart, uint64_t* words, size_t cap);
@@ -136,6 +136,11 @@ int  wsp_batch_restore(wsp_batch* b);
 int  wsp_decode_words(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out);
 /* The same decoder compiled for the host (no device needed; used by CPU-only tests). */
 int  wsp_decode_words_host(const char* isa, const uint32_t* words, size_t n, wsp_decoded* out);
+/* Run the device build of the softfloat (the arithmetic behind float.cpp / float-util.hpp:230-930, which the reference gets from
+ * third_party/softfloat) over n operand triples on the GPU: out[i], flags[i] = op(a[i], b[i], c[i]) under rounding mode rm (0..4,
+ * RISC-V order).  op & 0x100 selects double precision; low byte: 0 add 1 sub 2 mul 3 div 4 sqrt 5 fused multiply-add,
+ * 6..9 float -> integer (bit 0 signed, bit 1 64-bit), 10..13 integer c -> float (same bits), 14 convert to the other format. */
+int  wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n, uint64_t* out, uint32_t* flags);
 /* Parse an ISA string into the internal option bit set (tests). */
 uint32_t wsp_isa_flags(const char* isa);
 

@@ -77,6 +77,42 @@ int rvo_bind_softfloat(const char* path)
   return 0;
 }
 
+/* Batch evaluation of the reference SoftFloat for the device softfloat sweep (tests/test_gpu_softfloat.py).  Same op numbering as
+ * wsp_sf_eval (include/whisper_amd.h): op & 0x100 = double; 0 add 1 sub 2 mul 3 div 4 sqrt 5 mulAdd, 6..9 to int (bit 0 signed,
+ * bit 1 64-bit), 10..13 from int c (same bits), 14 convert to the other format.  rm 0..4 in RISC-V order (float-util.hpp:80-91). */
+int rvo_sf_ref(uint32_t op, uint32_t rm, const u64* a, const u64* b, const u64* c, size_t n, u64* out, uint32_t* flags)
+{
+  static const uint8_t rm_sf[5] = { 0 /*near_even*/, 1 /*minMag*/, 2 /*min*/, 3 /*max*/, 4 /*near_maxMag*/ };
+  if (!SF.lib || rm > 4) return -1;
+  const int dbl = (op & 0x100) != 0; const unsigned k = op & 0xff;
+  for (size_t i = 0; i < n; ++i) {
+    *SF.rm = rm_sf[rm]; *SF.flags = 0;
+    u64 r = 0;
+    sf32 x = { (uint32_t)a[i] }, y = { (uint32_t)b[i] }, z = { (uint32_t)c[i] };
+    sf64 X = { a[i] }, Y = { b[i] }, Z = { c[i] };
+    switch (k) {
+      case 0: r = dbl ? SF.f64_add(X, Y).v : SF.f32_add(x, y).v; break;
+      case 1: r = dbl ? SF.f64_sub(X, Y).v : SF.f32_sub(x, y).v; break;
+      case 2: r = dbl ? SF.f64_mul(X, Y).v : SF.f32_mul(x, y).v; break;
+      case 3: r = dbl ? SF.f64_div(X, Y).v : SF.f32_div(x, y).v; break;
+      case 4: r = dbl ? SF.f64_sqrt(X).v : SF.f32_sqrt(x).v; break;
+      case 5: r = dbl ? SF.f64_mulAdd(X, Y, Z).v : SF.f32_mulAdd(x, y, z).v; break;
+      case 6: r = dbl ? (u64)(uint32_t)SF.f64_to_ui32(X, rm_sf[rm], 1) : (u64)(uint32_t)SF.f32_to_ui32(x, rm_sf[rm], 1); break;
+      case 7: r = dbl ? (u64)(i64)(int32_t)SF.f64_to_i32(X, rm_sf[rm], 1) : (u64)(i64)(int32_t)SF.f32_to_i32(x, rm_sf[rm], 1); break;
+      case 8: r = dbl ? (u64)SF.f64_to_ui64(X, rm_sf[rm], 1) : (u64)SF.f32_to_ui64(x, rm_sf[rm], 1); break;
+      case 9: r = dbl ? (u64)SF.f64_to_i64(X, rm_sf[rm], 1) : (u64)SF.f32_to_i64(x, rm_sf[rm], 1); break;
+      case 10: r = dbl ? SF.ui32_to_f64((uint32_t)c[i]).v : SF.ui32_to_f32((uint32_t)c[i]).v; break;
+      case 11: r = dbl ? SF.i32_to_f64((int32_t)c[i]).v : SF.i32_to_f32((int32_t)c[i]).v; break;
+      case 12: r = dbl ? SF.ui64_to_f64(c[i]).v : SF.ui64_to_f32(c[i]).v; break;
+      case 13: r = dbl ? SF.i64_to_f64((i64)c[i]).v : SF.i64_to_f32((i64)c[i]).v; break;
+      case 14: r = dbl ? SF.f64_to_f32(X).v : SF.f32_to_f64(x).v; break;
+      default: return -2;
+    }
+    out[i] = r; flags[i] = *SF.flags;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ hart state */
 enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
 

@@ -60,14 +60,20 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    """Build under an exclusive file lock: several processes (ranks of a multi-process test, pytest-xdist workers) may find the
+    library stale at the same moment, and a library must never be loaded while another process is still writing it."""
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        srcs = [os.path.join(HERE, n) for n in ("rv_oracle.c", "rv_oracle.h", "rv_oracle_vec.inc")]
+        if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+            build()                                   # a stale oracle is never used silently
         L = C.CDLL(LIB)
         L.rvo_create.restype = C.c_void_p
         L.rvo_create.argtypes = [C.POINTER(Config)]

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-1 profiling recipe (run on the GPU box through gpurun from the repo root):
-#   bash profiles/run_profile.sh            -> gpurun_out/prof_r01/*; copy the summaries into profiles/
+# Profiling recipe (run on the GPU box through gpurun from the repo root):
+#   bash profiles/run_profile.sh <tag>      -> gpurun_out/prof_<tag>/*; then here: python profiles/summarize.py gpurun_out/prof_<tag> <tag> <commit>
 # 1. plain bench (JSON line), 2. rocprofv3 kernel trace + stats of the same command, 3./4. PMC passes
 # (FETCH_SIZE and WRITE_SIZE need separate runs: 3 + 2 TCC counters), 5. SQ instruction mix.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r01f; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r02_a}; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
 timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/kt.json 2> $O/kt.err

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Folds the rocprofv3 outputs of profiles/run_profile.sh (gpurun_out/prof_<tag>/) into the three files committed per profile:
    <tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_per_launch.json (counter totals / launches, per kernel).
-   usage: python profiles/summarize.py gpurun_out/prof_r01d r01_d"""
+   usage: python profiles/summarize.py gpurun_out/prof_r01d r01_d [commit]   (commit: the tree the profile was taken at)"""
 import collections
 import csv
 import json
@@ -27,5 +27,7 @@ for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
         e = out.setdefault(k, collections.OrderedDict(launches=len(disp[k])))
         for c, v in sorted(cs.items()):
             e[f"{c}_per_launch"] = v / len(disp[k])
+if len(sys.argv) > 3:
+    out["_commit"] = sys.argv[3]
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if "step" in k}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if "step" in k or k == "_commit"}, indent=1))

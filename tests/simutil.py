@@ -19,9 +19,18 @@ SHIM_LIB = os.path.join(ROOT, "tests", "host_shim", "libwsp_hostsim.so")
 
 def build_shim():
     deps = [SHIM_SRC, os.path.join(ROOT, "whisper_amd", "csrc", "wsp_core.h"), os.path.join(ROOT, "whisper_amd", "csrc", "wsp_softfloat.h")]
-    if os.path.exists(SHIM_LIB) and all(os.path.getmtime(SHIM_LIB) >= os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(SHIM_LIB) and all(os.path.getmtime(SHIM_LIB) >= os.path.getmtime(d) for d in deps)
+    if fresh():
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", SHIM_LIB, SHIM_SRC])
+    import fcntl
+    with open(SHIM_LIB + ".lock", "w") as lk:          # one builder at a time; the library appears under its name only when complete
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if fresh():
+            return
+        tmp = SHIM_LIB + f".{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp, SHIM_SRC])
+        os.replace(tmp, SHIM_LIB)
 
 
 _shim = None

@@ -424,16 +424,13 @@ def test_sharding_gather_world_size_2_gloo(tmp_path):
     assert shard.weak_range(4096, 3) == (12288, 16384)
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
+    # Cause of the launch failures seen in round 1: both ranks found the oracle library older than its sources right after an
+    # edit and rebuilt it at the same time (one rank then loaded a half-written file); the port picked here could also be taken
+    # between its release and the launcher's bind.  Builds now run under a file lock and are done once, here, before the ranks
+    # start; the launcher picks its own rendezvous port (--standalone).
+    S.rvoracle.lib()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    import socket
-    for attempt in range(3):                         # the rendezvous port is picked, released, then bound by the launcher: retry once if it was taken meanwhile
-        with socket.socket() as sk:                  # a free rendezvous port (a fixed one can linger in TIME_WAIT)
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                              "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300, env=env)
-        if out.returncode == 0 and "RANK 0 OK" in out.stdout and "RANK 1 OK" in out.stdout:
-            break
-        print(f"attempt {attempt}: rc={out.returncode}\n{out.stdout[-1500:]}\n{out.stderr[-3000:]}", file=sys.stderr)   # seen to fail once in a while right after a rebuild
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                          "--nproc-per-node", "2", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
     assert "RANK 0 OK" in out.stdout and "RANK 1 OK" in out.stdout, out.stdout + out.stderr[-2000:]

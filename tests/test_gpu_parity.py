@@ -309,7 +309,7 @@ def test_commit_ring_matches_oracle_log(kind):
         b.snapshot()
         assert b.run(trace_hash=True) == 0
         plain = [r.as_dict() for r in b.results()]
-        for cap in (1 << 18, 100):
+        for cap in (1 << 19, 100):
             b.restore()
             b.trace_ring(cap)
             assert b.run(trace_hash=True) == 0
@@ -318,7 +318,7 @@ def test_commit_ring_matches_oracle_log(kind):
                 _, _, log = S.run_oracle(p, hart_id=i, log_cap=100000)
                 want = [(c.pc, c.inst, c.size, c.trap, [(k, key, val) for k, key, val in c.changes()] or [(1, 0, 0)]) for c in log]
                 got = [(pc, inst, size, trap, pairs) for pc, inst, size, priv, trap, pairs in b.trace(i)]
-                if cap >= 1 << 18:
+                if cap >= 1 << 19:
                     assert got == want, (kind, i, next((g, w) for g, w in zip(got, want) if g != w) if len(got) == len(want) else (len(got), len(want)))
                 else:
                     assert 0 < len(got) < len(want) and got == want[:len(got)]

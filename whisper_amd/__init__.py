@@ -87,6 +87,7 @@ def lib():
         L.wsp_batch_run.argtypes = [vp, u64, u32]
         L.wsp_batch_last_run_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
         L.wsp_batch_results.argtypes = [vp, C.POINTER(Result)]
+        L.wsp_sf_eval.argtypes = [u32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_size_t, C.POINTER(u64), C.POINTER(u32)]
         L.wsp_batch_last_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
         L.wsp_batch_signature.restype = C.c_int64
         L.wsp_batch_signature.argtypes = [vp, u32, C.POINTER(u32), C.c_size_t]
@@ -124,6 +125,7 @@ class Batch:
         _check(self.L.wsp_batch_create(C.byref(desc), C.byref(h)))
         self.h = h
         self.n = n_harts
+        self.vlen_bytes = (vlen_bytes or 64) if "v" in isa.lower().split("_")[0][4:] else 0   # Hart.cpp:1081 default
 
     def close(self):
         if getattr(self, "h", None):
@@ -162,7 +164,7 @@ class Batch:
 
     def peek(self, hart, res, idx, size=8):
         if res == RES_V:
-            size = 64
+            size = self.vlen_bytes
         if res in (RES_MEM, RES_V):
             buf = C.create_string_buffer(size)
             _check(self.L.wsp_batch_peek(self.h, hart, res, idx, buf, size))
@@ -209,14 +211,14 @@ class Batch:
         buf = (C.c_uint64 * self._ring_cap)()
         n = _check(self.L.wsp_batch_trace_read(self.h, hart, buf, self._ring_cap))
         out, i = [], 0
-        while i + 2 <= n:
-            pc, meta = buf[i], buf[i + 1]
+        while i + 3 <= n:
+            pc, meta, kinds = buf[i], buf[i + 1], buf[i + 2]
             npairs = meta >> 56
-            if i + 2 + 2 * npairs > n:
+            if i + 3 + 2 * npairs > n:
                 break
-            pairs = [((buf[i + 2 + 2 * k] >> 60) & 7, buf[i + 2 + 2 * k] & ((1 << 60) - 1), buf[i + 3 + 2 * k]) for k in range(npairs)]
+            pairs = [((kinds >> (4 * k)) & 15, buf[i + 3 + 2 * k], buf[i + 4 + 2 * k]) for k in range(npairs)]
             out.append((pc, meta & 0xFFFFFFFF, (meta >> 48) & 0xFF, (meta >> 32) & 0xFF, (meta >> 40) & 0xFF, pairs))
-            i += 2 + 2 * npairs
+            i += 3 + 2 * npairs
         return out
 
     def snapshot(self):
@@ -239,3 +241,13 @@ def decode_words(isa, words, host=False):
     fn = L.wsp_decode_words_host if host else L.wsp_decode_words
     _check(fn(isa.encode(), arr, n, out))
     return out
+
+
+def sf_eval(op, rm, a, b, c):
+    """Device softfloat over operand lists (wsp_sf_eval): returns (results, flags)."""
+    L = lib()
+    n = len(a)
+    A = (C.c_uint64 * n)(*a); B = (C.c_uint64 * n)(*b); Cc = (C.c_uint64 * n)(*c)
+    out = (C.c_uint64 * n)(); fl = (C.c_uint32 * n)()
+    _check(L.wsp_sf_eval(op, rm, A, B, Cc, n, out, fl))
+    return list(out), list(fl)

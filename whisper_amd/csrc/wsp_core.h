@@ -2912,47 +2912,50 @@ template <class MEM> struct Lane {
 
   // ---- fold one commit record into the running trace hash
   // Commit record of one step.  The digest folds a word stream: pc, meta, then one (key, value) pair per change in the order the
-  // reference's log prints them (printTrace.cpp:380-495).  With a commit ring configured (wsp_batch_trace_ring) the same words are
-  // also appended to this hart's ring, the pair count patched into bits 56.. of the stored meta word; recording stops when the
-  // ring is full, the digest goes on.
+  // reference's log prints them (printTrace.cpp:380-495), key = id ^ kind << 60.  With a commit ring configured
+  // (wsp_batch_trace_ring) the record is also appended to this hart's ring as pc, meta, kinds, then (id, value) per pair: the
+  // ids are stored whole (a virtual address may use bits 60..63) and the 4-bit kinds travel in their own word, pair k in bits
+  // 4k..4k+3; the pair count is patched into bits 56.. of the stored meta word.  Recording stops when the ring is full, the
+  // digest goes on.
   template <bool TRACE> WSP_HD void commit(u64 cur_pc, u32 raw, u32 size, u32 priv0, u32 trap)
   {
     if (!TRACE) return;
     u64 t = h.thash;
-    u64* const rg = ring_; u32 pos = rg ? *ring_pos_ : 0; const u32 cap = ring_cap, meta_at = pos + 1; u32 np = 0;
-#define WSP_PUT(w) do { const u64 w_ = (w); t = fold(t, w_); if (rg && pos < cap) rg[pos++] = w_; } while (0)
-#define WSP_PAIR(k, v) do { WSP_PUT(k); WSP_PUT(v); ++np; } while (0)
-    WSP_PUT(cur_pc);
-    WSP_PUT((u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48));
+    u64* const rg = ring_; u32 pos = rg ? *ring_pos_ : 0; const u32 cap = ring_cap, meta_at = pos + 1, kinds_at = pos + 2; u32 np = 0; u64 kinds = 0;
+#define WSP_RING(w) do { if (rg && pos < cap) rg[pos++] = (w); } while (0)
+#define WSP_PAIR(kind, id, v) do { const u64 id_ = (id), v_ = (v); t = fold(t, id_ ^ ((u64)(kind) << 60)); t = fold(t, v_); \
+                                   WSP_RING(id_); WSP_RING(v_); if (np < 16) kinds |= (u64)(kind) << (4 * np); ++np; } while (0)
+    const u64 meta = (u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48);
+    t = fold(t, cur_pc); t = fold(t, meta);
+    WSP_RING(cur_pc); WSP_RING(meta); WSP_RING(0);
     const u32 c = s.chg;
-    if ((c & CH_IREG) && s.ireg) WSP_PAIR((u64)s.ireg ^ (1ULL << 60), s.ival);
-    if (c & CH_FREG) WSP_PAIR((u64)s.freg ^ (2ULL << 60), s.fval);
+    if ((c & CH_IREG) && s.ireg) WSP_PAIR(1, s.ireg, s.ival);
+    if (c & CH_FREG) WSP_PAIR(2, s.freg, s.fval);
     if (s.vgroup) {          // one v line per register of the group (printTrace.cpp:424-441): the record carries a digest of its bytes
       for (u32 g = 0; g < s.vgroup; ++g) {
         const u32 reg = (s.vreg + g) & 31; u64 d = 0;
         for (u32 w = 0; w < vlenb / 8; ++w) d = fold(d, m.vld(reg * vlenb + 8 * w, 3));
-        WSP_PAIR((u64)reg ^ (3ULL << 60), d);
+        WSP_PAIR(3, reg, d);
       }
     }
-    if (c & CH_MEM) WSP_PAIR(s.maddr ^ (4ULL << 60), s.mval);
-    const u64 K = 5ULL << 60;
+    if (c & CH_MEM) WSP_PAIR(4, s.maddr, s.mval);
     const bool gen_lo = (c & CH_GEN) && s.gen_csr < 0x300;
-    if (gen_lo) WSP_PAIR((u64)s.gen_csr ^ K, csr_peek(s.gen_csr));
-    if (c & CH_SSTATUS) WSP_PAIR((u64)C_SSTATUS ^ K, csr_peek(C_SSTATUS));
-    if (c & CH_SEPC) WSP_PAIR((u64)C_SEPC ^ K, m.cold(CI_SEPC) & epc_rmask());
-    if (c & CH_SCAUSE) WSP_PAIR((u64)C_SCAUSE ^ K, m.cold(CI_SCAUSE));
-    if (c & CH_STVAL) WSP_PAIR((u64)C_STVAL ^ K, m.cold(CI_STVAL));
-    if (c & CH_MSTATUS) WSP_PAIR((u64)C_MSTATUS ^ K, csr_peek(C_MSTATUS));
-    if ((c & CH_GEN) && !gen_lo) WSP_PAIR((u64)s.gen_csr ^ K, csr_peek(s.gen_csr));
-    if (c & CH_MEPC) WSP_PAIR((u64)C_MEPC ^ K, m.cold(CI_MEPC) & epc_rmask());
-    if (c & CH_MCAUSE) WSP_PAIR((u64)C_MCAUSE ^ K, m.cold(CI_MCAUSE));
-    if (c & CH_MTVAL) WSP_PAIR((u64)C_MTVAL ^ K, m.cold(CI_MTVAL));
-    if (c & CH_VL) WSP_PAIR((u64)C_VL ^ K, m.cold(CI_VL));
-    if (c & CH_VTYPE) WSP_PAIR((u64)C_VTYPE ^ K, m.cold(CI_VTYPE));
-    if (np == 0) WSP_PAIR(1ULL << 60, 0);                                                         // printTrace.cpp:491-493: an "r x0 0" line
+    if (gen_lo) WSP_PAIR(5, s.gen_csr, csr_peek(s.gen_csr));
+    if (c & CH_SSTATUS) WSP_PAIR(5, C_SSTATUS, csr_peek(C_SSTATUS));
+    if (c & CH_SEPC) WSP_PAIR(5, C_SEPC, m.cold(CI_SEPC) & epc_rmask());
+    if (c & CH_SCAUSE) WSP_PAIR(5, C_SCAUSE, m.cold(CI_SCAUSE));
+    if (c & CH_STVAL) WSP_PAIR(5, C_STVAL, m.cold(CI_STVAL));
+    if (c & CH_MSTATUS) WSP_PAIR(5, C_MSTATUS, csr_peek(C_MSTATUS));
+    if ((c & CH_GEN) && !gen_lo) WSP_PAIR(5, s.gen_csr, csr_peek(s.gen_csr));
+    if (c & CH_MEPC) WSP_PAIR(5, C_MEPC, m.cold(CI_MEPC) & epc_rmask());
+    if (c & CH_MCAUSE) WSP_PAIR(5, C_MCAUSE, m.cold(CI_MCAUSE));
+    if (c & CH_MTVAL) WSP_PAIR(5, C_MTVAL, m.cold(CI_MTVAL));
+    if (c & CH_VL) WSP_PAIR(5, C_VL, m.cold(CI_VL));
+    if (c & CH_VTYPE) WSP_PAIR(5, C_VTYPE, m.cold(CI_VTYPE));
+    if (np == 0) WSP_PAIR(1, 0, 0);                                                               // printTrace.cpp:491-493: an "r x0 0" line
 #undef WSP_PAIR
-#undef WSP_PUT
-    if (rg) { if (meta_at < pos) rg[meta_at] |= (u64)np << 56; *ring_pos_ = pos; }
+#undef WSP_RING
+    if (rg) { if (kinds_at < pos) { rg[meta_at] |= (u64)np << 56; rg[kinds_at] = kinds; } *ring_pos_ = pos; }
     h.thash = t;
   }
 };

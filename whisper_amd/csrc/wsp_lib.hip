@@ -758,6 +758,34 @@ __global__ void wsp_results_kernel(DevState d, const u64* memhash, wsp_result* o
   out[hart] = r;
 }
 
+// Device softfloat sweep (diagnostic surface, wsp_sf_eval): the gfx950 build of wsp_softfloat.h - the schoolbook 128 / 64
+// division, __umul64hi products and clz paths that a host build of the header replaces with compiler builtins.
+__global__ void wsp_sf_eval_kernel(u32 op, int rm, const u64* a, const u64* b, const u64* c, u64 n, u64* out, u32* flags)
+{
+  using namespace wsf;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool dbl = (op & 0x100) != 0; const u32 k = op & 0xff;
+  const u64 x = a[i], y = b[i], z = c[i];
+  unsigned fl = 0; u64 r = 0;
+  switch (k) {
+    case 0: r = dbl ? f_add<F64>(x, y, rm, fl) : f_add<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
+    case 1: r = dbl ? f_sub<F64>(x, y, rm, fl) : f_sub<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
+    case 2: r = dbl ? f_mul<F64>(x, y, rm, fl) : f_mul<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
+    case 3: r = dbl ? f_div<F64>(x, y, rm, fl) : f_div<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
+    case 4: r = dbl ? f_sqrt<F64>(x, rm, fl) : f_sqrt<F32>(x & 0xffffffffULL, rm, fl); break;
+    case 5: r = dbl ? f_fma<F64>(x, y, z, rm, fl) : f_fma<F32>(x & 0xffffffffULL, y & 0xffffffffULL, z & 0xffffffffULL, rm, fl); break;
+    case 6: case 7: case 8: case 9: {
+      const bool sg = (k - 6) & 1, w = ((k - 6) & 2) != 0;
+      r = dbl ? f_to_int<F64>(x, rm, sg, w, fl) : f_to_int<F32>(x & 0xffffffffULL, rm, sg, w, fl); break; }
+    case 10: case 11: case 12: case 13: {
+      const bool sg = (k - 10) & 1, w = ((k - 10) & 2) != 0;
+      r = dbl ? int_to_f<F64>(z, sg, w, rm, fl) : int_to_f<F32>(z, sg, w, rm, fl); break; }
+    default: r = dbl ? f64_to_f32(x, rm, fl) : f32_to_f64(x & 0xffffffffULL, fl); break;
+  }
+  out[i] = r; flags[i] = fl;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -926,6 +954,14 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   return WSP_OK;
 }
 
+// Device staging buffer that is released on every return path.
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+  template <class T> T* as() const { return (T*)p; }
+};
+
 static int check_range(wsp_batch* b, u32 lo, u32 hi)
 {
   if (!b) return fail(WSP_EINVAL, "null batch");
@@ -938,14 +974,13 @@ static int write_arena(wsp_batch* b, u32 lo, u32 hi, u64 addr, const void* bytes
   DevState& d = b->d;
   if (n == 0) return WSP_OK;
   if (addr < d.mem_base || addr - d.mem_base > d.mem_size - n || n > d.mem_size) return fail(WSP_ERANGE, "image outside the hart arena");
-  u8* stage = nullptr;
-  HIPOK(hipMalloc(&stage, n));
-  HIPOK(hipMemcpy(stage, bytes, n, hipMemcpyHostToDevice));
+  DevBuf stage;
+  HIPOK(stage.alloc(n));
+  HIPOK(hipMemcpy(stage.p, bytes, n, hipMemcpyHostToDevice));
   u64 off = addr - d.mem_base, nw = ((off + n + 7) >> 3) - (off >> 3), total = nw * (hi - lo);
-  hipLaunchKernelGGL(wsp_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, off, stage, (u64)n);
+  hipLaunchKernelGGL(wsp_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, off, stage.as<u8>(), (u64)n);
   HIPOK(hipGetLastError());
   HIPOK(hipStreamSynchronize(b->stream));
-  HIPOK(hipFree(stage));
   return WSP_OK;
 }
 
@@ -998,15 +1033,16 @@ static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vec
   if (!text.empty()) {
     p.text_lo = text_lo; p.text_hi = text_lo + (text.size() & ~(size_t)1);
     u64 nslots = (p.text_hi - p.text_lo) / 2;
-    u8* dimg = nullptr;
-    HIPOK(hipMalloc(&dimg, text.size()));
-    HIPOK(hipMemcpy(dimg, text.data(), text.size(), hipMemcpyHostToDevice));
     if (nslots >= (1u << 29)) return fail(WSP_ERANGE, "code image of 1 GiB or more");
-    HIPOK(hipMalloc(&p.d_recs, (nslots + 2) * sizeof(Rec)));
-    hipLaunchKernelGGL(wsp_predecode_kernel, dim3((unsigned)((nslots + 2 + 255) / 256)), dim3(256), 0, b->stream, dimg, (u64)(p.text_hi - p.text_lo), d.isa, p.d_recs);
+    DevBuf dimg;
+    HIPOK(dimg.alloc(text.size()));
+    HIPOK(hipMemcpy(dimg.p, text.data(), text.size(), hipMemcpyHostToDevice));
+    DevBuf recs;
+    HIPOK(recs.alloc((nslots + 2) * sizeof(Rec)));
+    hipLaunchKernelGGL(wsp_predecode_kernel, dim3((unsigned)((nslots + 2 + 255) / 256)), dim3(256), 0, b->stream, dimg.as<u8>(), (u64)(p.text_hi - p.text_lo), d.isa, recs.as<Rec>());
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(b->stream));
-    HIPOK(hipFree(dimg));
+    p.d_recs = recs.as<Rec>(); recs.p = nullptr;       // owned by the batch from here on
   }
   b->progs.push_back(p);
   u32 id = (u32)b->progs.size() - 1;
@@ -1052,14 +1088,18 @@ extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, co
   if (e[4] != 2) return fail(WSP_EFORMAT, "ELF class is not 64-bit");        // Session.cpp:1373-1424 xlen from ELF class
   if (e[5] != 1) return fail(WSP_EFORMAT, "ELF is not little-endian");
   Elf64_Ehdr_ eh; memcpy(&eh, e, sizeof eh);
-  if (eh.phoff + (u64)eh.phnum * sizeof(Elf64_Phdr_) > n) return fail(WSP_EFORMAT, "program headers out of file");
+  // every range check in the form "off > n || len > n - off": no sum can wrap
+  auto in_file = [n](u64 off, u64 len) { return off <= n && len <= n - off; };
+  if (eh.phnum && eh.phentsize != sizeof(Elf64_Phdr_)) return fail(WSP_EFORMAT, "unexpected program header entry size");
+  if (eh.shnum && eh.shentsize != sizeof(Elf64_Shdr_)) return fail(WSP_EFORMAT, "unexpected section header entry size");
+  if (!in_file(eh.phoff, (u64)eh.phnum * sizeof(Elf64_Phdr_))) return fail(WSP_EFORMAT, "program headers out of file");
   DevState& d = b->d;
   u64 xlo = ~0ULL, xhi = 0;
   std::vector<Elf64_Phdr_> loads;
   for (u32 i = 0; i < eh.phnum; ++i) {
     Elf64_Phdr_ ph; memcpy(&ph, e + eh.phoff + (u64)i * eh.phentsize, sizeof ph);
     if (ph.type != 1 || ph.filesz == 0) continue;                            // PT_LOAD, p_filesz bytes only (Memory.cpp:450-489)
-    if (ph.offset + ph.filesz > n) return fail(WSP_EFORMAT, "segment out of file");
+    if (!in_file(ph.offset, ph.filesz)) return fail(WSP_EFORMAT, "segment out of file");
     if (ph.paddr < d.mem_base || ph.paddr - d.mem_base > d.mem_size - ph.filesz || ph.filesz > d.mem_size)
       return fail(WSP_ERANGE, "ELF segment outside the hart arena");
     loads.push_back(ph);
@@ -1068,21 +1108,26 @@ extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, co
   for (auto& ph : loads) { rc = write_arena(b, lo, hi, ph.paddr, e + ph.offset, ph.filesz); if (rc) return rc; }
   // symbols + .tdata
   std::map<std::string, u64> syms; u64 tdata = 0;
-  if (eh.shoff && eh.shoff + (u64)eh.shnum * sizeof(Elf64_Shdr_) <= n) {
+  if (eh.shoff && in_file(eh.shoff, (u64)eh.shnum * sizeof(Elf64_Shdr_))) {
     std::vector<Elf64_Shdr_> sh(eh.shnum);
     for (u32 i = 0; i < eh.shnum; ++i) memcpy(&sh[i], e + eh.shoff + (u64)i * eh.shentsize, sizeof(Elf64_Shdr_));
-    const char* shstr = (eh.shstrndx < eh.shnum && sh[eh.shstrndx].offset < n) ? (const char*)e + sh[eh.shstrndx].offset : nullptr;
+    // a name is taken only when its terminating NUL lies inside its string table (and the table inside the file)
+    auto name_at = [&](const Elf64_Shdr_& tab, u64 off) -> const char* {
+      if (!in_file(tab.offset, tab.size) || off >= tab.size) return nullptr;
+      const char* p0 = (const char*)e + tab.offset + off;
+      return memchr(p0, 0, tab.size - off) ? p0 : nullptr;
+    };
+    const Elf64_Shdr_* shstr = eh.shstrndx < eh.shnum ? &sh[eh.shstrndx] : nullptr;
     for (u32 i = 0; i < eh.shnum; ++i) {
-      if (shstr && sh[i].name < sh[eh.shstrndx].size && strcmp(shstr + sh[i].name, ".tdata") == 0) tdata = sh[i].addr;
-      if (sh[i].type != 2 || sh[i].link >= eh.shnum || sh[i].offset + sh[i].size > n) continue;   // SHT_SYMTAB
+      const char* sn = shstr ? name_at(*shstr, sh[i].name) : nullptr;
+      if (sn && strcmp(sn, ".tdata") == 0) tdata = sh[i].addr;
+      if (sh[i].type != 2 || sh[i].link >= eh.shnum || !in_file(sh[i].offset, sh[i].size)) continue;   // SHT_SYMTAB
       const Elf64_Shdr_& st = sh[sh[i].link];
-      if (st.offset + st.size > n) continue;
       size_t cnt = sh[i].size / sizeof(Elf64_Sym_);
       for (size_t k = 0; k < cnt; ++k) {
         Elf64_Sym_ sy; memcpy(&sy, e + sh[i].offset + k * sizeof(Elf64_Sym_), sizeof sy);
-        if (sy.name >= st.size) continue;
-        const char* nm = (const char*)e + st.offset + sy.name;
-        if (*nm) syms[nm] = sy.value;
+        const char* nm = name_at(st, sy.name);
+        if (nm && *nm) syms[nm] = sy.value;
       }
     }
   }
@@ -1188,10 +1233,10 @@ extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
       return WSP_OK;
     case WSP_RES_MEM: {
       if (idx < d.mem_base || idx - d.mem_base > d.mem_size - size || size > d.mem_size) return fail(WSP_ERANGE, "memory peek outside arena");
-      u8* tmp = nullptr; HIPOK(hipMalloc(&tmp, size));
-      hipLaunchKernelGGL(wsp_gather_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, b->stream, d, hart, idx - d.mem_base, tmp, (u64)size);
+      DevBuf tmp; HIPOK(tmp.alloc(size));
+      hipLaunchKernelGGL(wsp_gather_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, b->stream, d, hart, idx - d.mem_base, tmp.as<u8>(), (u64)size);
       HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream));
-      HIPOK(hipMemcpy(val, tmp, size, hipMemcpyDeviceToHost)); HIPOK(hipFree(tmp));
+      HIPOK(hipMemcpy(val, tmp.p, size, hipMemcpyDeviceToHost));
       return WSP_OK; }
     default: return fail(WSP_EINVAL, "unknown resource");
   }
@@ -1261,10 +1306,10 @@ extern "C" int wsp_batch_poke_each(wsp_batch* b, uint32_t lo, uint32_t hi, uint3
     if ((idx & 7) || idx < d.mem_base || idx - d.mem_base > d.mem_size - 8) return fail(WSP_ERANGE, "memory dword outside arena or unaligned");
     key = idx - d.mem_base;
   } else return fail(WSP_EINVAL, "poke_each supports X and MEM");
-  u64* dv = nullptr; size_t n = hi - lo;
-  HIPOK(hipMalloc(&dv, n * 8)); HIPOK(hipMemcpy(dv, vals, n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(wsp_poke_each_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, res, key, dv);
-  HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream)); HIPOK(hipFree(dv));
+  DevBuf dv; size_t n = hi - lo;
+  HIPOK(dv.alloc(n * 8)); HIPOK(hipMemcpy(dv.p, vals, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(wsp_poke_each_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, d, lo, hi, res, key, dv.as<u64>());
+  HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream));
   return WSP_OK;
 }
 
@@ -1306,12 +1351,11 @@ extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flag
 extern "C" int wsp_batch_last_run_stats(wsp_batch* b, double* s, uint32_t* launches)
 { if (!b) return fail(WSP_EINVAL, "null batch"); if (s) *s = b->last_kernel_s; if (launches) *launches = b->last_launches; return WSP_OK; }
 
-extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
+// memory digest + result records: partial sums in `memhash` (S words, zeroed here), records into `d_out` (device memory)
+static int results_on_device(wsp_batch* b, u64* memhash, wsp_result* d_out)
 {
-  if (!b || !out) return fail(WSP_EINVAL, "null argument");
-  HIPOK(hipSetDevice(b->device));
   DevState& d = b->d;
-  HIPOK(hipMemsetAsync(b->d_memhash, 0, (size_t)d.S * 8, b->stream));
+  HIPOK(hipMemsetAsync(memhash, 0, (size_t)d.S * 8, b->stream));
   const u64 total = (d.mem_size >> 3) * d.lpw;          // words per wave block; mem_size is a multiple of 4096
   // enough chunks that the grid has >= ~8 workgroups per CU even for small batches; chunk = multiple of 256 words
   u64 chunks = 1;
@@ -1319,11 +1363,20 @@ extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
   u64 wpc = (total / chunks + WSP_MH_THREADS - 1) / WSP_MH_THREADS * WSP_MH_THREADS;
   chunks = (total + wpc - 1) / wpc;
   HIPOK(hipEventRecord(b->ev0, b->stream));
-  hipLaunchKernelGGL(wsp_memhash_kernel, dim3(d.n_waves, (unsigned)chunks), dim3(WSP_MH_THREADS), 0, b->stream, d, wpc, b->d_memhash);
+  hipLaunchKernelGGL(wsp_memhash_kernel, dim3(d.n_waves, (unsigned)chunks), dim3(WSP_MH_THREADS), 0, b->stream, d, wpc, memhash);
   HIPOK(hipGetLastError());
   HIPOK(hipEventRecord(b->ev1, b->stream));
-  hipLaunchKernelGGL(wsp_results_kernel, dim3((d.n_harts + 127) / 128), dim3(128), 0, b->stream, d, b->d_memhash, b->d_results);
+  hipLaunchKernelGGL(wsp_results_kernel, dim3((d.n_harts + 127) / 128), dim3(128), 0, b->stream, d, (const u64*)memhash, d_out);
   HIPOK(hipGetLastError());
+  return WSP_OK;
+}
+
+extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
+{
+  if (!b || !out) return fail(WSP_EINVAL, "null argument");
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d;
+  int rc = results_on_device(b, b->d_memhash, b->d_results); if (rc) return rc;
   HIPOK(hipMemcpyAsync(out, b->d_results, (size_t)d.n_harts * sizeof(wsp_result), hipMemcpyDeviceToHost, b->stream));
   HIPOK(hipStreamSynchronize(b->stream));
   float ms = 0; HIPOK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
@@ -1344,7 +1397,7 @@ extern "C" int wsp_batch_trace_ring(wsp_batch* b, uint32_t words_per_hart)
   if (d.ring_pos) { HIPOK(hipFree(d.ring_pos)); d.ring_pos = nullptr; }
   d.ring_cap = 0;
   if (words_per_hart == 0) return WSP_OK;
-  if (words_per_hart < 4) return fail(WSP_EINVAL, "trace ring: at least 4 words per hart (one record is pc, meta and one pair)");
+  if (words_per_hart < 5) return fail(WSP_EINVAL, "trace ring: at least 5 words per hart (one record is pc, meta, kinds and one pair)");
   const size_t bytes = (size_t)d.n_harts * words_per_hart * 8;
   if (hipMalloc((void**)&d.ring, bytes) != hipSuccess) { d.ring = nullptr; return fail(WSP_ENOMEM, "trace ring: hipMalloc failed"); }
   if (hipMalloc((void**)&d.ring_pos, (size_t)d.n_harts * 4) != hipSuccess) { hipFree(d.ring); d.ring = nullptr; d.ring_pos = nullptr; return fail(WSP_ENOMEM, "trace ring: hipMalloc failed"); }
@@ -1418,12 +1471,28 @@ extern "C" int wsp_decode_words(const char* isa, const uint32_t* words, size_t n
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device");
   if (n == 0) return WSP_OK;
-  u32* dw = nullptr; Rec* dr = nullptr;
-  HIPOK(hipMalloc(&dw, n * 4)); HIPOK(hipMalloc(&dr, n * sizeof(Rec)));
-  HIPOK(hipMemcpy(dw, words, n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(wsp_decode_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dw, (u64)n, f, dr);
+  DevBuf dw, dr;
+  HIPOK(dw.alloc(n * 4)); HIPOK(dr.alloc(n * sizeof(Rec)));
+  HIPOK(hipMemcpy(dw.p, words, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(wsp_decode_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dw.as<u32>(), (u64)n, f, dr.as<Rec>());
   HIPOK(hipGetLastError()); HIPOK(hipDeviceSynchronize());
-  HIPOK(hipMemcpy(out, dr, n * sizeof(Rec), hipMemcpyDeviceToHost));
-  HIPOK(hipFree(dw)); HIPOK(hipFree(dr));
+  HIPOK(hipMemcpy(out, dr.p, n * sizeof(Rec), hipMemcpyDeviceToHost));
+  return WSP_OK;
+}
+
+
+extern "C" int wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n, uint64_t* out, uint32_t* flags)
+{
+  if (!a || !b || !c || !out || !flags) return fail(WSP_EINVAL, "null argument");
+  if (rm > 4 || (op & 0xff) > 14 || (op & ~0x1ffu)) return fail(WSP_EINVAL, "wsp_sf_eval: bad op or rounding mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device");
+  if (n == 0) return WSP_OK;
+  DevBuf da, db, dc, dout, dfl;
+  HIPOK(da.alloc(n * 8)); HIPOK(db.alloc(n * 8)); HIPOK(dc.alloc(n * 8)); HIPOK(dout.alloc(n * 8)); HIPOK(dfl.alloc(n * 4));
+  HIPOK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(db.p, b, n * 8, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(dc.p, c, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(wsp_sf_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (int)rm, da.as<u64>(), db.as<u64>(), dc.as<u64>(), (u64)n, dout.as<u64>(), dfl.as<u32>());
+  HIPOK(hipGetLastError()); HIPOK(hipDeviceSynchronize());
+  HIPOK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(flags, dfl.p, n * 4, hipMemcpyDeviceToHost));
   return WSP_OK;
 }

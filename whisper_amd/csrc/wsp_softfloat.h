@@ -5,8 +5,9 @@
 // result, invalid on signaling NaNs, tininess detected AFTER rounding, RISC-V integer saturation
 // values), which the reference reaches through float-util.hpp:230-930.  Written from the IEEE
 // behaviour, not from the library's code: every operation funnels an exact (sign, exponent,
-// 128-bit significand + sticky) value through one rounding routine.  tests/test_softfloat.py
-// compares each entry point against the real library (oracle/_ref) on directed + random operands.
+// 128-bit significand + sticky) value through one rounding routine.  oracle/sf_check.cpp (host build)
+// and tests/test_gpu_softfloat.py (the gfx950 build, through wsp_sf_eval) compare each entry point against the real library
+// (oracle/_ref) on directed + random operands.
 //
 // All functions are WSP_HD so the same source is compiled into the HIP kernels and into the
 // host-side unit-test shim; there is no separate CPU implementation.
@@ -14,7 +15,7 @@
 #include <stdint.h>
 
 #ifndef WSP_HD
-#  if defined(__HIPCC__) || defined(__CUDACC__)
+#  if defined(__HIPCC__)
 #    define WSP_HD __host__ __device__ __forceinline__
 #    define WSP_HDN __host__ __device__ __attribute__((noinline))     /* large, rarely taken paths: kept out of their callers' register budget */
 #  else
