@@ -87,6 +87,7 @@ def lib():
         L.wsp_batch_run.argtypes = [vp, u64, u32]
         L.wsp_batch_last_run_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
         L.wsp_batch_results.argtypes = [vp, C.POINTER(Result)]
+        L.wsp_batch_results_noalloc.argtypes = [vp, C.c_void_p]
         L.wsp_sf_eval.argtypes = [u32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.c_size_t, C.POINTER(u64), C.POINTER(u32)]
         L.wsp_batch_last_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
         L.wsp_batch_signature.restype = C.c_int64
@@ -194,6 +195,10 @@ class Batch:
         arr = (Result * self.n)()
         _check(self.L.wsp_batch_results(self.h, arr))
         return arr
+
+    def results_noalloc(self, device_ptr):
+        """wsp_batch_results_noalloc: records written to caller-owned DEVICE memory (n * sizeof(Result) bytes at device_ptr)."""
+        _check(self.L.wsp_batch_results_noalloc(self.h, C.c_void_p(device_ptr)))
 
     def hash_stats(self):
         s = C.c_double(); n = C.c_uint64()

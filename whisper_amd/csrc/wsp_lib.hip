@@ -786,6 +786,12 @@ __global__ void wsp_sf_eval_kernel(u32 op, int rm, const u64* a, const u64* b, c
   out[i] = r; flags[i] = fl;
 }
 
+// Scratch of wsp_batch_results_noalloc: the per-slot partial sums of the memory digest.  One copy per GPU the library runs on,
+// held until the process ends (8 MiB); its device address is looked up once per device (scratch_of) and only that pointer is
+// ever handed to a kernel or a memset - the array's name is a host-side stand-in, not a device address.
+#define WSP_SCRATCH_SLOTS (1u << 20)
+static __device__ __align__(256) unsigned long long wsp_scratch[WSP_SCRATCH_SLOTS];
+
 // ------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -828,6 +834,21 @@ static int parse_isa(const char* isa, u32* out, std::string* why)
 }
 
 extern "C" uint32_t wsp_isa_flags(const char* isa) { u32 f = 0; std::string w; if (parse_isa(isa, &f, &w) != WSP_OK) { g_err = w; return 0xffffffffu; } return f; }
+
+// Device address of wsp_scratch on each GPU, looked up with that GPU current (each GPU holds its own copy at its own address).
+static u64* g_scratch_ptr[64];
+static int scratch_of(int dev, u64** out)
+{
+  if (dev < 0 || dev >= 64) return fail(WSP_ENODEV, "device ordinal out of range for the static scratch table");
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIPOK(hipSetDevice(dev));
+    HIPOK(hipGetSymbolAddress(&p, HIP_SYMBOL(wsp_scratch)));
+    g_scratch_ptr[dev] = (u64*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return WSP_OK;
+}
 
 struct Program {
   u64 text_lo = 0, text_hi = 0;
@@ -947,6 +968,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   std::vector<u32> v32(S, (u32)PRV_M);                hipMemcpy(d.hot32 + (size_t)H32_PRIV * S, v32.data(), S * 4, hipMemcpyHostToDevice);
   std::fill(v32.begin(), v32.end(), ~0u);             hipMemcpy(d.prog, v32.data(), S * 4, hipMemcpyHostToDevice);
   b->hart_prog.assign(d.n_harts, ~0u);
+  { u64* sp = nullptr; if (scratch_of(dev, &sp) != WSP_OK) { std::string m_ = g_err; wsp_batch_destroy(b); return fail(WSP_EHIP, m_); } }   // set-up time: wsp_batch_results_noalloc must not look anything up
   if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
     wsp_batch_destroy(b); return fail(WSP_EHIP, "stream/event creation failed");
   }
@@ -1381,6 +1403,22 @@ extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
   HIPOK(hipStreamSynchronize(b->stream));
   float ms = 0; HIPOK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
   b->last_hash_s = ms * 1e-3; b->last_hash_bytes = (u64)d.n_harts * d.mem_size;
+  return WSP_OK;
+}
+
+// The variant of wsp_batch_results that allocates nothing (for callers that cannot: HIP graph capture, tight serving loops).
+// Same two kernels; the digest's partial sums live in the static device array wsp_scratch instead of a buffer of the batch,
+// and the records are written straight into the caller's device buffer.  Every call on a GPU shares that GPU's array: the
+// part used is cleared at the start of each call, and calls that overlap on one GPU race.
+extern "C" int wsp_batch_results_noalloc(wsp_batch* b, wsp_result* d_out)
+{
+  if (!b || !d_out) return fail(WSP_EINVAL, "null argument");
+  if (b->d.S > WSP_SCRATCH_SLOTS) return fail(WSP_ERANGE, "wsp_batch_results_noalloc: batch has more than 1048576 hart slots (n_waves * 64): use wsp_batch_results");
+  u64* sp = b->device >= 0 && b->device < 64 ? g_scratch_ptr[b->device] : nullptr;   // looked up when the batch was created
+  if (!sp) return fail(WSP_EHIP, "wsp_batch_results_noalloc: no scratch address for this device");
+  HIPOK(hipSetDevice(b->device));
+  int rc = results_on_device(b, sp, d_out); if (rc) return rc;
+  HIPOK(hipStreamSynchronize(b->stream));
   return WSP_OK;
 }
 
