@@ -83,8 +83,8 @@ struct DevMem {
 #ifndef WSP_WAVES_PER_EU
 #define WSP_WAVES_PER_EU 4
 #endif
-#ifndef WSP_SCALAR_MAX_WAVES
-#define WSP_SCALAR_MAX_WAVES 1024u
+#ifndef WSP_CONVERGED_LOOP
+#define WSP_CONVERGED_LOOP 1
 #endif
 extern __shared__ __align__(16) u64 wsp_lds[];
 
@@ -138,6 +138,13 @@ struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status, fcsr; };
 
 // The general path, out of line: rebuilds the full lane from HBM, runs one complete general step
 // (interrupt poll, fetch, full exec(), retire, commit record) and stores the lane back.
+// A lane that needed one general step usually needs the next one too (S / U-mode code, self-modified code, a trap handler,
+// vector code), and what a general step costs is mostly the round trips that bring the lane's state in from HBM and take it
+// back.  So the lane stays here, state in registers, until it is hot again at a pre-decoded pc, stops, has used its budget,
+// or has run WSP_COLD_BURST steps (the other lanes of the wave wait meanwhile).
+#ifndef WSP_COLD_BURST
+#define WSP_COLD_BURST 64u
+#endif
 template <bool TRACE>
 __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, HotRegs hr)
 {
@@ -149,8 +156,12 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, H
   const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
   L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
   L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
-  L.template cold_step<TRACE>(recs);
+  u32 k = 0;
+  do {
+    L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+    L.template cold_step<TRACE>(recs);
+  } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < hr.stop_at &&
+           !((L.h.flags & HF_HOT) && L.h.pc - L.text_lo < L.text_hi - L.text_lo));
   wsp_store_hot(L, d, slot);
   HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
   return r;
@@ -184,16 +195,24 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   return r;
 }
 
-// v_writelane_b32 (this clang has no __builtin for it): the LLVM intrinsic, bound by name.
-extern "C" __device__ int wsp_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
-#define WSP_WRITELANE(v, l, o) wsp_writelane_i32((v), (l), (o))
-
 // Wave-wide minimum of a u32 (all 64 lanes participate).
 __device__ __forceinline__ u32 wave_min_u32(u32 v)
 {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { const u32 t = (u32)__shfl_xor((int)v, o, 64); v = t < v ? t : v; }
   return v;
+}
+
+// The same through DPP row shifts / broadcasts (no LDS permute traffic): result in every lane's return value (read from lane 63).
+// All 64 lanes must be active at the call.
+__device__ __forceinline__ u32 wave_min_dpp(u32 v)
+{
+  int x = (int)v;
+#define WSP_DPPMIN(ctrl, rmask) { const u32 t_ = (u32)__builtin_amdgcn_update_dpp(-1, x, ctrl, rmask, 0xf, false); x = (int)(t_ < (u32)x ? t_ : (u32)x); }
+  WSP_DPPMIN(0x111, 0xf) WSP_DPPMIN(0x112, 0xf) WSP_DPPMIN(0x114, 0xf) WSP_DPPMIN(0x118, 0xf)     // row_shr 1, 2, 4, 8: lane 15 of each row = row minimum
+  WSP_DPPMIN(0x142, 0xa) WSP_DPPMIN(0x143, 0xc)                                                   // row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
+#undef WSP_DPPMIN
+  return (u32)__builtin_amdgcn_readlane(x, 63);
 }
 
 // Record image is plain global memory.  Untraced runs load {w0, imm, pad}; traced runs also the raw instruction bits.
@@ -239,170 +258,10 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   __syncthreads();
 
   const bool zca = (d.isa & ISA_C) != 0;                 // without C, taken control transfers can trap: general path
+  // Every hart of the wave runs the same program image: the converged loop below applies (one pc for the running group).
+  const u32 pg0 = (u32)__builtin_amdgcn_readfirstlane((int)d.prog[wave * 64]);
+  const bool same_prog = pg0 != ~0u && __all(!active || d.prog[slot] == pg0);
 
-  // ================================================================================================================
-  // One hart per wave (lanes_per_wave == 1, the layout picked for batches that fit the chip with one hart per wave):
-  // the interpreter runs on the scalar unit.  Everything about the hart is wave-uniform, so pc, operands and results
-  // live in SGPRs, the integer register file sits across the lanes of two VGPRs (lane r = x[r]; lane 0 is the write
-  // sink for rd = x0, lane 32 the constant zero, exactly like the LDS slots) and is accessed with v_readlane /
-  // v_writelane, and records come through the scalar cache (the image is read-only while the kernel runs).  Arena
-  // data is read and written with vector instructions only: the scalar cache is never used for anything the kernel
-  // writes.  The CU has one scalar unit for its four SIMDs, so this mode pays only while few waves share a CU: measured
-  // +20 % at 1024 harts (one wave per SIMD), level at 2048, -10 % at 4096 (four waves per SIMD) against the vector loop
-  // below; it is used up to WSP_SCALAR_MAX_WAVES waves.
-  if (d.lpw == 1 && d.n_waves <= WSP_SCALAR_MAX_WAVES) {
-#define RFL(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
-#define RFL64(x) ((u64)RFL((u32)(x)) | ((u64)RFL((u32)((x) >> 32)) << 32))
-    u64 u_pc = RFL64(L.h.pc), u_exec = RFL64(L.h.exec), u_thash = RFL64(L.h.thash), u_stop = RFL64(stop_at);
-    u32 u_flags = RFL(L.h.flags), u_status = RFL(d.hot32[H32_STATUS * S + slot]), u_fcsr = RFL(L.h.fcsr);
-    if (wave >= d.n_harts) u_status = ST_STOP_LIMIT;   // lpw == 1: hart index = wave (uniform; `hart` itself differs per lane)
-    u64 tlo = RFL64(L.text_lo), thi = RFL64(L.text_hi), tohost = RFL64(L.tohost);
-    const u64 mbase = d.mem_base, msize = d.mem_size;
-    const char* recs_u = (const char*)(size_t)RFL64((u64)(size_t)recs);
-    u8* const arena_u = d.arena + (size_t)wave * d.mem_size;
-    // register file: LDS slots -> lanes
-    u32 xlo = 0, xhi = 0;
-    if (lane <= 32) { const u64 v = L.m.xs[lane]; xlo = (u32)v; xhi = (u32)(v >> 32); }
-#define XR(l) ((u64)(u32)__builtin_amdgcn_readlane((int)xlo, (int)(l)) | ((u64)(u32)__builtin_amdgcn_readlane((int)xhi, (int)(l)) << 32))
-#define XW(l, val) do { const u64 v_ = (val); xlo = (u32)WSP_WRITELANE((int)(u32)v_, (int)(l), (int)xlo); \
-                        xhi = (u32)WSP_WRITELANE((int)(u32)(v_ >> 32), (int)(l), (int)xhi); } while (0)
-    typedef wsp_u32x4 QT;                                            // scalar loads come in 1/2/4/8 dwords
-    typedef const __attribute__((address_space(4))) QT* CQ;          // constant address space: scalar loads
-
-    while (u_status == ST_RUNNING && u_exec < u_stop) {
-      const u64 off64 = u_pc - tlo;
-      const u32 text_len = (u32)(thi - tlo);
-      if ((u_flags & HF_HOT) && off64 < (u64)text_len) {
-        u32 pco = (u32)off64;
-        const u64 left = u_stop - u_exec;
-        const u32 n = left > 0x40000000ULL ? 0x40000000u : (u32)left;
-        u32 it = 0; bool nc = false;
-        QT q = *(CQ)(recs_u + ((u64)pco << 3));
-        do {
-          const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 ofs = q.z; const u32 raw = q.w;
-          const u32 uop = w0 & 0xff, ld = (w0 >> 8) & 31;
-          const u32 size = 2u + ((w0 >> 27) & 2u);
-          const u32 spc = pco + size;
-          const QT qn = *(CQ)(recs_u + ((u64)spc << 3));              // next sequential record: in flight during this step
-          const u64 a = XR((ofs >> 3) & 63), b2 = XR((ofs >> 19) & 63);
-          const u64 simm = (u64)(i64)imm, bi = b2 + simm;
-          u32 npc = spc;
-          u64 tr_k = 1ULL << 60, tr_v = 0;
-          // every case leaves its result in (wl, wv): one register-file write site after the chain (wl = 0: the sink lane)
-          u32 wl = 0; u64 wv = 0;
-#define SWX(val) do { wv = (val); wl = ld; } while (0)
-          if (uop == OP_ADD) SWX(a + bi);
-          else if (uop >= OP_LB && uop <= OP_LWU) {
-            const u32 k = uop - OP_LB, sz = 1u << (k & 3);
-            const u64 va = a + simm, off = va - mbase;
-            if ((va & (sz - 1)) || off > msize - sz || va == tohost) nc = true;
-            else {
-              const u8* p = arena_u + off;
-              u64 v;
-              if (k == 2) v = (u64)(i64)*(const i32*)p; else if (k == 3) v = *(const u64*)p;
-              else if (k == 6) v = *(const u32*)p; else if (k == 4) v = *p; else if (k == 0) v = (u64)(i64)*(const int8_t*)p;
-              else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;
-              SWX(RFL64(v));
-            }
-          } else if (uop >= OP_BEQ && uop <= OP_BGEU) {
-            const u32 m = uop - OP_BEQ;
-            const bool c = m < 2 ? a == b2 : m < 4 ? (i64)a < (i64)b2 : a < b2;
-            if (c != (bool)(m & 1)) {
-              const u32 t = pco + (u32)imm;
-              if (!zca || t >= text_len) nc = true; else npc = t & ~1u;
-            }
-          } else if (uop == OP_ADDW) SWX((u64)(i64)(i32)((u32)a + (u32)bi));
-          else if (uop == OP_MULW) SWX((u64)(i64)(i32)((u32)a * (u32)bi));
-          else if (uop == OP_SLL) SWX(a << (bi & 63));
-          else if (uop == OP_SRL) SWX(a >> (bi & 63));
-          else if (uop >= OP_SB && uop <= OP_SD) {
-            const u32 k = uop - OP_SB, sz = 1u << k;
-            const u64 va = a + simm, off = va - mbase;
-            if ((va & (sz - 1)) || off > msize - sz || va == tohost || va == tohost + 4 || (va + sz > tlo && va < thi)) nc = true;
-            else {
-              u8* p = arena_u + off;
-              const u64 sv = k == 3 ? b2 : (b2 & ((1ULL << (8 * sz)) - 1));
-              if (k == 2) *(u32*)p = (u32)sv; else if (k == 3) *(u64*)p = sv; else if (k == 0) *p = (u8)sv; else *(u16*)p = (u16)sv;
-              if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }
-            }
-          } else if (uop == OP_AND) SWX(a & bi);
-          else if (uop == OP_MUL) SWX(a * bi);
-          else if (uop == OP_JAL || uop == OP_JALR) {
-            const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((a + simm) & ~1ULL) - tlo);
-            if (!zca || t >= (u64)text_len) nc = true;
-            else { SWX(tlo + pco + size); npc = (u32)t & ~1u; }
-          } else switch (uop) {
-            case OP_SUB: SWX(a - bi); break;
-            case OP_SLT: SWX((u64)((i64)a < (i64)bi)); break;
-            case OP_SLTU: SWX((u64)(a < bi)); break;
-            case OP_XOR: SWX(a ^ bi); break;
-            case OP_SRA: SWX((u64)((i64)a >> (bi & 63))); break;
-            case OP_OR: SWX(a | bi); break;
-            case OP_SUBW: SWX((u64)(i64)(i32)((u32)a - (u32)bi)); break;
-            case OP_SLLW: SWX((u64)(i64)(i32)((u32)a << (bi & 31))); break;
-            case OP_SRLW: SWX((u64)(i64)(i32)((u32)a >> (bi & 31))); break;
-            case OP_SRAW: SWX((u64)(i64)((i32)a >> (bi & 31))); break;
-            case OP_AUIPC: SWX(tlo + pco + simm); break;
-            case OP_NOP: break;
-            default: nc = true; break;                    // not in the inline subset
-          }
-#undef SWX
-          XW(wl, wv);
-          if (TRACE && wl) { tr_k = (u64)wl ^ (1ULL << 60); tr_v = wv; }
-          // keep all four destination registers of the in-flight record load reserved until here: a register of the
-          // tuple that is reused early forces a wait for the whole load right after it was issued
-          asm volatile("" :: "s"(qn.x), "s"(qn.y), "s"(qn.z), "s"(qn.w));
-          if (nc) break;
-          if (TRACE) {
-            u64 t = u_thash;
-            t = fold(t, tlo + pco);
-            t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
-            t = fold(t, tr_k); t = fold(t, tr_v);
-            u_thash = t;
-          }
-          q = qn;
-          if (npc != spc) q = *(CQ)(recs_u + ((u64)npc << 3));
-          pco = npc;
-          ++it;
-        } while (it < n);
-        u_exec += it;
-        u_pc = tlo + pco;
-        if (!nc) continue;
-      }
-      // ---- one general (or warm) step: registers to LDS, lane 0 runs the out-of-line path, registers back
-      // (the register file crosses lanes through LDS: workgroup barriers order the accesses; one wave per workgroup)
-      if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
-      __syncthreads();
-      HotRegs hr; hr.pc = u_pc; hr.exec = u_exec; hr.thash = u_thash; hr.stop_at = u_stop; hr.flags = u_flags; hr.status = u_status; hr.fcsr = u_fcsr;
-      if (lane == 0) {
-        bool done = false;
-        if (FP && (u_flags & (HF_HOT | HF_FS_DIRTY)) == (HF_HOT | HF_FS_DIRTY) && u_pc - tlo < thi - tlo) {
-          const wsp_u32x4 q = *(const wsp_u32x4*)(recs_u + (((u_pc - tlo) >> 1) << 4));
-          const u32 op = q.x & 0xff;
-          if (op >= OP_FADD && op <= OP_FMV_X2F) {
-            const WarmRet w = wsp_warm<TRACE>(d.isa, 0, WSP_XSLOTS * 8, q.x, (i32)q.y, q.w, u_pc, u_thash, u_fcsr);
-            if (w.handled) { hr.pc = u_pc + ((q.x & F_SIZE4) ? 4 : 2); hr.exec = u_exec + 1; hr.thash = w.thash; hr.fcsr = w.fcsr; done = true; }
-          }
-        }
-        if (!done) hr = wsp_cold<TRACE>(dp, blockIdx.x, 0, hr);
-      }
-      u_pc = RFL64(hr.pc); u_exec = RFL64(hr.exec); u_thash = RFL64(hr.thash); u_flags = RFL(hr.flags); u_status = RFL(hr.status); u_fcsr = RFL(hr.fcsr);
-      __syncthreads();
-      if (lane <= 32) { const u64 v = L.m.xs[lane]; xlo = (u32)v; xhi = (u32)(v >> 32); }
-      {                                                    // the general step may have changed nothing else that the loop caches
-        const u32 pg = d.prog[blockIdx.x * 64];
-        if (pg != ~0u) { const ProgDev pd = d.progs[pg]; tlo = RFL64(pd.text_lo); thi = RFL64(pd.text_hi); }
-        tohost = RFL64(d.tohost[blockIdx.x * 64]);
-      }
-    }
-    if (lane <= 32) L.m.xs[lane] = (u64)xlo | ((u64)xhi << 32);
-    __syncthreads();
-    L.h.pc = u_pc; L.h.exec = u_exec; L.h.thash = u_thash; L.h.flags = u_flags; L.h.fcsr = u_fcsr; L.h.status = active ? u_status : (u32)ST_STOP_LIMIT;
-#undef XR
-#undef XW
-#undef RFL64
-#undef RFL
-  } else
   // Outer loop: { hot inner loop (no calls) ; one general step for the lanes that asked for it }.
   //
   // Hot inner loop.  Entered only when every running lane of the wave is hot (HF_HOT) with its pc inside its pre-decoded
@@ -424,7 +283,171 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     if (!__any(need_cold)) {
       const u64 left = stop_at - L.h.exec;
       const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu));
-      if (can) {
+      if (WSP_CONVERGED_LOOP && same_prog) {
+        // ============================================================================================================
+        // Converged loop (all harts of the wave share one program image).  One pc - `upc`, an SGPR - is scheduled per
+        // iteration: the record comes through the scalar cache and is decoded on the scalar unit (op, register offsets,
+        // immediate, size all wave-uniform), and exactly the lanes whose own pc `vpc` equals `upc` execute it, together,
+        // on the vector unit.  Lanes at other pcs wait; a lane whose pc becomes `upc` joins by itself (the membership
+        // test is one compare per iteration).  After a control transfer the next `upc` is the minimum pc over all
+        // eligible lanes, so that lanes which left a loop or a branch arm early wait at the join point for the others
+        // (min-pc reconvergence); after any other instruction it is simply the sequential successor.  Every iteration
+        // executes at least one lane (upc is always some eligible lane's pc), nothing inside can stop a hart, and the trip
+        // count is bounded by the smallest remaining budget, so the loop ends.
+        typedef wsp_u32x4 SQ;
+        typedef const __attribute__((address_space(4))) SQ* SQP;            // constant address space: scalar loads
+        const ProgDev pd = d.progs[pg0];
+        const u64 tlo = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)pd.text_lo) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(pd.text_lo >> 32)) << 32);
+        const u64 thi = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)pd.text_hi) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(pd.text_hi >> 32)) << 32);
+        const u64 recs_a = (u64)(size_t)pd.recs;
+        const char* const recs_u = (const char*)(size_t)((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)recs_a) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(recs_a >> 32)) << 32));
+        const u32 tlen = (u32)(thi - tlo);
+        const u64 tohost = L.tohost, mbase = d.mem_base, msize = d.mem_size;
+        const u32 xb = (u32)(size_t)((char*)L.m.xs - (char*)wsp_lds);      // byte offset of this lane's x block
+        const char* const ldsb = (const char*)wsp_lds;
+        u64* const sinkx = (u64*)(ldsb + xb);
+        const u32 foff = d.lpw * (WSP_XSLOTS * 8);
+        const bool fsd = (L.h.flags & HF_FS_DIRTY) != 0, boxd = (d.isa & ISA_D) != 0;
+        u8* const gsink = (u8*)(d.cold + (size_t)CI_COUNT * S + (blockIdx.x * 64 + ln_of(d)));
+        u32 vpc = can ? (u32)off64 : 0xffffffffu;          // lanes that take no part never match a scheduled pc
+        u32 vit = 0, ncv = 0, left_it = n;
+        u32 upc = wave_min_dpp(vpc);
+        SQ q = *(SQP)(recs_u + ((u64)upc << 3));
+        do {
+          // operand reads first (every lane reads its own block: lanes outside the group discard the values), the rest of
+          // the decode runs on the scalar unit while they are in flight
+          const u32 ofs = q.z;
+          u64 a = *(const u64*)(ldsb + (xb + (ofs & 0xffffu)));
+          u64 b2 = *(const u64*)(ldsb + (xb + (ofs >> 16)));
+          const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 raw = q.w;
+          const u32 op = w0 & 0xff;
+          const u32 size = 2u + ((w0 >> 27) & 2u);
+          const u32 spc = upc + size;
+          const u64 simm = (u64)(i64)imm;
+          // The operands must have arrived before the next record is requested: LDS and scalar loads share one counter
+          // (lgkmcnt) and scalar loads return out of order, so a record load issued earlier would be waited for right
+          // here.  Issued now it is in flight for the rest of the step and is first needed at the top of the next one.
+          // (The address of the record load is made to depend on an operand that has arrived: a zero derived from it.)
+          asm volatile("" : "+v"(a), "+v"(b2));
+          u32 zero;
+          asm volatile("s_and_b32 %0, %1, 0" : "=s"(zero) : "s"(__builtin_amdgcn_readfirstlane((int)(u32)a)) : "scc");
+          zero = (u32)__builtin_amdgcn_readfirstlane((int)zero);   // (an asm result counts as divergent: say that it is not)
+          const SQ qn = *(SQP)(recs_u + ((u64)(spc + zero) << 3));
+          if (vpc == upc) {
+            u64* const rdp = (u64*)(ldsb + (xb + ((w0 >> 5) & 0xf8u)));
+            const u64 bi = b2 + simm;
+            u32 npc = spc; bool bad = false;
+            u64 tr_k = 1ULL << 60, tr_v = 0;
+            const bool rd_nz = (w0 & 0x1f00u) != 0;
+            const u64 rd_key = rd_nz ? ((u64)((w0 >> 8) & 31) ^ (1ULL << 60)) : (1ULL << 60);
+#define WSP_CW(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? v_ : 0; } } while (0)
+#define WSP_BAD(cond) do { bad = (cond); } while (0)
+            if (op == OP_ADD) WSP_CW(a + bi);
+            else if (op >= OP_LB && op <= OP_LWU) {
+              const u32 k = op - OP_LB, sz = 1u << (k & 3);
+              const u64 va = a + simm, off = va - mbase;
+              const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);
+              const u8* p = L.m.p(ok ? off : 0);
+              u64 v;
+              if (k == 2) v = (u64)(i64)*(const i32*)p; else if (k == 3) v = *(const u64*)p;
+              else if (k == 6) v = *(const u32*)p; else if (k == 4) v = *p; else if (k == 0) v = (u64)(i64)*(const int8_t*)p;
+              else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;
+              *(ok ? rdp : sinkx) = v;
+              WSP_BAD(!ok);
+              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? v : 0; }
+            } else if (op >= OP_BEQ && op <= OP_BGEU) {
+              const u32 m = op - OP_BEQ;
+              const bool c = m < 2 ? a == b2 : m < 4 ? (i64)a < (i64)b2 : a < b2;
+              const bool take = c != (bool)(m & 1);
+              const u32 t = upc + (u32)imm;
+              const bool ok = zca & (t < tlen);          // wave-uniform
+              npc = take ? (t & ~1u) : spc;
+              if (!ok) WSP_BAD(take);
+            } else if (op == OP_ADDW) WSP_CW((u64)(i64)(i32)((u32)a + (u32)bi));
+            else if (op == OP_MULW) WSP_CW((u64)(i64)(i32)((u32)a * (u32)bi));
+            else if (op == OP_SLL) WSP_CW(a << (bi & 63));
+            else if (op == OP_SRL) WSP_CW(a >> (bi & 63));
+            else if (op >= OP_SB && op <= OP_SD) {
+              const u32 k = op - OP_SB, sz = 1u << k;
+              const u64 va = a + simm, off = va - mbase;
+              const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost) & (va != tohost + 4) &
+                              !((va + sz > tlo) & (va < thi));
+              u8* p = ok ? L.m.p(off) : gsink;
+              const u64 sv = k == 3 ? b2 : (b2 & ((1ULL << (8 * sz)) - 1));
+              if (k == 2) *(u32*)p = (u32)sv; else if (k == 3) *(u64*)p = sv; else if (k == 0) *p = (u8)sv; else *(u16*)p = (u16)sv;
+              WSP_BAD(!ok);
+              if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }
+            } else if (op == OP_AND) WSP_CW(a & bi);
+            else if (op == OP_MUL) WSP_CW(a * bi);
+            else if (FP && op >= OP_FLW && op <= OP_FSD) {
+              const bool st = op >= OP_FSW, dw = (op & 1u) == (OP_FLD & 1u);
+              const u32 sz = dw ? 8u : 4u;
+              const u64 va = a + simm, off = va - mbase;
+              bool ok = fsd & ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);
+              if (st) {
+                ok = ok & (va != tohost + 4) & !((va + sz > tlo) & (va < thi));
+                const u64 fv = *(const u64*)(ldsb + (xb + foff + ((w0 >> 15) & 0xf8u)));
+                u8* p = ok ? L.m.p(off) : gsink;
+                const u64 sv = dw ? fv : (fv & 0xffffffffULL);
+                if (dw) *(u64*)p = sv; else *(u32*)p = (u32)sv;
+                if (TRACE) { tr_k = va ^ (4ULL << 60); tr_v = sv; }
+              } else {
+                const u8* p = L.m.p(ok ? off : 0);
+                u64 v;
+                if (dw) v = *(const u64*)p; else v = (u64)*(const u32*)p | (boxd ? 0xffffffff00000000ULL : 0);
+                *(u64*)(ldsb + (ok ? (xb + foff + ((w0 >> 5) & 0xf8u)) : xb)) = v;
+                if (TRACE) { tr_k = (u64)((w0 >> 8) & 31) ^ (2ULL << 60); tr_v = v; }
+              }
+              WSP_BAD(!ok);
+            } else if (op == OP_JAL || op == OP_JALR) {
+              const u64 t = op == OP_JAL ? (u64)(upc + (u32)imm) : (((a + simm) & ~1ULL) - tlo);
+              const bool ok = zca & (t < (u64)tlen);
+              const u64 link = tlo + upc + size;
+              *(ok ? rdp : sinkx) = link;
+              npc = (u32)t & ~1u;
+              WSP_BAD(!ok);
+              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? link : 0; }
+            } else switch (op) {
+              case OP_SUB: WSP_CW(a - bi); break;
+              case OP_SLT: WSP_CW((u64)((i64)a < (i64)bi)); break;
+              case OP_SLTU: WSP_CW((u64)(a < bi)); break;
+              case OP_XOR: WSP_CW(a ^ bi); break;
+              case OP_SRA: WSP_CW((u64)((i64)a >> (bi & 63))); break;
+              case OP_OR: WSP_CW(a | bi); break;
+              case OP_SUBW: WSP_CW((u64)(i64)(i32)((u32)a - (u32)bi)); break;
+              case OP_SLLW: WSP_CW((u64)(i64)(i32)((u32)a << (bi & 31))); break;
+              case OP_SRLW: WSP_CW((u64)(i64)(i32)((u32)a >> (bi & 31))); break;
+              case OP_SRAW: WSP_CW((u64)(i64)((i32)a >> (bi & 31))); break;
+              case OP_AUIPC: WSP_CW(tlo + upc + simm); break;
+              case OP_NOP: break;
+              default: bad = true; break;                 // not in the inline subset
+            }
+#undef WSP_CW
+#undef WSP_BAD
+            if (TRACE && !bad) {
+              u64 t = L.h.thash;
+              t = fold(t, tlo + upc);
+              t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
+              t = fold(t, tr_k); t = fold(t, tr_v);
+              L.h.thash = t;
+            }
+            vpc = bad ? vpc : npc;                        // a lane that needs the general step changed nothing and stays put
+            vit += bad ? 0u : 1u;
+            ncv = bad ? 1u : 0u;
+          }
+          if (__any(ncv != 0)) break;                     // (a ballot taken inside the group's branch would not be uniform out here)
+          u32 nupc = spc;
+          if (op >= OP_JAL && op <= OP_BGEU) {            // control transfer: schedule the minimum pc
+            nupc = wave_min_dpp(vpc);
+            if (!__any(vpc == nupc)) nupc = (u32)__builtin_amdgcn_readlane((int)vpc, __ffsll((long long)__ballot(can)) - 1);   // cannot happen; guards the loop's progress
+          }
+          q = qn;
+          if (nupc != spc) q = *(SQP)(recs_u + ((u64)nupc << 3));
+          upc = nupc;
+        } while (--left_it);
+        if (can) { L.h.exec += vit; L.h.pc = tlo + vpc; }
+        need_cold = ncv != 0;
+      } else if (can) {
         u32 pco = (u32)off64, it = 0;
         u32 ncv = 0;                                      // "needs the general step", as a VGPR flag (no lane-mask algebra)
         const u32 xb = (u32)(size_t)((char*)L.m.xs - (char*)wsp_lds);      // byte offset of this lane's x block
@@ -929,11 +952,12 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   HIPOK(hipSetDevice(dev));
   u32 lpw = desc->lanes_per_wave;
   if (lpw == 0) {
-    // The step kernel is issue/latency bound per wave and runs 4 waves per SIMD: the chip holds 256 CUs x 4 SIMDs x 4 =
-    // 4096 resident waves.  Harts of one wave only share work while they execute the same op, so the fewest lanes per
-    // wave that still fit the batch in one resident set are the fastest (4096 harts: lpw 1/2/4/8 -> 8.1/4.8/3.6/3.1 GIPS).
+    // One wave's step takes about the same time however many of its lanes carry harts (harts of one program execute
+    // together in the converged loop), and one wave per SIMD already hides most of what can be hidden: the fewest waves that
+    // still give every SIMD one - 1024 - is the fastest layout measured (profiles/r02/: 4096 harts lpw 1/2/4/8 -> 9.5 / 11.9 /
+    // 13.5 / 13.7 GIPS, 16384 harts lpw 4/16/64 -> 36 / 55 / 57, 65536 harts lpw 16/64 -> 140 / 207).
     lpw = 1;
-    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 4096) lpw <<= 1;
+    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 1024) lpw <<= 1;
   }
   if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
   wsp_batch* b = new wsp_batch();
