@@ -31,7 +31,8 @@ enum { WSP_ST_RUNNING = 0,
        WSP_ST_STOP_TOHOST = 1,      /* store to tohost, bit 0 set (Hart.cpp:2665); success iff (value>>1)==0 (printTrace.cpp:943) */
        WSP_ST_STOP_ILLEGAL = 2,     /* >16 consecutive illegal/no-di exceptions (Hart.cpp:3329-3340), value 3 */
        WSP_ST_STOP_LIMIT = 3,       /* instruction-count limit reached (Hart.cpp:6025, setInstructionCountLimit) */
-       WSP_ST_STOP_UNSUPPORTED = 4  /* left the modelled subset; stop_value holds the reason */ };
+       WSP_ST_STOP_UNSUPPORTED = 4, /* left the modelled subset; stop_value holds the reason */
+       WSP_ST_STOP_ADDR = 5         /* pc reached the stop address before executing it (Hart.cpp:6025, 6230) */ };
 
 /* Resources for peek/poke (Hart::peekIntReg/pokeIntReg ... Hart.hpp:219-325, Hart.cpp:1345-1560). */
 enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4, WSP_RES_V = 5 /* whole vector register, vlen_bytes bytes */ };
@@ -42,18 +43,36 @@ enum { WSP_RUN_TRACE_HASH = 1 /* fold every commit record (printTrace.cpp:302-51
 enum { WSP_LOAD_EXEC = 1 /* bytes are code: pre-decode them */ };
 
 typedef struct {
-  uint32_t xlen;            /* 64 (32 is reserved)                                        */
+  uint32_t xlen;            /* 64, or 0 = from config_json / the ISA string (HartConfig::getXlen, HartConfig.cpp:3431) */
   uint32_t n_harts;         /* number of independent single-hart systems                                   */
-  const char* isa;          /* e.g. "rv64imafdc_zicsr" (Hart::configIsa, Hart.cpp:5122; Isa.cpp:561)       */
+  const char* isa;          /* e.g. "rv64imafdc_zicsr" (Hart::configIsa, Hart.cpp:5122; Isa.cpp:561); NULL = config tag "isa" */
   uint64_t mem_base;        /* arena base; accesses outside the arena take access faults (PMA no-access)   */
-  uint64_t mem_size;        /* bytes per hart, multiple of 4096 (System ctor memSize, System.cpp:50)       */
+  uint64_t mem_size;        /* bytes per hart, multiple of 4096 (System ctor memSize, System.cpp:50); 0 = config tag memmap.size */
   uint32_t lanes_per_wave;  /* 0 = auto; else a power of two <= 64: harts per 64-lane wavefront           */
   int32_t  device;          /* HIP device ordinal, -1 = current                                            */
   uint32_t hart_id_base;    /* mhartid of hart 0 (core_hart_id_offset)                                     */
   uint32_t tlb_entries;     /* TLB entries per hart, a power of two; 0 = 2048 (Hart.cpp:106; config tag tlb_entries) */
   uint32_t vlen_bytes;      /* bytes per vector register: 16, 32 or 64; 0 = 64 (Hart.cpp:1081; config tag vector.bytes_per_vec) */
   uint32_t reserved;
+  const char* config_json;  /* text of a Whisper JSON configuration file, or NULL (HartConfig::loadConfigFile + applyConfig,
+                               HartConfig.cpp:61, 2085).  Tags that change what a hart executes are honoured; tags the device does
+                               not model are rejected with WSP_EUNSUPPORTED, never ignored; non-zero descriptor fields override the
+                               file (as command-line options do, Session.cpp:1373-1424).  See wsp_config_parse. */
 } wsp_batch_desc;
+
+/* What a configuration file asks for, as wsp_batch_create understands it (diagnostic / test surface: the same parser).
+ * features: bit 16 enable_misaligned_data = false, 17 clear_mtval_on_illegal_instruction, 18 clear_mtval_on_ebreak,
+ * 19 cancel_lr_on_trap, 20 clear_mprv_on_ret = false, 21 address_translation_modes without sv39. */
+typedef struct {
+  uint32_t xlen, features;
+  uint64_t mem_size, reset_pc;
+  uint32_t has_reset_pc, tlb_entries, vlen_bytes, abi_names, n_csr_resets, reserved;
+  uint32_t csr_num[32]; uint64_t csr_value[32];
+  char isa[256];
+} wsp_config_info;
+/* HartConfig::loadConfigFile + applyConfig (HartConfig.cpp:61, 2085) on a text: 0, or WSP_EFORMAT (not JSON), WSP_EINVAL (a value
+ * of the wrong kind), WSP_EUNSUPPORTED (a tag the device does not model; wsp_last_error names it). */
+int  wsp_config_parse(const char* json_text, wsp_config_info* out);
 
 typedef struct {
   uint32_t status;          /* WSP_ST_*                                                                    */
@@ -94,9 +113,12 @@ int  wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_t idx, voi
  * [hart_lo, hart_hi) (per-instance seeds); vals has hart_hi-hart_lo entries. */
 int  wsp_batch_poke_each(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint32_t res, uint64_t idx, const uint64_t* vals);
 
-/* Hart::setToHostAddress (Hart.cpp:1626) + setInstructionCountLimit (Hart.hpp:1385).
- * tohost = UINT64_MAX leaves/clears it; max_inst = UINT64_MAX means no limit. */
-int  wsp_batch_set_stop(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t tohost, uint64_t max_inst);
+/* Hart::setToHostAddress (Hart.cpp:1626) + setInstructionCountLimit / setRetiredInstructionCountLimit (Hart.hpp:1385) + the stop
+ * address of Hart::untilAddress / setStopAddress (Hart.cpp:6003, 6025-6026, 6256): the loop condition
+ * `pc != stop_pc and executed < max_inst and retired < max_ret`.  tohost = UINT64_MAX leaves it as it is; max_inst / max_ret =
+ * UINT64_MAX mean no limit; stop_pc = UINT64_MAX means none.  Limits end a hart with WSP_ST_STOP_LIMIT, the address with
+ * WSP_ST_STOP_ADDR (the instruction at stop_pc is not executed). */
+int  wsp_batch_set_stop(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t tohost, uint64_t max_inst, uint64_t max_ret, uint64_t stop_pc);
 
 /* System::batchRun / Hart::run (System.cpp:1654, Hart.cpp:6963): step every running hart until it
  * stops or has executed max_steps more instructions. Returns the number of harts still running

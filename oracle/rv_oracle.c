@@ -167,6 +167,7 @@ struct rvo_hart {
   u64 stvec, scounteren, senvcfg, sscratch, sepc, scause, stval, satp;
   u64 fcsr;
   u64 cycle, instret, time_;
+  u64 max_ret, stop_pc; int stop_pc_valid;   /* retCountLim_, untilAddress' address */
   /* run bookkeeping (Hart.hpp:6707-6717) */
   u64 exec_count, retire_count;
   u64 exec_last_ill, consec_ill;
@@ -209,6 +210,7 @@ rvo_hart* rvo_create(const rvo_config* cfg)
   h->tlb_n = cfg->tlb_entries ? cfg->tlb_entries : 2048;
   if (h->tlb_n & (h->tlb_n - 1)) { free(h->mem); free(h); return NULL; }   /* Tlb.cpp:11 */
   h->tlb = (struct rvo_tlbe*)calloc(h->tlb_n, sizeof(struct rvo_tlbe));
+  h->max_ret = ~0ULL;
   return h;
 }
 
@@ -553,6 +555,7 @@ static void take_exception_ex(rvo_hart* h, unsigned cause, u64 epc, u64 tval, in
     h->exec_last_ill = h->exec_count;
   }
   h->has_exc = 1;
+  if (ext(h, RVO_CFG_CANCEL_LR_TRAP)) h->lr_valid = 0;        /* cancelLrOnTrap_ (Hart.cpp:3570-3571) */
 
   unsigned next = PRV_M;
   if (ext(h, RVO_ISA_S) && h->priv != PRV_M && ((h->medeleg >> cause) & 1)) next = PRV_S;
@@ -607,6 +610,7 @@ static int interrupt_possible(const rvo_hart* h, unsigned* cause, unsigned* next
 static void take_interrupt(rvo_hart* h, unsigned cause, unsigned next, u64 epc)
 {
   unsigned orig = h->priv;
+  if (ext(h, RVO_CFG_CANCEL_LR_TRAP)) h->lr_valid = 0;        /* Hart.cpp:3570-3571 */
   h->priv = next;
   u64 cv = (1ULL << 63) | cause, tvec;
   if (next == PRV_M) {
@@ -634,7 +638,7 @@ static void take_interrupt(rvo_hart* h, unsigned cause, unsigned next, u64 epc)
 static void take_exception(rvo_hart* h, unsigned cause, u64 epc, u64 tval) { take_exception_ex(h, cause, epc, tval, 1); }
 /* load/store/AMO faults pass their DecodedInst (Hart.cpp:1972-1983): heuristic untouched. */
 static void ldst_exception(rvo_hart* h, unsigned cause, u64 tval) { take_exception_ex(h, cause, h->curr_pc, tval, 0); }
-static void illegal(rvo_hart* h, u32 inst) { take_exception(h, 2, h->curr_pc, inst); }
+static void illegal(rvo_hart* h, u32 inst) { take_exception(h, 2, h->curr_pc, ext(h, RVO_CFG_CLR_MTVAL_ILL) ? 0 : inst); }   /* clearMtvalOnIllInst_ (Hart.cpp:3256) */
 
 /* ------------------------------------------------------------------ memory access checks */
 /* PMP with no programmed entries: M-mode allowed, S/U denied (PmpManager.hpp:155-177). */
@@ -814,6 +818,7 @@ static unsigned ldst_addr(rvo_hart* h, u64 va, unsigned size, unsigned need, u64
   const u64 va2 = misal ? ((va + size - 1) & ~mask) : va;
   unsigned c;
   *pa1 = va;
+  if (misal && ext(h, RVO_CFG_NO_MISAL)) { *tval = va; return need == 1 ? 4 : 6; }   /* misalHasPriority_ and not misalDataOk_ (Hart.cpp:2013-2016, 13810-13813) */
   if (tr && (c = translate(h, va, pm, need, pa1)) != 0) { *tval = va; return c; }
   if (!misal) {
     if (!pmp_ok(h, pm, *pa1, need) || !in_mem(h, *pa1, size)) { *tval = va; return af; }
@@ -1020,6 +1025,7 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   wx(h, rd, prev);
   if (num == C_SATP) {
     unsigned mode = (unsigned)(next >> 60);
+    if (mode == 8 && ext(h, RVO_CFG_NO_SV39)) goto done;   /* configAddressTranslationModes without sv39 */
     if (mode != 0 && mode != 8 && mode != 9 && mode != 10) goto done;  /* unsupported MODE: dropped (13284-13294) */
     if (mode > 8) { stop(h, RVO_STOP_UNSUPPORTED, 0x180); return; }   /* Sv48 / Sv57: not modelled */
   }
@@ -1259,7 +1265,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
       if (f3 == 0) {
         if (rd != 0) break;
         if (inst == 0x00000073) { take_exception(h, h->priv == PRV_M ? 11 : h->priv == PRV_S ? 9 : 8, h->curr_pc, 0); return; }
-        if (inst == 0x00100073) { take_exception(h, 3, h->curr_pc, h->curr_pc); return; }      /* Hart.cpp:12094-12101 */
+        if (inst == 0x00100073) { take_exception(h, 3, h->curr_pc, ext(h, RVO_CFG_CLR_MTVAL_EBREAK) ? 0 : h->curr_pc); return; }      /* Hart.cpp:12094-12101 */
         if (inst == 0x30200073) {                                                              /* mret: Hart.cpp:12247-12336 */
           if (h->priv < PRV_M) goto ill;
           u64 v = h->mstatus; unsigned saved = (v >> MST_MPP_SH) & 3;
@@ -1267,7 +1273,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
           unsigned least = ext(h, RVO_ISA_U) ? PRV_U : ext(h, RVO_ISA_S) ? PRV_S : PRV_M;
           v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)least << MST_MPP_SH);
           v |= MST_MPIE;
-          if (saved != PRV_M) v &= ~MST_MPRV;
+          if (saved != PRV_M && !ext(h, RVO_CFG_KEEP_MPRV)) v &= ~MST_MPRV;   /* clearMprvOnRet_ (Hart.cpp:12283) */
           csr_store(h, C_MSTATUS, v, 1);
           h->pc = h->mepc & epc_rmask(h); h->priv = saved; return;      /* readSignExtend(MEPC) applies the read mask */
         }
@@ -1279,7 +1285,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
           v = (v & ~MST_SIE) | ((v & MST_SPIE) ? MST_SIE : 0);
           v = ext(h, RVO_ISA_U) ? (v & ~MST_SPP) : (v | MST_SPP);
           v |= MST_SPIE;
-          v &= ~MST_MPRV;                                    /* savedMode is never M for sret */
+          if (!ext(h, RVO_CFG_KEEP_MPRV)) v &= ~MST_MPRV;    /* savedMode is never M for sret (Hart.cpp:12499) */
           h->mstatus = legalize_mstatus(h, v); record_csr(h, C_SSTATUS);
           h->pc = h->sepc & epc_rmask(h); h->priv = saved; return;
         }
@@ -1327,6 +1333,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
     /* determineLoadException first (a translation fault wins), then the alignment / reservability check; either way
      * the trap value is the LR's own address (amo.cpp:203-207) */
     unsigned c = ldst_addr(h, va, size, 1, &pa1, &pa2, &tval);
+    if (c == 4) c = 5;                                      /* misalAtomicCauseAccessFault_ (amo.cpp:180-181) */
     if (c == 0 && (va & (size - 1))) c = 5;
     if (c) { ldst_exception(h, c, va); return; }
     u64 v = ld_le(h->mem + (pa1 - h->cfg.mem_base), size);
@@ -1575,11 +1582,14 @@ static u32 read_inst_for_log(rvo_hart* h, u64 va)
   return iw;
 }
 
+void rvo_set_stop(rvo_hart* h, u64 max_ret, int stop_pc_valid, u64 stop_pc) { h->max_ret = max_ret; h->stop_pc_valid = stop_pc_valid; h->stop_pc = stop_pc; }
+
 int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)
 {
   if (n) *n = 0;
   while (h->status == RVO_RUNNING) {
-    if (h->exec_count >= max_exec) { h->status = RVO_STOP_LIMIT; break; }
+    if (h->exec_count >= max_exec || h->retire_count >= h->max_ret) { h->status = RVO_STOP_LIMIT; break; }   /* Hart.cpp:6025-6026, 6224 */
+    if (h->stop_pc_valid && h->pc == h->stop_pc) { h->status = RVO_STOP_ADDR; break; }                         /* Hart.cpp:6025, 6230 */
     begin_inst(h);
     h->time_++;                                              /* tickTime, timeDownSample_=0, 1 hart (Hart.hpp:3101) */
     h->curr_pc = h->pc;

@@ -25,7 +25,14 @@ extern "C" {
 enum {
   RVO_ISA_M = 1 << 0, RVO_ISA_A = 1 << 1, RVO_ISA_F = 1 << 2, RVO_ISA_D = 1 << 3,
   RVO_ISA_C = 1 << 4, RVO_ISA_S = 1 << 5, RVO_ISA_U = 1 << 6, RVO_ISA_V = 1 << 7,
-  RVO_ISA_ZICNTR = 1 << 8
+  RVO_ISA_ZICNTR = 1 << 8,
+  /* configuration switches (HartConfig::applyConfig tags, HartConfig.cpp:2085-2958); all clear = the reference's defaults */
+  RVO_CFG_NO_MISAL = 1 << 16,          /* enable_misaligned_data = false */
+  RVO_CFG_CLR_MTVAL_ILL = 1 << 17,     /* clear_mtval_on_illegal_instruction */
+  RVO_CFG_CLR_MTVAL_EBREAK = 1 << 18,  /* clear_mtval_on_ebreak */
+  RVO_CFG_CANCEL_LR_TRAP = 1 << 19,    /* cancel_lr_on_trap */
+  RVO_CFG_KEEP_MPRV = 1 << 20,         /* clear_mprv_on_ret = false */
+  RVO_CFG_NO_SV39 = 1 << 21            /* address_translation_modes without sv39 */
 };
 
 /* Stop reasons (mirror include/whisper_amd.h WSP_ST_*). */
@@ -34,7 +41,8 @@ enum {
   RVO_STOP_TOHOST = 1,     /* store to tohost with bit0 set; value = HTIF word (Hart.cpp:2665)      */
   RVO_STOP_ILLEGAL = 2,    /* >16 consecutive no-di exceptions (Hart.cpp:3329-3340); value = 3      */
   RVO_STOP_LIMIT = 3,      /* execCount reached the instruction limit (Hart.cpp:6025)               */
-  RVO_STOP_UNSUPPORTED = 4 /* outside the modelled subset; value = reason code                      */
+  RVO_STOP_UNSUPPORTED = 4,/* outside the modelled subset; value = reason code                      */
+  RVO_STOP_ADDR = 5        /* pc reached the stop address (Hart.cpp:6025, 6230)                     */
 };
 
 /* Kinds of change in a commit record (printTrace.cpp:388-493 order r,f,v,m,c). */
@@ -100,6 +108,9 @@ void      rvo_set_vreg(rvo_hart* h, unsigned i, const void* src);
  * (Hart::setInstructionCountLimit semantics: counts trapped instructions too).  If `log` is
  * non-NULL up to `log_cap` commit records are stored and *log_n updated. Returns status. */
 int       rvo_run(rvo_hart* h, uint64_t max_exec, rvo_commit* log, size_t log_cap, size_t* log_n);
+
+/* retCountLim_ and the stop address of Hart::untilAddress (Hart.cpp:6011, 6025-6026): max_ret = UINT64_MAX for none */
+void      rvo_set_stop(rvo_hart* h, uint64_t max_ret, int stop_pc_valid, uint64_t stop_pc);
 
 int       rvo_status(const rvo_hart* h);
 uint64_t  rvo_stop_value(const rvo_hart* h);

@@ -15,7 +15,7 @@ WH_LIB = os.path.join(HERE, "_ref", "libwhisper_ref.so")
 
 ISA_BITS = dict(m=1, a=2, f=4, d=8, c=16, s=32, u=64, v=128, zicntr=256)
 
-RUNNING, STOP_TOHOST, STOP_ILLEGAL, STOP_LIMIT, STOP_UNSUPPORTED = range(5)
+RUNNING, STOP_TOHOST, STOP_ILLEGAL, STOP_LIMIT, STOP_UNSUPPORTED, STOP_ADDR = range(6)
 CH_R, CH_F, CH_V, CH_M, CH_C = 1, 2, 3, 4, 5
 MAX_CHANGES = 16
 
@@ -99,6 +99,7 @@ def lib():
             getattr(L, n).restype = C.c_uint64
             getattr(L, n).argtypes = [C.c_void_p]
         L.rvo_status.argtypes = [C.c_void_p]
+        L.rvo_set_stop.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]
         L.rvo_translate.restype = C.c_uint
         L.rvo_translate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]
         L.rvo_sfence.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_uint64]
@@ -121,9 +122,10 @@ def has_softfloat() -> bool:
 
 class Hart:
     def __init__(self, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, tohost=None,
-                 hart_id=0, reset_pc=None, tlb_entries=0, vlenb=0):
+                 hart_id=0, reset_pc=None, tlb_entries=0, vlenb=0, features=0):
+        """features: RVO_CFG_* configuration switches (same bit positions as wsp_config_info.features)."""
         self.L = lib()
-        cfg = Config(64, isa_flags(isa), mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
+        cfg = Config(64, isa_flags(isa) | features, mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
                      mem_base if reset_pc is None else reset_pc, tlb_entries, vlenb)
         self.h = self.L.rvo_create(C.byref(cfg))
         if not self.h:
@@ -134,6 +136,9 @@ class Hart:
         if getattr(self, "h", None):
             self.L.rvo_destroy(self.h)
             self.h = None
+
+    def set_stop(self, max_ret=2**64 - 1, stop_pc=None):
+        self.L.rvo_set_stop(self.h, max_ret, 0 if stop_pc is None else 1, stop_pc or 0)
 
     def write_mem(self, addr, data: bytes):
         if self.L.rvo_write_mem(self.h, addr, data, len(data)) != 0:

@@ -31,14 +31,15 @@ struct HostMem {
   void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
 };
 
-struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<u8> vreg; std::vector<Rec> recs; u64 max_exec; int use_fast = 1; };
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<u8> vreg; std::vector<Rec> recs; u64 max_exec; u64 max_ret = ~0ULL; int use_fast = 1; };
 
 template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 {
   Lane<HostMem>& L = s->L;
   L.update_hot_flag();
   while (L.h.status == ST_RUNNING) {
-    if (L.h.exec >= max_exec) { L.h.status = ST_STOP_LIMIT; break; }
+    if (L.h.exec >= max_exec || L.h.retired >= s->max_ret) { L.h.status = ST_STOP_LIMIT; break; }
+    if (L.h.pc == L.stop_pc) { L.h.status = ST_STOP_ADDR; break; }
     // same structure as the GPU kernel: hot harts try the pre-decoded fetch + inline subset first
     Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
     if (s->use_fast && (L.h.flags & HF_HOT) && L.hot_fetch(s->recs.data(), rec)) {
@@ -73,7 +74,7 @@ Sim* hs_create3(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u3
   s->L.m.cold_[CI_VTYPE] = 1ULL << 63;
   s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
   s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
-  s->max_exec = ~0ULL;
+  s->max_exec = ~0ULL; s->L.stop_pc = ~0ULL;
   return s;
 }
 Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id) { return hs_create2(isa, mem_base, mem_size, tohost, hart_id, 0); }
@@ -98,6 +99,7 @@ void hs_predecode(Sim* s, u64 addr, u64 n)
   s->L.text_lo = addr; s->L.text_hi = addr + n;
 }
 void hs_use_fast(Sim* s, int f) { s->use_fast = f; }
+void hs_set_stop(Sim* s, u64 max_ret, u64 stop_pc) { s->max_ret = max_ret; s->L.stop_pc = stop_pc; }
 void hs_set_pc(Sim* s, u64 pc) { s->L.h.pc = pc & ~1ULL; }
 void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = v; }
 u64 hs_get_x(Sim* s, u32 i) { return s->L.m.x[i & 31]; }

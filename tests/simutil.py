@@ -56,6 +56,7 @@ def shim():
         L.hs_set_f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.hs_poke_csr.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.hs_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.hs_set_stop.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         for n in ("hs_get_pc", "hs_stop_value", "hs_exec", "hs_retired", "hs_thash", "hs_state_hash", "hs_mem_hash"):
             getattr(L, n).restype = C.c_uint64
             getattr(L, n).argtypes = [C.c_void_p]
@@ -72,9 +73,12 @@ def result_tuple(status, value, pc, execn, retired, state_hash, mem_hash, trace_
                 trace_hash=trace_hash)
 
 
-def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart_id=0):
+def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart_id=0, features=0, max_ret=None, stop_pc=None):
     h = rvoracle.Hart(isa=prog.isa, mem_base=prog.mem_base, mem_size=prog.mem_size, tohost=prog.tohost, reset_pc=prog.entry,
-                      hart_id=hart_id, tlb_entries=prog.meta.get("tlb_entries", 0), vlenb=prog.meta.get("vlenb", 0))
+                      hart_id=hart_id, tlb_entries=prog.meta.get("tlb_entries", 0), vlenb=prog.meta.get("vlenb", 0),
+                      features=features or prog.meta.get("features", 0))
+    if max_ret is not None or stop_pc is not None:
+        h.set_stop(2**64 - 1 if max_ret is None else max_ret, stop_pc)
     for paddr, data, _ in prog.segments:
         h.write_mem(paddr, data)
     if seed_a0 is not None:
@@ -86,9 +90,9 @@ def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart
     return r, h, log
 
 
-def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0):
+def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0, features=0, max_ret=None, stop_pc=None):
     L = shim()
-    s = L.hs_create3(rvoracle.isa_flags(prog.isa), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
+    s = L.hs_create3(rvoracle.isa_flags(prog.isa) | (features or prog.meta.get("features", 0)), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
                      prog.meta.get("tlb_entries", 0), prog.meta.get("vlenb", 0))
     try:
         for paddr, data, _ in prog.segments:
@@ -98,6 +102,8 @@ def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True
             lo = min(p for p, _ in x); hi = max(p + n for p, n in x)
             L.hs_predecode(s, lo, hi - lo)
         L.hs_set_pc(s, prog.entry)
+        if max_ret is not None or stop_pc is not None:
+            L.hs_set_stop(s, 2**64 - 1 if max_ret is None else max_ret, 2**64 - 1 if stop_pc is None else stop_pc)
         if seed_a0 is not None:
             L.hs_set_x(s, 10, seed_a0)
         if seed_mem is not None:

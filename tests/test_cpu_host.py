@@ -413,7 +413,9 @@ allrec = (W.Result * (per * world)).from_buffer_copy(b"".join(parts))
 ok = len(parts) == world and tmax == float(world) and tot == sum(r.exec_count for r in allrec)
 mine = [(r.state_hash, r.exec_count) for r in allrec[lo:hi]] == [(r.state_hash, r.exec_count) for r in recs]
 distinct = len(set(r.state_hash for r in allrec)) == per * world
-print("RANK", rank, "OK" if ok and mine and distinct else "BAD", flush=True)
+# one write per rank: print() with several arguments writes them piece by piece, and the two ranks share one pipe
+# (that interleaving - "RANK RANK1  0OK" - was the intermittent failure of this test)
+sys.stdout.write("RANK %d %s\n" % (rank, "OK" if ok and mine and distinct else "BAD")); sys.stdout.flush()
 dist.destroy_process_group()
 """
 
@@ -424,10 +426,10 @@ def test_sharding_gather_world_size_2_gloo(tmp_path):
     assert shard.weak_range(4096, 3) == (12288, 16384)
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
-    # Cause of the launch failures seen in round 1: both ranks found the oracle library older than its sources right after an
-    # edit and rebuilt it at the same time (one rank then loaded a half-written file); the port picked here could also be taken
-    # between its release and the launcher's bind.  Builds now run under a file lock and are done once, here, before the ranks
-    # start; the launcher picks its own rendezvous port (--standalone).
+    # Causes of the failures seen in rounds 1 and 2, all removed: (a) both ranks printed their verdict with a multi-argument print()
+    # into one pipe and the pieces interleaved (found from the captured output: "RANK RANK1  0OK"); (b) both ranks could rebuild a
+    # stale oracle library at the same time: builds run under a file lock and once, here, before the ranks start; (c) the launcher
+    # picks its own rendezvous port (--standalone).
     S.rvoracle.lib()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",

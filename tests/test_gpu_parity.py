@@ -160,6 +160,19 @@ def test_sv39_programs():
     assert sum(r["status"] == W.ST_STOP_TOHOST for r in res) > 90
 
 
+@pytest.mark.parametrize("kind,lanes", [("sv39", 64), ("sv39", 2), ("pmp", 16), ("fuzz", 64)])
+def test_untraced_general_path_mixed_waves(kind, lanes):
+    """Untraced runs (the bench's mode) of programs that live on the general path, several different programs per wave: the
+    wsp_step_kernel<false, *> instantiations' divergent dispatch and cold bursts.  (Found by a sweep, not by a test: a build whose
+    general-path call passed its arguments through the stack faulted here while every traced test passed.)"""
+    gen = {"sv39": WL.sv39_program, "pmp": WL.pmp_program, "fuzz": lambda s: WL.fuzz_program(s, 300)}[kind]
+    progs = [gen(s) for s in range(200, 296)]
+    b, left, res = _run_batch(progs, lanes=lanes, trace=False)
+    b.close()
+    assert left == 0
+    _check(progs, res, trace=False)
+
+
 def test_sv39_default_tlb_and_snapshot():
     """The reference's default 2048-entry TLB, and snapshot / restore carrying the TLB."""
     progs = [WL.sv39_program(s) for s in range(16)]

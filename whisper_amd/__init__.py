@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("WSP_AMD_LIB") or os.path.join(HERE, "lib", "libwhisper_amd.so")   # WSP_AMD_LIB: A/B builds while tuning
 SRC = os.path.join(HERE, "csrc", "wsp_lib.hip")
 
-ST_RUNNING, ST_STOP_TOHOST, ST_STOP_ILLEGAL, ST_STOP_LIMIT, ST_STOP_UNSUPPORTED = range(5)
+ST_RUNNING, ST_STOP_TOHOST, ST_STOP_ILLEGAL, ST_STOP_LIMIT, ST_STOP_UNSUPPORTED, ST_STOP_ADDR = range(6)
 RES_PC, RES_X, RES_F, RES_CSR, RES_MEM, RES_V = range(6)
 RUN_TRACE_HASH = 1
 LOAD_EXEC = 1
@@ -31,7 +31,14 @@ class WspError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [("xlen", C.c_uint32), ("n_harts", C.c_uint32), ("isa", C.c_char_p), ("mem_base", C.c_uint64),
                 ("mem_size", C.c_uint64), ("lanes_per_wave", C.c_uint32), ("device", C.c_int32), ("hart_id_base", C.c_uint32),
-                ("tlb_entries", C.c_uint32), ("vlen_bytes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tlb_entries", C.c_uint32), ("vlen_bytes", C.c_uint32), ("reserved", C.c_uint32), ("config_json", C.c_char_p)]
+
+
+class ConfigInfo(C.Structure):
+    _fields_ = [("xlen", C.c_uint32), ("features", C.c_uint32), ("mem_size", C.c_uint64), ("reset_pc", C.c_uint64),
+                ("has_reset_pc", C.c_uint32), ("tlb_entries", C.c_uint32), ("vlen_bytes", C.c_uint32), ("abi_names", C.c_uint32),
+                ("n_csr_resets", C.c_uint32), ("reserved", C.c_uint32), ("csr_num", C.c_uint32 * 32), ("csr_value", C.c_uint64 * 32),
+                ("isa", C.c_char * 256)]
 
 
 class Result(C.Structure):
@@ -50,7 +57,7 @@ class Decoded(C.Structure):
 
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_softfloat.h"),
+    deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_softfloat.h"), os.path.join(HERE, "csrc", "wsp_config.h"),
             os.path.join(ROOT, "include", "whisper_amd.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -82,7 +89,8 @@ def lib():
         L.wsp_batch_poke.argtypes = [vp, u32, u32, u64, C.c_void_p, C.c_size_t]
         L.wsp_batch_peek.argtypes = [vp, u32, u32, u64, C.c_void_p, C.c_size_t]
         L.wsp_batch_poke_each.argtypes = [vp, u32, u32, u32, u64, C.POINTER(u64)]
-        L.wsp_batch_set_stop.argtypes = [vp, u32, u32, u64, u64]
+        L.wsp_batch_set_stop.argtypes = [vp, u32, u32, u64, u64, u64, u64]
+        L.wsp_config_parse.argtypes = [C.c_char_p, C.POINTER(ConfigInfo)]
         L.wsp_batch_run.restype = C.c_int64
         L.wsp_batch_run.argtypes = [vp, u64, u32]
         L.wsp_batch_last_run_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
@@ -118,15 +126,23 @@ class Batch:
     System64/Hart64, py-bindings.cpp:330-469, for a batch)."""
 
     def __init__(self, n_harts, isa="rv64imafdc_zicsr", mem_base=0x80000000, mem_size=1 << 16, lanes_per_wave=0, device=-1,
-                 hart_id_base=0, tlb_entries=0, vlen_bytes=0):
+                 hart_id_base=0, tlb_entries=0, vlen_bytes=0, config=None, xlen=0):
+        """config: text of a Whisper JSON configuration file (or a dict, dumped to JSON); isa / mem_size = None / 0 take the file's."""
         self.L = lib()
-        self._isa = isa.encode()
-        desc = BatchDesc(64, n_harts, self._isa, mem_base, mem_size, lanes_per_wave, device, hart_id_base, tlb_entries, vlen_bytes, 0)
+        if isinstance(config, dict):
+            import json
+            config = json.dumps(config)
+        self._cfg = config.encode() if isinstance(config, str) else config
+        info = parse_config(self._cfg) if self._cfg else None
+        self._isa = isa.encode() if isa else None
+        desc = BatchDesc(xlen, n_harts, self._isa, mem_base, mem_size or 0, lanes_per_wave, device, hart_id_base, tlb_entries, vlen_bytes, 0, self._cfg)
         h = C.c_void_p()
         _check(self.L.wsp_batch_create(C.byref(desc), C.byref(h)))
         self.h = h
         self.n = n_harts
-        self.vlen_bytes = (vlen_bytes or 64) if "v" in isa.lower().split("_")[0][4:] else 0   # Hart.cpp:1081 default
+        eff_isa = isa or (info.isa.decode() if info else "")
+        vb = vlen_bytes or (info.vlen_bytes if info else 0) or 64                              # Hart.cpp:1081 default
+        self.vlen_bytes = vb if "v" in eff_isa.lower().split("_")[0][4:] else 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -179,9 +195,10 @@ class Batch:
         arr = (C.c_uint64 * (hi - lo))(*[v & NO_LIMIT for v in values])
         _check(self.L.wsp_batch_poke_each(self.h, lo, hi, res, idx, arr))
 
-    def set_stop(self, tohost=None, max_inst=NO_LIMIT, lo=None, hi=None):
+    def set_stop(self, tohost=None, max_inst=NO_LIMIT, lo=None, hi=None, max_ret=NO_LIMIT, stop_pc=None):
         lo, hi = self._rng(lo, hi)
-        _check(self.L.wsp_batch_set_stop(self.h, lo, hi, NO_LIMIT if tohost is None else tohost, max_inst))
+        _check(self.L.wsp_batch_set_stop(self.h, lo, hi, NO_LIMIT if tohost is None else tohost, max_inst, max_ret,
+                                         NO_LIMIT if stop_pc is None else stop_pc))
 
     def run(self, max_steps=NO_LIMIT, trace_hash=False):
         return _check(self.L.wsp_batch_run(self.h, max_steps, RUN_TRACE_HASH if trace_hash else 0))
@@ -236,6 +253,15 @@ class Batch:
         arr = (C.c_uint32 * cap)()
         n = _check(self.L.wsp_batch_signature(self.h, hart, arr, cap))
         return list(arr[:n])
+
+
+def parse_config(text):
+    """wsp_config_parse: what a Whisper JSON configuration asks of a batch (raises WspError on tags the device does not model)."""
+    if isinstance(text, str):
+        text = text.encode()
+    info = ConfigInfo()
+    _check(lib().wsp_config_parse(text, C.byref(info)))
+    return info
 
 
 def decode_words(isa, words, host=False):

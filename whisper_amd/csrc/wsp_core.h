@@ -27,7 +27,17 @@ typedef uint8_t  u8;
 
 // ---------------------------------------------------------------------------------- constants
 enum { ISA_M = 1, ISA_A = 2, ISA_F = 4, ISA_D = 8, ISA_C = 16, ISA_S = 32, ISA_U = 64, ISA_V = 128, ISA_ZICNTR = 256 };
-enum { ST_RUNNING = 0, ST_STOP_TOHOST = 1, ST_STOP_ILLEGAL = 2, ST_STOP_LIMIT = 3, ST_STOP_UNSUPPORTED = 4 };
+// Configuration switches (HartConfig::applyConfig tags, HartConfig.cpp:2085-2958) travel in the same word as the ISA bits: they are
+// fixed for the lifetime of a batch exactly as the ISA is.  All zero = the reference's defaults.
+enum : u32 {
+  CFG_NO_MISAL = 1u << 16,          // enable_misaligned_data = false: misaligned loads / stores trap (Hart.cpp:2013-2016, 13810-13813)
+  CFG_CLR_MTVAL_ILL = 1u << 17,     // clear_mtval_on_illegal_instruction (Hart.cpp:3256)
+  CFG_CLR_MTVAL_EBREAK = 1u << 18,  // clear_mtval_on_ebreak (Hart.cpp:12097)
+  CFG_CANCEL_LR_TRAP = 1u << 19,    // cancel_lr_on_trap (Hart.cpp:3570, 4311)
+  CFG_KEEP_MPRV = 1u << 20,         // clear_mprv_on_ret = false (Hart.cpp:12283, 12499)
+  CFG_NO_SV39 = 1u << 21            // address_translation_modes without sv39: a satp write selecting it is dropped (Hart.cpp:13284-13294)
+};
+enum { ST_RUNNING = 0, ST_STOP_TOHOST = 1, ST_STOP_ILLEGAL = 2, ST_STOP_LIMIT = 3, ST_STOP_UNSUPPORTED = 4, ST_STOP_ADDR = 5 };
 enum { PRV_U = 0, PRV_S = 1, PRV_M = 3 };
 
 // Unsupported-reason codes reported in wsp_result.stop_value when status == ST_STOP_UNSUPPORTED
@@ -53,6 +63,8 @@ enum Op : u32 {
   OP_FMV_F2X, OP_FCLASS, OP_FMV_X2F,
   OP_VEC, OP_VLD, OP_VST,               // RVV: OP-V (0x57), vector load, vector store; fields are taken from Rec.raw
   OP_SLOWFETCH,                         // predecoded slot cannot be trusted: fetch + decode from RAM
+  OP_STOPCHK,                           // some hart's stop address (wsp_batch_set_stop): never in the inline subset, so the general
+                                        // path sees it, compares its own stop address and otherwise decodes Rec.raw again
   OP_COUNT
 };
 
@@ -311,7 +323,8 @@ enum ColdIx {
 enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, HF_HOT = 16,
              HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */,
              HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */,
-             HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */ };
+             HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */,
+             HF_NOTRACE = 512 /* this run folds no commit records (set per launch): commit() returns at once */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -372,6 +385,7 @@ template <class MEM> struct Lane {
   Step s;
   MEM m;
   u64 mem_base, mem_size, tohost, text_lo, text_hi;   // tohost == ~0: none
+  u64 stop_pc = ~0ULL;                                 // Hart::untilAddress' address (Hart.cpp:6025): ~0 = none (pcs are even)
   u32 isa, hart_id;
   u32 tlb_n;                                           // TLB entries (power of two; 0 when the ISA has no S)
   u32 vlenb;                                           // bytes per vector register (0 when the ISA has no V)
@@ -420,6 +434,7 @@ template <class MEM> struct Lane {
       h.exec_last_ill = h.exec;
     }
     s.chg |= CH_EXC;
+    if (ext(CFG_CANCEL_LR_TRAP)) h.flags &= ~(u32)HF_LR_VALID;                            // initiateTrap (Hart.cpp:3570-3571)
     u32 next = PRV_M;
     if (ext(ISA_S) && h.priv != PRV_M && ((m.cold(CI_MEDELEG) >> cause) & 1)) next = PRV_S;
     u32 orig = h.priv;
@@ -443,7 +458,7 @@ template <class MEM> struct Lane {
     h.mstatus = v;
     h.pc = tvec & ~3ULL;
   }
-  WSP_HD void illegal(const Rec& r, u64 cur_pc) { take_exception(2, cur_pc, r.raw, true); }
+  WSP_HD void illegal(const Rec& r, u64 cur_pc) { take_exception(2, cur_pc, ext(CFG_CLR_MTVAL_ILL) ? 0 : r.raw, true); }   // illegalInst (Hart.cpp:3247-3258)
 
   // ---- interrupts: Hart::isInterruptPossible (Hart.cpp:7028-7083, 7135-7157) without H/AIA/NMI.  A bare system has no
   // timer or external source, so pending = mip as software left it; M-destined = mip & mie & ~mideleg, S-destined =
@@ -470,6 +485,7 @@ template <class MEM> struct Lane {
   WSP_HD void take_interrupt(u32 cause, u32 next, u64 epc)
   {
     const u32 orig = h.priv;
+    if (ext(CFG_CANCEL_LR_TRAP)) h.flags &= ~(u32)HF_LR_VALID;
     h.priv = next;
     const u64 cv = (1ULL << 63) | cause;
     u64 tvec, v = h.mstatus;
@@ -729,6 +745,7 @@ template <class MEM> struct Lane {
     const bool misal = (va & mask) != 0;
     u32 c;
     pa1 = va;
+    if (misal && ext(CFG_NO_MISAL)) { tval = va; return need == 1 ? 4u : 6u; }           // misalHasPriority_ and not misalDataOk_ (Hart.cpp:2013-2016)
     if (tr && (c = translate(va, pm, need, pa1)) != 0) { tval = va; return c; }
     if (!misal) {
       if (!(pmp_perm(pm, pa1) & need) || !in_mem(pa1, size)) { tval = va; return af; }
@@ -969,7 +986,7 @@ template <class MEM> struct Lane {
     wx(rd, prev);
     if (num == C_SATP) {
       u32 mode = (u32)(next >> 60);
-      if (mode != 0 && mode != 8 && mode != 9 && mode != 10) return;                      // unsupported MODE: write dropped (13284-13294)
+      if ((mode != 0 && mode != 8 && mode != 9 && mode != 10) || (mode == 8 && ext(CFG_NO_SV39))) return;                      // unsupported MODE: write dropped (13284-13294)
       if (mode > 8) { stop(ST_STOP_UNSUPPORTED, UNS_PAGING); return; }                   // Sv48 / Sv57: not modelled
     }
     if (num >= 0x3B0 && num < 0x3EF && !pmpaddr_locked(num - 0x3B0)) {
@@ -1098,7 +1115,7 @@ template <class MEM> struct Lane {
     if (op == OP_LR) {                                                                     // amo.cpp:142-266
       // determineLoadException first (a translation fault wins), then alignment; the trap value is the LR's own address
       u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
-      if (c == 0 && (va & (size - 1))) c = 5;
+      if (c == 4 || (c == 0 && (va & (size - 1)))) c = 5;                                  // misalAtomicCauseAccessFault_ (amo.cpp:180-181, 188-201)
       if (c) { take_exception(c, cur_pc, va, false); return; }
       u64 v = mem_read(pa1 - mem_base, size);
       if (size == 4) v = (u64)(i64)(i32)v;
@@ -2767,7 +2784,7 @@ template <class MEM> struct Lane {
       case OP_SB: case OP_SH: case OP_SW: case OP_SD: do_store(a + (u64)(i64)r.imm, 1u << (op - OP_SB), b, cur_pc); break;
       case OP_NOP: break;
       case OP_ECALL: take_exception(h.priv == PRV_M ? 11 : h.priv == PRV_S ? 9 : 8, cur_pc, 0, true); break;   // Hart.cpp:12006-12014
-      case OP_EBREAK: take_exception(3, cur_pc, cur_pc, true); break;                        // Hart.cpp:12094-12101
+      case OP_EBREAK: take_exception(3, cur_pc, ext(CFG_CLR_MTVAL_EBREAK) ? 0 : cur_pc, true); break;                        // Hart.cpp:12094-12101
       case OP_MRET: {                                                                        // Hart.cpp:12247-12336
         if (h.priv < PRV_M) { illegal(r, cur_pc); break; }
         u64 v = h.mstatus; u32 saved = (v >> MST_MPP_SH) & 3;
@@ -2775,7 +2792,7 @@ template <class MEM> struct Lane {
         u32 least = ext(ISA_U) ? PRV_U : ext(ISA_S) ? PRV_S : PRV_M;
         v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)least << MST_MPP_SH);
         v |= MST_MPIE;
-        if (saved != PRV_M) v &= ~MST_MPRV;
+        if (saved != PRV_M && !ext(CFG_KEEP_MPRV)) v &= ~MST_MPRV;
         csr_store(C_MSTATUS, v); s.chg |= CH_MSTATUS;
         h.pc = m.cold(CI_MEPC) & epc_rmask(); h.priv = saved; break; }
       case OP_SRET: {                                                                        // Hart.cpp:12428-12560
@@ -2783,7 +2800,7 @@ template <class MEM> struct Lane {
         u64 v = h.mstatus; u32 saved = (v & MST_SPP) ? PRV_S : PRV_U;
         v = (v & ~MST_SIE) | ((v & MST_SPIE) ? MST_SIE : 0);
         v = ext(ISA_U) ? (v & ~MST_SPP) : (v | MST_SPP);
-        v |= MST_SPIE; v &= ~MST_MPRV;
+        v |= MST_SPIE; if (!ext(CFG_KEEP_MPRV)) v &= ~MST_MPRV;                              // Hart.cpp:12499 (saved mode is never M here)
         h.mstatus = legalize_mstatus(v); s.chg |= CH_SSTATUS;
         h.pc = m.cold(CI_SEPC) & epc_rmask(); h.priv = saved; break; }
       case OP_WFI:                                                                           // Hart.cpp:12618
@@ -2896,10 +2913,12 @@ template <class MEM> struct Lane {
   template <bool TRACE> WSP_HD void cold_step(const Rec* recs)
   {
     u64 cur_pc, a = 0, b = 0; u32 priv0; Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+    if (h.pc == stop_pc) { h.status = ST_STOP_ADDR; return; }                  // `while (pc_ != address ...` (Hart.cpp:6025): nothing executes
     cold_begin(cur_pc, priv0);
     if (poll_interrupt<TRACE>(cur_pc, priv0)) { update_hot_flag(); return; }
     bool have = false;
     if (recs && h.priv == PRV_M && !(h.flags & (HF_CODE_DIRTY | HF_PMP_MLOCK)) && hot_fetch(recs, rec)) {
+      if ((rec.w0 & 0xff) == OP_STOPCHK) { const Rec r2 = decode(rec.raw, isa); rec.w0 = r2.w0; rec.imm = r2.imm; }   // another hart's stop address
       h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
       a = m.rx(rec_rs1(rec));
       b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
@@ -2919,7 +2938,7 @@ template <class MEM> struct Lane {
   // digest goes on.
   template <bool TRACE> WSP_HD void commit(u64 cur_pc, u32 raw, u32 size, u32 priv0, u32 trap)
   {
-    if (!TRACE) return;
+    if (!TRACE || (h.flags & HF_NOTRACE)) return;
     u64 t = h.thash;
     u64* const rg = ring_; u32 pos = rg ? *ring_pos_ : 0; const u32 cap = ring_cap, meta_at = pos + 1, kinds_at = pos + 2; u32 np = 0; u64 kinds = 0;
 #define WSP_RING(w) do { if (rg && pos < cap) rg[pos++] = (w); } while (0)

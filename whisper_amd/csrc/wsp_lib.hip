@@ -17,6 +17,7 @@
 #include <map>
 #include <algorithm>
 #include "wsp_core.h"
+#include "wsp_config.h"
 #include "../../include/whisper_amd.h"
 
 using namespace wsp;
@@ -36,6 +37,7 @@ struct DevState {
   u32 vlenb, ring_cap;
   u64* ring; u32* ring_pos;   // commit ring: [n_harts][ring_cap] words and the words written per hart; null when off
   u64* tohost; u64* max_exec; u32* prog;
+  u64* max_ret; u64* stop_pc;   // retired-instruction limit and stop address per slot (Hart.cpp:6025-6026); ~0 = none
   u8* arena;
   const ProgDev* progs;
   u32* running;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& 
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
   L.mem_base = d.mem_base; L.mem_size = d.mem_size; L.isa = d.isa; L.hart_id = d.hart_id_base + wave * d.lpw + ln;
-  L.tohost = d.tohost[slot];
+  L.tohost = d.tohost[slot]; L.stop_pc = d.stop_pc[slot];
   const u32 pg = d.prog[slot];
   recs = nullptr; L.text_lo = 0; L.text_hi = 0;
   if (pg != ~0u) { ProgDev p = d.progs[pg]; recs = p.recs; L.text_lo = p.text_lo; L.text_hi = p.text_hi; }
@@ -134,7 +136,18 @@ __device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevSt
 // cold steps; exec/cycle/instret/retired are synchronised lazily: a hot step advances all four by
 // exactly one (HF_HOT guarantees no inhibit, no trap), so the HBM copies are brought up to date
 // from the difference between the register exec counter and the stored one.
-struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status, fcsr; };
+struct HotRegs { u64 pc, exec, thash, stop_at, slice_end; u32 flags, status, fcsr; };
+
+// First value of the executed-instruction counter at which the hart must not start another instruction: the end of this launch's
+// slice, the instruction-count limit, or the retired-instruction limit, whichever comes first (Hart.cpp:6025-6026).  retired lags
+// exec by the number of trapped instructions, which only the general path can change: it calls this again after every step.
+__device__ __forceinline__ u64 wsp_stop_at(u64 slice_end, u64 max_exec, u64 max_ret, u64 exec, u64 retired)
+{
+  u64 r = max_ret + (exec - retired);
+  if (r < max_ret) r = ~0ULL;
+  const u64 a = slice_end < max_exec ? slice_end : max_exec;
+  return a < r ? a : r;
+}
 
 // The general path, out of line: rebuilds the full lane from HBM, runs one complete general step
 // (interrupt poll, fetch, full exec(), retire, commit record) and stores the lane back.
@@ -145,10 +158,13 @@ struct HotRegs { u64 pc, exec, thash, stop_at; u32 flags, status, fcsr; };
 #ifndef WSP_COLD_BURST
 #define WSP_COLD_BURST 64u
 #endif
-template <bool TRACE>
-__device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, HotRegs hr)
+// One compiled body serves traced and untraced runs (HF_NOTRACE in the lane's flags makes commit() return at once): what an
+// untraced run executes here is exactly what the traced parity tests execute.  The arguments fit the 16 argument registers (2 for
+// dp + 13 for HotRegs), so HotRegs travels in registers; wave and lane are recomputed here.
+__device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
 {
   const DevState& d = *dp;
+  const u32 wave = blockIdx.x, ln = ln_of(d);
   const u32 slot = wave * 64 + ln;
   Lane<DevMem> L; const Rec* recs;
   wsp_lane_setup(L, d, wave, ln, slot, recs);
@@ -156,14 +172,17 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, u32 wave, u32 ln, H
   const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
   L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
   L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
+  const u64 max_exec = d.max_exec[slot], max_ret = d.max_ret[slot];
+  u64 stop_at = hr.stop_at;
   u32 k = 0;
   do {
     L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
-    L.template cold_step<TRACE>(recs);
-  } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < hr.stop_at &&
+    L.template cold_step<true>(recs);
+    stop_at = wsp_stop_at(hr.slice_end, max_exec, max_ret, L.h.exec, L.h.retired);
+  } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < stop_at &&
            !((L.h.flags & HF_HOT) && L.h.pc - L.text_lo < L.text_hi - L.text_lo));
   wsp_store_hot(L, d, slot);
-  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = hr.stop_at; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
+  HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = stop_at; r.slice_end = hr.slice_end; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
   return r;
 }
 
@@ -223,8 +242,12 @@ template <> struct RecQ<true> { typedef wsp_u32x4 T; static __device__ __forcein
 template <> struct RecQ<false> { typedef wsp_u32x3 T; static __device__ __forceinline__ u32 raw(const T&) { return 0; } };
 
 template <bool TRACE, bool FP>
-__global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState d, const DevState* dp, u64 max_steps)
+__global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState d, const DevState* dp, u64 max_steps, u32 notrace)
 {
+  // TRACE = false is the lean build of the inline loops for untraced batches in which every wave runs one program image (the
+  // host picks it, wsp_batch_run).  Every other untraced batch runs the TRACE = true kernel with notrace set: one compiled body of
+  // the divergent dispatch loop for traced and untraced runs, so the traced parity tests cover what untraced runs execute.
+  const bool tr = TRACE && !notrace;
   const u32 lane = threadIdx.x, wave = blockIdx.x;
   const u32 hart = wave * d.lpw + lane;
   const bool active = lane < d.lpw && hart < d.n_harts;
@@ -239,11 +262,14 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.fcsr = d.hot32[H32_FCSR * S + slot];
   L.update_pmp_flags();                                  // host pokes may have changed priv / mstatus / mip / mie / pmpcfg / flags
   L.h.flags = d.ring ? (L.h.flags | HF_RING) : (L.h.flags & ~(u32)HF_RING);
+  L.h.flags = tr ? (L.h.flags & ~(u32)HF_NOTRACE) : (L.h.flags | HF_NOTRACE);
   L.update_hot_flag();
-  u64 stop_at;
+  u64 stop_at, slice_end;
   {
-    const u64 max_exec = d.max_exec[slot], exec0 = L.h.exec;
-    stop_at = exec0 >= max_exec ? exec0 : ((max_exec - exec0 < max_steps) ? max_exec : exec0 + max_steps);
+    const u64 exec0 = L.h.exec;
+    slice_end = exec0 + max_steps < exec0 ? ~0ULL : exec0 + max_steps;
+    stop_at = wsp_stop_at(slice_end, d.max_exec[slot], d.max_ret[slot], exec0, d.hot64[H64_RETIRED * S + slot]);
+    if (stop_at < exec0) stop_at = exec0;
   }
 
   if (active) {
@@ -424,7 +450,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             }
 #undef WSP_CW
 #undef WSP_BAD
-            if (TRACE && !bad) {
+            if (TRACE && tr && !bad) {
               u64 t = L.h.thash;
               t = fold(t, tlo + upc);
               t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
@@ -592,7 +618,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
           }
 #undef WSP_HOT_OP
 #undef WSP_WX
-          if (TRACE && !ncv) {                            // commit record of an M-mode instruction without trap or CSR change
+          if (TRACE && tr && !ncv) {                      // commit record of an M-mode instruction without trap or CSR change
             u64 t = L.h.thash;
             t = fold(t, tlo + pco);
             t = fold(t, (u64)raw | ((u64)PRV_M << 32) | ((u64)size << 48));
@@ -614,8 +640,9 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
       Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
       if (L.hot_fetch(recs, rec) && (rec.w0 & 0xff) >= OP_FADD && (rec.w0 & 0xff) <= OP_FMV_X2F) {
         const u32 ln2 = ln_of(d);
-        const WarmRet w = wsp_warm<TRACE>(d.isa, ln2 * (WSP_XSLOTS * 8), (d.lpw + ln2) * (WSP_XSLOTS * 8), rec.w0, rec.imm, rec.raw,
-                                          L.h.pc, L.h.thash, L.h.fcsr);
+        const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
+        const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr)
+                                        : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr);
         if (w.handled) {
           L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
           need_cold = false;
@@ -625,24 +652,25 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     if (need_cold) {
       // A cold call is a context switch: every per-lane value of the hot loop is either passed through HotRegs or
       // rebuilt from the kernel arguments afterwards.
-      HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.stop_at = stop_at;
+      HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.stop_at = stop_at; hr.slice_end = slice_end;
       hr.flags = L.h.flags; hr.status = L.h.status; hr.fcsr = L.h.fcsr;
-      hr = wsp_cold<TRACE>(dp, blockIdx.x, ln_of(d), hr);
+      hr = wsp_cold(dp, hr);
       const u32 ln2 = ln_of(d);
       wsp_lane_setup(L, d, blockIdx.x, ln2, blockIdx.x * 64 + ln2, recs);
-      L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; stop_at = hr.stop_at;
+      L.h.pc = hr.pc; L.h.exec = hr.exec; L.h.thash = hr.thash; stop_at = hr.stop_at; slice_end = hr.slice_end;
       L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
     }
   }
 
   __syncthreads();
   if (active) {
-    if (L.h.status == ST_RUNNING && L.h.exec >= d.max_exec[slot]) L.h.status = ST_STOP_LIMIT;   // Hart.cpp:6025
     for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
     if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
     // bring the lazily synchronised counters up to date
     const u64 dlt = L.h.exec - d.hot64[H64_EXEC * S + slot];
-    d.hot64[H64_CYCLE * S + slot] += dlt; d.hot64[H64_INSTRET * S + slot] += dlt; d.hot64[H64_RETIRED * S + slot] += dlt;
+    const u64 retired = d.hot64[H64_RETIRED * S + slot] + dlt;
+    if (L.h.status == ST_RUNNING && (L.h.exec >= d.max_exec[slot] || retired >= d.max_ret[slot])) L.h.status = ST_STOP_LIMIT;   // Hart.cpp:6025-6026
+    d.hot64[H64_CYCLE * S + slot] += dlt; d.hot64[H64_INSTRET * S + slot] += dlt; d.hot64[H64_RETIRED * S + slot] = retired;
     d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_THASH * S + slot] = L.h.thash;
     d.hot32[H32_FLAGS * S + slot] = L.h.flags; d.hot32[H32_STATUS * S + slot] = L.h.status; d.hot32[H32_FCSR * S + slot] = L.h.fcsr;
   }
@@ -886,16 +914,19 @@ struct wsp_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<Program> progs;
   std::vector<u32> hart_prog;          // host copy, index = hart
+  std::vector<u64> hart_stop_pc;       // host copy of the stop addresses (~0: none)
   ProgDev* d_progs = nullptr; size_t d_progs_cap = 0;
   DevState* d_state = nullptr;
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
   double last_kernel_s = 0, last_hash_s = 0; u32 last_launches = 0; u64 last_hash_bytes = 0;
   bool has_fp = false;
-  void* snap[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool abi_names = false;              // config tag abi_names: the text log prints ABI register names
+#define WSP_SNAP_PARTS 13
+  void* snap[WSP_SNAP_PARTS] = {};
 };
 
 struct SnapPart { void* live; size_t bytes; };
-static void snap_parts(wsp_batch* b, SnapPart out[11])
+static void snap_parts(wsp_batch* b, SnapPart out[WSP_SNAP_PARTS])
 {
   DevState& d = b->d; size_t S = d.S;
   out[0] = { d.x, 32 * S * 8 }; out[1] = { d.f, 32 * S * 8 }; out[2] = { d.hot64, H64_COUNT * S * 8 }; out[3] = { d.hot32, H32_COUNT * S * 4 };
@@ -903,6 +934,7 @@ static void snap_parts(wsp_batch* b, SnapPart out[11])
   out[8] = { d.arena, (size_t)d.n_waves * d.lpw * d.mem_size };
   out[9] = { d.tlb, (size_t)d.n_harts * 2 * d.tlb_n * 8 };
   out[10] = { d.vreg, (size_t)d.n_harts * 32 * d.vlenb };
+  out[11] = { d.max_ret, S * 8 }; out[12] = { d.stop_pc, S * 8 };
 }
 
 static int upload_progs(wsp_batch* b)
@@ -919,12 +951,38 @@ static int upload_progs(wsp_batch* b)
   return WSP_OK;
 }
 
+static int csr_loc(u32 num, u32* ix);
+
+// Reset value of a modelled CSR for every hart of a fresh batch (all harts are in the reset state: legalisation against
+// the previous value uses the built-in reset values).
+static int reset_csr_all(wsp_batch* b, u32 num, u64 v)
+{
+  DevState& d = b->d; const size_t S = d.S;
+  u32 ix = 0; const int loc = csr_loc(num, &ix);
+  if (loc < 0) return fail(WSP_EUNSUPPORTED, "config csr reset: only CSRs with storage of their own can be given a reset value (not sstatus / sie / sip / fflags / frm / vxsat / vxrm views)");
+  if (loc == 1) { std::vector<u32> r(S, (u32)v & 0xff); HIPOK(hipMemcpy(d.hot32 + ix * S, r.data(), S * 4, hipMemcpyHostToDevice)); return WSP_OK; }
+  if (num == C_MSTATUS) v = (MSTATUS_RESET & ~MSTATUS_WMASK) | (v & (MSTATUS_WMASK | MST_SD));
+  if (loc == 2) {
+    if (ix >= CI_PMPCFG0 && ix < CI_PMPADDR0) v = Lane<DevMem>::legalize_pmpcfg(0, v) & 0x9f9f9f9f9f9f9f9fULL;
+    else if (ix >= CI_PMPADDR0 && ix < CI_PMPADDR0 + 64) v &= 0x003fffffffffffffULL;
+    if (num == C_SATP && (v >> 60) != 0 && (v >> 60) != 8) return fail(WSP_EUNSUPPORTED, "config csr reset: satp mode other than bare / sv39");
+    if (num == C_MCOUNTINHIBIT) {
+      v &= 0xfffffffdULL;
+      std::vector<u32> fl(S, ((v & 1) ? (u32)HF_INH_CY : 0) | ((v & 4) ? (u32)HF_INH_IR : 0));
+      HIPOK(hipMemcpy(d.hot32 + (size_t)H32_FLAGS * S, fl.data(), S * 4, hipMemcpyHostToDevice));
+    }
+  }
+  std::vector<u64> r(S, v);
+  HIPOK(hipMemcpy((loc == 0 ? d.hot64 : d.cold) + ix * S, r.data(), S * 8, hipMemcpyHostToDevice));
+  return WSP_OK;
+}
+
 extern "C" void wsp_batch_destroy(wsp_batch* b)
 {
   if (!b) return;
   hipSetDevice(b->device);
   for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
-  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state, b->d.ring, b->d.ring_pos };
+  void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state, b->d.ring, b->d.ring_pos, b->d.max_ret, b->d.stop_pc };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -937,13 +995,28 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
 {
   if (!desc || !out) return fail(WSP_EINVAL, "null argument");
   *out = nullptr;
-  if (desc->xlen != 64) return fail(WSP_EUNSUPPORTED, "only xlen=64 is supported");
+  // Configuration file text first; explicit descriptor fields override it (as command line options override the file,
+  // Session.cpp:1373-1424, 1440-1520).
+  wspcfg::Parsed cfg;
+  if (desc->config_json) {
+    wspcfg::JVal root; std::string perr;
+    if (!wspcfg::parse_json(desc->config_json, root, perr)) return fail(WSP_EFORMAT, perr);
+    int crc = wspcfg::apply(root, cfg, perr);
+    if (crc != WSP_OK) return fail(crc, perr);
+  }
+  const char* isa_str = desc->isa ? desc->isa : (cfg.isa.empty() ? nullptr : cfg.isa.c_str());
+  if (!isa_str) return fail(WSP_EINVAL, "no ISA string (descriptor isa or config tag \"isa\")");
+  u32 xlen = desc->xlen ? desc->xlen : cfg.xlen;
+  if (!xlen) { std::string t = isa_str; xlen = (t.rfind("rv32", 0) == 0 || t.rfind("RV32", 0) == 0) ? 32 : 64; }   // HartConfig::getXlen (HartConfig.cpp:3431-3459)
+  if (xlen != 64) return fail(WSP_EUNSUPPORTED, "only xlen=64 is supported");
+  const u64 mem_size = desc->mem_size ? desc->mem_size : cfg.mem_size;
   if (desc->n_harts == 0) return fail(WSP_EINVAL, "n_harts must be > 0");
-  if (desc->mem_size == 0 || (desc->mem_size & 4095)) return fail(WSP_EINVAL, "mem_size must be a non-zero multiple of 4096");
-  if (desc->mem_base + desc->mem_size < desc->mem_base) return fail(WSP_EINVAL, "arena wraps the address space");
+  if (mem_size == 0 || (mem_size & 4095)) return fail(WSP_EINVAL, "mem_size must be a non-zero multiple of 4096");
+  if (desc->mem_base + mem_size < desc->mem_base) return fail(WSP_EINVAL, "arena wraps the address space");
   u32 isa = 0; std::string why;
-  int rc = parse_isa(desc->isa, &isa, &why);
+  int rc = parse_isa(isa_str, &isa, &why);
   if (rc != WSP_OK) return fail(rc, why);
+  isa |= cfg.features;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device: whisper_amd has no CPU execution path");
   int dev = desc->device;
@@ -965,10 +1038,12 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   DevState& d = b->d;
   d.n_harts = desc->n_harts; d.lpw = lpw; d.lpw_shift = (u32)__builtin_ctz(lpw);
   d.n_waves = (desc->n_harts + lpw - 1) / lpw; d.S = d.n_waves * 64; d.isa = isa; d.hart_id_base = desc->hart_id_base;
-  d.mem_base = desc->mem_base; d.mem_size = desc->mem_size;
-  d.tlb_n = (isa & ISA_S) ? (desc->tlb_entries ? desc->tlb_entries : 2048u) : 0u;        // Hart.cpp:106
+  d.mem_base = desc->mem_base; d.mem_size = mem_size;
+  b->abi_names = cfg.abi_names;
+  const u32 tlb_req = desc->tlb_entries ? desc->tlb_entries : cfg.tlb_entries, vlen_req = desc->vlen_bytes ? desc->vlen_bytes : cfg.vlen_bytes;
+  d.tlb_n = (isa & ISA_S) ? (tlb_req ? tlb_req : 2048u) : 0u;        // Hart.cpp:106
   if (d.tlb_n & (d.tlb_n - 1)) { delete b; return fail(WSP_EINVAL, "tlb_entries must be a power of two"); }   // Tlb.cpp:11
-  d.vlenb = (isa & ISA_V) ? (desc->vlen_bytes ? desc->vlen_bytes : 64u) : 0u;           // Hart.cpp:1081
+  d.vlenb = (isa & ISA_V) ? (vlen_req ? vlen_req : 64u) : 0u;           // Hart.cpp:1081
   if ((isa & ISA_V) && d.vlenb != 16 && d.vlenb != 32 && d.vlenb != 64) { delete b; return fail(WSP_EINVAL, "vlen_bytes must be 16, 32 or 64"); }
   b->has_fp = (isa & ISA_F) != 0;
   size_t vreg_bytes = (size_t)d.n_harts * 32 * d.vlenb;
@@ -979,24 +1054,46 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m_ = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); wsp_batch_destroy(b); return fail(WSP_ENOMEM, m_); } \
     e_ = hipMemset((ptr), 0, (bytes)); if (e_ != hipSuccess) { wsp_batch_destroy(b); return fail(WSP_EHIP, "hipMemset failed"); } } while (0)
   ALLOC(d.x, 32 * S * 8); ALLOC(d.f, 32 * S * 8); ALLOC(d.hot64, H64_COUNT * S * 8); ALLOC(d.hot32, H32_COUNT * S * 4);
-  ALLOC(d.cold, (CI_COUNT + 1) * S * 8);   /* + one row: per-slot store sink of the hot loop */ ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4);
+  ALLOC(d.cold, (CI_COUNT + 1) * S * 8);   /* + one row: per-slot store sink of the hot loop */ ALLOC(d.tohost, S * 8); ALLOC(d.max_exec, S * 8); ALLOC(d.prog, S * 4); ALLOC(d.max_ret, S * 8); ALLOC(d.stop_pc, S * 8);
   ALLOC(d.arena, arena_bytes); if (tlb_bytes) ALLOC(d.tlb, tlb_bytes); if (vreg_bytes) ALLOC(d.vreg, vreg_bytes); ALLOC(d.running, 4); ALLOC(b->d_state, sizeof(DevState)); ALLOC(b->d_memhash, S * 8); ALLOC(b->d_results, (size_t)d.n_harts * sizeof(wsp_result));
 #undef ALLOC
   // Hart::reset (Hart.cpp:942-1070): pc = reset pc (arena base here), M mode, mstatus reset value.
   std::vector<u64> v64(S);
-  std::fill(v64.begin(), v64.end(), d.mem_base);      hipMemcpy(d.hot64 + (size_t)H64_PC * S, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::fill(v64.begin(), v64.end(), cfg.has_reset_pc ? (cfg.reset_pc & ~1ULL) : d.mem_base);   // defineResetPc (config tag reset_vec), else the arena base
+  hipMemcpy(d.hot64 + (size_t)H64_PC * S, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::fill(v64.begin(), v64.end(), MSTATUS_RESET);   hipMemcpy(d.hot64 + (size_t)H64_MSTATUS * S, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::fill(v64.begin(), v64.end(), 1ULL << 63);      hipMemcpy(d.cold + (size_t)CI_VTYPE * S, v64.data(), S * 8, hipMemcpyHostToDevice);   // vtype resets to vill (CsRegs.cpp:5363)
   std::fill(v64.begin(), v64.end(), ~0ULL);           hipMemcpy(d.tohost, v64.data(), S * 8, hipMemcpyHostToDevice);
   hipMemcpy(d.max_exec, v64.data(), S * 8, hipMemcpyHostToDevice);
+  hipMemcpy(d.max_ret, v64.data(), S * 8, hipMemcpyHostToDevice); hipMemcpy(d.stop_pc, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::vector<u32> v32(S, (u32)PRV_M);                hipMemcpy(d.hot32 + (size_t)H32_PRIV * S, v32.data(), S * 4, hipMemcpyHostToDevice);
   std::fill(v32.begin(), v32.end(), ~0u);             hipMemcpy(d.prog, v32.data(), S * 4, hipMemcpyHostToDevice);
-  b->hart_prog.assign(d.n_harts, ~0u);
+  b->hart_prog.assign(d.n_harts, ~0u); b->hart_stop_pc.assign(d.n_harts, ~0ULL);
   { u64* sp = nullptr; if (scratch_of(dev, &sp) != WSP_OK) { std::string m_ = g_err; wsp_batch_destroy(b); return fail(WSP_EHIP, m_); } }   // set-up time: wsp_batch_results_noalloc must not look anything up
   if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
     wsp_batch_destroy(b); return fail(WSP_EHIP, "stream/event creation failed");
   }
+  for (auto& cr : cfg.csr) {                            // config "csr": { name: { "reset": v } } (applyCsrConfig, HartConfig.cpp:243-330)
+    int crc = reset_csr_all(b, cr.num, cr.value);
+    if (crc != WSP_OK) { std::string m_ = g_err; wsp_batch_destroy(b); return fail(crc, m_); }
+  }
   *out = b;
+  return WSP_OK;
+}
+
+extern "C" int wsp_config_parse(const char* json_text, wsp_config_info* out)
+{
+  if (!json_text || !out) return fail(WSP_EINVAL, "null argument");
+  memset(out, 0, sizeof *out);
+  wspcfg::JVal root; wspcfg::Parsed cfg; std::string perr;
+  if (!wspcfg::parse_json(json_text, root, perr)) return fail(WSP_EFORMAT, perr);
+  int rc = wspcfg::apply(root, cfg, perr);
+  if (rc != WSP_OK) return fail(rc, perr);
+  out->xlen = cfg.xlen; out->features = cfg.features; out->mem_size = cfg.mem_size; out->reset_pc = cfg.reset_pc; out->has_reset_pc = cfg.has_reset_pc;
+  out->tlb_entries = cfg.tlb_entries; out->vlen_bytes = cfg.vlen_bytes; out->abi_names = cfg.abi_names;
+  out->n_csr_resets = (u32)std::min<size_t>(cfg.csr.size(), 32);
+  for (u32 i = 0; i < out->n_csr_resets; ++i) { out->csr_num[i] = cfg.csr[i].num; out->csr_value[i] = cfg.csr[i].value; }
+  snprintf(out->isa, sizeof out->isa, "%s", cfg.isa.c_str());
   return WSP_OK;
 }
 
@@ -1071,6 +1168,19 @@ static int set_u32_slots(wsp_batch* b, u32* base, u32 lo, u32 hi, u32 val)
   return WSP_OK;
 }
 
+// Turn the pre-decoded record at `stop_pc` of program `pg` into OP_STOPCHK (see wsp_batch_set_stop).
+static int patch_stop(wsp_batch* b, u32 pg, u64 stop_pc)
+{
+  Program& p = b->progs[pg];
+  if (!p.d_recs || stop_pc < p.text_lo || stop_pc >= p.text_hi) return WSP_OK;
+  u32* w0p = &p.d_recs[(stop_pc - p.text_lo) / 2].w0; u32 w0 = 0;
+  HIPOK(hipMemcpy(&w0, w0p, 4, hipMemcpyDeviceToHost));
+  if ((w0 & 0xff) == OP_SLOWFETCH || (w0 & 0xff) == OP_STOPCHK) return WSP_OK;
+  w0 = (w0 & ~0xffu) | OP_STOPCHK;
+  HIPOK(hipMemcpy(w0p, &w0, 4, hipMemcpyHostToDevice));
+  return WSP_OK;
+}
+
 // Register a code region: upload, pre-decode on the device, bind to harts [lo, hi).
 static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vector<u8>& text, const std::map<std::string, u64>& syms)
 {
@@ -1095,6 +1205,8 @@ static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vec
   int rc = upload_progs(b); if (rc) return rc;
   rc = set_u32_slots(b, d.prog, lo, hi, id); if (rc) return rc;
   for (u32 h = lo; h < hi; ++h) b->hart_prog[h] = id;
+  u64 last = ~0ULL;                                    // stop addresses set before the code was loaded
+  for (u32 h = lo; h < hi; ++h) if (b->hart_stop_pc[h] != last) { last = b->hart_stop_pc[h]; if (last != ~0ULL) { rc = patch_stop(b, id, last); if (rc) return rc; } }
   return WSP_OK;
 }
 
@@ -1220,16 +1332,33 @@ extern "C" int wsp_batch_symbol(wsp_batch* b, uint32_t hart, const char* name, u
   return WSP_OK;
 }
 
-extern "C" int wsp_batch_set_stop(wsp_batch* b, uint32_t lo, uint32_t hi, uint64_t tohost, uint64_t max_inst)
+extern "C" int wsp_batch_set_stop(wsp_batch* b, uint32_t lo, uint32_t hi, uint64_t tohost, uint64_t max_inst, uint64_t max_ret, uint64_t stop_pc)
 {
   int rc = check_range(b, lo, hi); if (rc) return rc;
   HIPOK(hipSetDevice(b->device));
+  if (stop_pc != ~0ULL && (stop_pc & 1)) return fail(WSP_EINVAL, "stop_pc must be even (a pc never has bit 0 set)");
   if (tohost != ~0ULL) { rc = set_u64_slots(b, b->d.tohost, lo, hi, tohost); if (rc) return rc; }
-  return set_u64_slots(b, b->d.max_exec, lo, hi, max_inst);
+  rc = set_u64_slots(b, b->d.max_exec, lo, hi, max_inst); if (rc) return rc;
+  rc = set_u64_slots(b, b->d.max_ret, lo, hi, max_ret); if (rc) return rc;
+  rc = set_u64_slots(b, b->d.stop_pc, lo, hi, stop_pc); if (rc) return rc;
+  if (stop_pc != ~0ULL) {
+    // The inline loops never compare pcs: the pre-decoded record at the stop address is turned into OP_STOPCHK, which is outside
+    // their subset, so a hart arriving there takes the general path, which makes the comparison (Lane::cold_step).  The image may
+    // be shared: harts with another stop address decode Rec.raw again and go on.
+    u32 last = ~0u;
+    for (u32 h = lo; h < hi; ++h) {
+      const u32 pg = b->hart_prog[h];
+      if (pg == last || pg == ~0u) continue;
+      last = pg;
+      rc = patch_stop(b, pg, stop_pc); if (rc) return rc;
+    }
+  }
+  for (u32 h = lo; h < hi; ++h) b->hart_stop_pc[h] = stop_pc;
+  return WSP_OK;
 }
 
 // location of a modelled CSR in device state: returns 0 hot64, 1 hot32, 2 cold, -1 none
-static int csr_loc(u32 num, u32* ix)
+int csr_loc(u32 num, u32* ix)
 {
   switch (num) {
     case C_FCSR: *ix = H32_FCSR; return 1;
@@ -1359,13 +1488,13 @@ extern "C" int wsp_batch_poke_each(wsp_batch* b, uint32_t lo, uint32_t hi, uint3
   return WSP_OK;
 }
 
-template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 steps)
+template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 steps, u32 notrace)
 {
   DevState& d = b->d;
   size_t lds = (size_t)d.lpw * WSP_XSLOTS * 8 * (FP ? 2 : 1);
   hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps);
+  hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps, notrace);
   return hipGetLastError();
 }
 
@@ -1377,12 +1506,24 @@ extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flag
   u64 remaining = max_steps; u32 running = 0;
   b->last_kernel_s = 0; b->last_launches = 0;
   bool trace = (flags & WSP_RUN_TRACE_HASH) != 0;
+  // The lean TRACE = false kernels only for untraced batches whose every wave runs a single program image (their converged
+  // loop); any other untraced batch runs the TRACE = true kernel with `notrace` set.
+  bool lean = !trace;
+  if (lean) {
+    const DevState& d = b->d;
+    for (u32 w = 0; w < d.n_waves && lean; ++w) {
+      const u32 h0 = w * d.lpw, h1 = std::min(d.n_harts, h0 + d.lpw), pg = b->hart_prog[h0];
+      if (pg == ~0u) lean = false;
+      for (u32 h = h0 + 1; h < h1 && lean; ++h) lean = b->hart_prog[h] == pg;
+    }
+  }
+  const u32 nt = trace ? 0u : 1u;
   do {
     u64 n = std::min(remaining, SLICE);
     HIPOK(hipMemsetAsync(b->d.running, 0, 4, b->stream));
     HIPOK(hipEventRecord(b->ev0, b->stream));
-    hipError_t e = trace ? (b->has_fp ? launch_step<true, true>(b, n) : launch_step<true, false>(b, n))
-                         : (b->has_fp ? launch_step<false, true>(b, n) : launch_step<false, false>(b, n));
+    hipError_t e = !lean ? (b->has_fp ? launch_step<true, true>(b, n, nt) : launch_step<true, false>(b, n, nt))
+                         : (b->has_fp ? launch_step<false, true>(b, n, nt) : launch_step<false, false>(b, n, nt));
     if (e != hipSuccess) return fail(WSP_EHIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     HIPOK(hipEventRecord(b->ev1, b->stream));
     HIPOK(hipMemcpyAsync(&running, b->d.running, 4, hipMemcpyDeviceToHost, b->stream));
@@ -1499,8 +1640,8 @@ extern "C" int wsp_batch_snapshot(wsp_batch* b)
 {
   if (!b) return fail(WSP_EINVAL, "null batch");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[11]; snap_parts(b, parts);
-  for (int i = 0; i < 11; ++i) {
+  SnapPart parts[WSP_SNAP_PARTS]; snap_parts(b, parts);
+  for (int i = 0; i < WSP_SNAP_PARTS; ++i) {
     if (!parts[i].bytes) continue;
     if (!b->snap[i]) { if (hipMalloc(&b->snap[i], parts[i].bytes) != hipSuccess) return fail(WSP_ENOMEM, "snapshot allocation failed"); }
     HIPOK(hipMemcpyAsync(b->snap[i], parts[i].live, parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
@@ -1514,8 +1655,8 @@ extern "C" int wsp_batch_restore(wsp_batch* b)
   if (!b) return fail(WSP_EINVAL, "null batch");
   if (!b->snap[0]) return fail(WSP_EINVAL, "no snapshot taken");
   HIPOK(hipSetDevice(b->device));
-  SnapPart parts[11]; snap_parts(b, parts);
-  for (int i = 0; i < 11; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
+  SnapPart parts[WSP_SNAP_PARTS]; snap_parts(b, parts);
+  for (int i = 0; i < WSP_SNAP_PARTS; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   HIPOK(hipStreamSynchronize(b->stream));
   return WSP_OK;
 }
