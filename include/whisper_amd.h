@@ -100,6 +100,10 @@ void wsp_batch_destroy(wsp_batch* b);
 int  wsp_batch_load_elf(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, const char* path);
 /* Same from an in-memory ELF image. */
 int  wsp_batch_load_elf_mem(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, const void* elf, size_t n);
+/* System::loadElfFiles (System.cpp:288) for `count` systems at once: ELF image i goes to the harts_per_elf harts starting at
+ * hart_lo + i * harts_per_elf.  Same result as `count` calls of wsp_batch_load_elf_mem, with one staging upload, one scatter
+ * launch and one pre-decode launch for all of them (BASELINE configs[4]: 125 000 distinct programs per GPU). */
+int  wsp_batch_load_elf_many(wsp_batch* b, uint32_t hart_lo, uint32_t count, const void* const* elfs, const size_t* sizes, uint32_t harts_per_elf);
 /* System::loadHexFiles/loadBinaryFiles / Hart::pokeMemory (System.cpp:363,434; Hart.cpp:1345). */
 int  wsp_batch_load_image(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t addr, const void* bytes, size_t n, uint32_t flags);
 /* Address of an ELF symbol of the last ELF loaded into `hart` (Memory::findElfSymbol). */

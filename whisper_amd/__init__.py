@@ -84,6 +84,7 @@ def lib():
         L.wsp_batch_destroy.argtypes = [vp]
         L.wsp_batch_load_elf.argtypes = [vp, u32, u32, C.c_char_p]
         L.wsp_batch_load_elf_mem.argtypes = [vp, u32, u32, C.c_char_p, C.c_size_t]
+        L.wsp_batch_load_elf_many.argtypes = [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), u32]
         L.wsp_batch_load_image.argtypes = [vp, u32, u32, u64, C.c_char_p, C.c_size_t, u32]
         L.wsp_batch_symbol.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
         L.wsp_batch_poke.argtypes = [vp, u32, u32, u64, C.c_void_p, C.c_size_t]
@@ -161,6 +162,13 @@ class Batch:
     def load_elf_bytes(self, elf: bytes, lo=None, hi=None):
         lo, hi = self._rng(lo, hi)
         _check(self.L.wsp_batch_load_elf_mem(self.h, lo, hi, elf, len(elf)))
+
+    def load_elfs(self, elfs, lo=0, harts_per_elf=1):
+        """wsp_batch_load_elf_many: ELF image i -> harts [lo + i * harts_per_elf, lo + (i + 1) * harts_per_elf), one call."""
+        n = len(elfs)
+        ptrs = (C.c_char_p * n)(*elfs)
+        sizes = (C.c_size_t * n)(*[len(e) for e in elfs])
+        _check(self.L.wsp_batch_load_elf_many(self.h, lo, n, ptrs, sizes, harts_per_elf))
 
     def load_image(self, addr, data: bytes, lo=None, hi=None, executable=False):
         lo, hi = self._rng(lo, hi)

@@ -904,6 +904,7 @@ static int scratch_of(int dev, u64** out)
 struct Program {
   u64 text_lo = 0, text_hi = 0;
   Rec* d_recs = nullptr;
+  bool pooled = false;                 // d_recs points into one of the batch's rec_pools (wsp_batch_load_elf_many)
   std::map<std::string, u64> symbols;
 };
 
@@ -915,6 +916,7 @@ struct wsp_batch {
   std::vector<Program> progs;
   std::vector<u32> hart_prog;          // host copy, index = hart
   std::vector<u64> hart_stop_pc;       // host copy of the stop addresses (~0: none)
+  std::vector<Rec*> rec_pools;         // record allocations shared by many programs
   ProgDev* d_progs = nullptr; size_t d_progs_cap = 0;
   DevState* d_state = nullptr;
   u64* d_memhash = nullptr; wsp_result* d_results = nullptr;
@@ -981,7 +983,8 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
 {
   if (!b) return;
   hipSetDevice(b->device);
-  for (auto& p : b->progs) if (p.d_recs) hipFree(p.d_recs);
+  for (auto& p : b->progs) if (p.d_recs && !p.pooled) hipFree(p.d_recs);
+  for (Rec* p : b->rec_pools) hipFree(p);
   void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state, b->d.ring, b->d.ring_pos, b->d.max_ret, b->d.stop_pc };
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : b->snap) if (p) hipFree(p);
@@ -1237,10 +1240,17 @@ struct Elf64_Phdr_ { u32 type, flags; u64 offset, vaddr, paddr, filesz, memsz, a
 struct Elf64_Shdr_ { u32 name, type; u64 flags, addr, offset, size; u32 link, info; u64 addralign, entsize; };
 struct Elf64_Sym_ { u32 name; u8 info, other; u16 shndx; u64 value, size; };
 
-extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, const void* elf, size_t n)
+// What one ELF file asks of a hart (Memory::loadElfFile, Memory.cpp:450-489, 687; System::loadElfFiles, System.cpp:288-354).
+struct ElfSeg { u64 paddr, file_off, size; };
+struct ParsedElf {
+  std::vector<ElfSeg> loads;            // PT_LOAD segments, p_filesz bytes each, by physical address
+  std::vector<u8> text; u64 text_lo = 0;   // the executable span [text_lo, text_lo + text.size()), gaps zero-filled
+  std::map<std::string, u64> syms;
+  u64 entry = 0, gp = 0, tdata = 0, tohost = ~0ULL;
+};
+
+static int parse_elf(const DevState& d, const void* elf, size_t n, ParsedElf& out)
 {
-  int rc = check_range(b, lo, hi); if (rc) return rc;
-  HIPOK(hipSetDevice(b->device));
   const u8* e = (const u8*)elf;
   if (!e || n < sizeof(Elf64_Ehdr_) || memcmp(e, "\177ELF", 4) != 0) return fail(WSP_EFORMAT, "not an ELF file");
   if (e[4] != 2) return fail(WSP_EFORMAT, "ELF class is not 64-bit");        // Session.cpp:1373-1424 xlen from ELF class
@@ -1251,21 +1261,18 @@ extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, co
   if (eh.phnum && eh.phentsize != sizeof(Elf64_Phdr_)) return fail(WSP_EFORMAT, "unexpected program header entry size");
   if (eh.shnum && eh.shentsize != sizeof(Elf64_Shdr_)) return fail(WSP_EFORMAT, "unexpected section header entry size");
   if (!in_file(eh.phoff, (u64)eh.phnum * sizeof(Elf64_Phdr_))) return fail(WSP_EFORMAT, "program headers out of file");
-  DevState& d = b->d;
   u64 xlo = ~0ULL, xhi = 0;
-  std::vector<Elf64_Phdr_> loads;
+  std::vector<Elf64_Phdr_> xs;
   for (u32 i = 0; i < eh.phnum; ++i) {
     Elf64_Phdr_ ph; memcpy(&ph, e + eh.phoff + (u64)i * eh.phentsize, sizeof ph);
     if (ph.type != 1 || ph.filesz == 0) continue;                            // PT_LOAD, p_filesz bytes only (Memory.cpp:450-489)
     if (!in_file(ph.offset, ph.filesz)) return fail(WSP_EFORMAT, "segment out of file");
     if (ph.paddr < d.mem_base || ph.paddr - d.mem_base > d.mem_size - ph.filesz || ph.filesz > d.mem_size)
       return fail(WSP_ERANGE, "ELF segment outside the hart arena");
-    loads.push_back(ph);
-    if (ph.flags & 1) { xlo = std::min(xlo, ph.paddr); xhi = std::max(xhi, ph.paddr + ph.filesz); }
+    out.loads.push_back({ ph.paddr, ph.offset, ph.filesz });
+    if (ph.flags & 1) { xlo = std::min(xlo, ph.paddr); xhi = std::max(xhi, ph.paddr + ph.filesz); xs.push_back(ph); }
   }
-  for (auto& ph : loads) { rc = write_arena(b, lo, hi, ph.paddr, e + ph.offset, ph.filesz); if (rc) return rc; }
   // symbols + .tdata
-  std::map<std::string, u64> syms; u64 tdata = 0;
   if (eh.shoff && in_file(eh.shoff, (u64)eh.shnum * sizeof(Elf64_Shdr_))) {
     std::vector<Elf64_Shdr_> sh(eh.shnum);
     for (u32 i = 0; i < eh.shnum; ++i) memcpy(&sh[i], e + eh.shoff + (u64)i * eh.shentsize, sizeof(Elf64_Shdr_));
@@ -1278,35 +1285,170 @@ extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, co
     const Elf64_Shdr_* shstr = eh.shstrndx < eh.shnum ? &sh[eh.shstrndx] : nullptr;
     for (u32 i = 0; i < eh.shnum; ++i) {
       const char* sn = shstr ? name_at(*shstr, sh[i].name) : nullptr;
-      if (sn && strcmp(sn, ".tdata") == 0) tdata = sh[i].addr;
+      if (sn && strcmp(sn, ".tdata") == 0) out.tdata = sh[i].addr;
       if (sh[i].type != 2 || sh[i].link >= eh.shnum || !in_file(sh[i].offset, sh[i].size)) continue;   // SHT_SYMTAB
       const Elf64_Shdr_& st = sh[sh[i].link];
       size_t cnt = sh[i].size / sizeof(Elf64_Sym_);
       for (size_t k = 0; k < cnt; ++k) {
         Elf64_Sym_ sy; memcpy(&sy, e + sh[i].offset + k * sizeof(Elf64_Sym_), sizeof sy);
         const char* nm = name_at(st, sy.name);
-        if (nm && *nm) syms[nm] = sy.value;
+        if (nm && *nm) out.syms[nm] = sy.value;
       }
     }
   }
-  std::vector<u8> text;
   if (xlo < xhi) {
     if (xhi - xlo > (64u << 20)) return fail(WSP_EUNSUPPORTED, "executable span larger than 64 MiB");
-    text.assign(xhi - xlo, 0);
-    for (auto& ph : loads) if (ph.flags & 1) memcpy(text.data() + (ph.paddr - xlo), e + ph.offset, ph.filesz);
+    out.text.assign(xhi - xlo, 0); out.text_lo = xlo;
+    for (auto& ph : xs) memcpy(out.text.data() + (ph.paddr - xlo), e + ph.offset, ph.filesz);
   }
-  rc = add_program(b, lo, hi, xlo < xhi ? xlo : 0, text, syms); if (rc) return rc;
+  out.entry = eh.entry;
+  auto gp = out.syms.find("__global_pointer$"); if (gp != out.syms.end()) out.gp = gp->second;
+  auto th = out.syms.find("tohost"); if (th != out.syms.end()) out.tohost = th->second;
+  return WSP_OK;
+}
+
+// Fill x[reg] of harts [lo, hi) with v where the register is still zero (System.cpp:334-354: gp / tp are set only when unset).
+__global__ void wsp_set_if_zero_kernel(DevState d, u32 lo, u32 hi, u32 reg, u64 v)
+{
+  const u32 h = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= hi) return;
+  u64* p = d.x + (size_t)reg * d.S + slot_of(d, h);
+  if (*p == 0) *p = v;
+}
+
+extern "C" int wsp_batch_load_elf_mem(wsp_batch* b, uint32_t lo, uint32_t hi, const void* elf, size_t n)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d;
+  ParsedElf pe;
+  rc = parse_elf(d, elf, n, pe); if (rc) return rc;
+  for (auto& sg : pe.loads) { rc = write_arena(b, lo, hi, sg.paddr, (const u8*)elf + sg.file_off, sg.size); if (rc) return rc; }
+  rc = add_program(b, lo, hi, pe.text.empty() ? 0 : pe.text_lo, pe.text, pe.syms); if (rc) return rc;
   // pc = entry, gp, tp (System.cpp:334-354); tohost (System.cpp:323)
-  if (eh.entry) { rc = set_u64_slots(b, d.hot64 + (size_t)H64_PC * d.S, lo, hi, eh.entry & ~1ULL); if (rc) return rc; }
-  auto gp = syms.find("__global_pointer$");
-  for (u32 h = lo; h < hi; ++h) {
-    u64 cur = 0; u32 s = slot_of(d, h);
-    if (gp != syms.end() && gp->second) { HIPOK(hipMemcpy(&cur, d.x + (size_t)3 * d.S + s, 8, hipMemcpyDeviceToHost)); if (!cur) HIPOK(hipMemcpy(d.x + (size_t)3 * d.S + s, &gp->second, 8, hipMemcpyHostToDevice)); }
-    if (tdata) { HIPOK(hipMemcpy(&cur, d.x + (size_t)4 * d.S + s, 8, hipMemcpyDeviceToHost)); if (!cur) HIPOK(hipMemcpy(d.x + (size_t)4 * d.S + s, &tdata, 8, hipMemcpyHostToDevice)); }
-    if (gp == syms.end() && !tdata) break;
+  if (pe.entry) { rc = set_u64_slots(b, d.hot64 + (size_t)H64_PC * d.S, lo, hi, pe.entry & ~1ULL); if (rc) return rc; }
+  const unsigned grid = (hi - lo + 255) / 256;
+  if (pe.gp) hipLaunchKernelGGL(wsp_set_if_zero_kernel, dim3(grid), dim3(256), 0, b->stream, d, lo, hi, 3u, pe.gp);
+  if (pe.tdata) hipLaunchKernelGGL(wsp_set_if_zero_kernel, dim3(grid), dim3(256), 0, b->stream, d, lo, hi, 4u, pe.tdata);
+  if (pe.gp || pe.tdata) { HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream)); }
+  if (pe.tohost != ~0ULL) { rc = set_u64_slots(b, d.tohost, lo, hi, pe.tohost); if (rc) return rc; }
+  return WSP_OK;
+}
+
+// ---- many ELF files in one call (BASELINE configs[4]: 125 000 distinct programs per GPU).  One staging upload, one scatter
+// launch, one pre-decode launch, one upload each of the program table and the per-hart rows; nothing per program on the device.
+struct ManySeg { u64 src_off, arena_off, n; u32 hart_lo, hart_hi; };
+struct ManyProg { u64 img_off, n_bytes, rec_off; };
+
+// block = one segment: its bytes go to every hart of [hart_lo, hart_hi) (consecutive threads -> consecutive harts)
+__global__ void wsp_scatter_many_kernel(DevState d, const ManySeg* segs, const u8* src)
+{
+  const ManySeg sg = segs[blockIdx.x];
+  const u64 w0 = sg.arena_off >> 3, nw = ((sg.arena_off + sg.n + 7) >> 3) - w0, nh = sg.hart_hi - sg.hart_lo;
+  for (u64 i = threadIdx.x; i < nw * nh; i += blockDim.x) {
+    const u32 hart = sg.hart_lo + (u32)(i % nh);
+    const u64 bo = (w0 + i / nh) << 3;
+    u8* dst = d.arena + arena_off(d, hart, bo);
+    for (u32 k = 0; k < 8; ++k) { const u64 a = bo + k; if (a >= sg.arena_off && a < sg.arena_off + sg.n) dst[k] = src[sg.src_off + (a - sg.arena_off)]; }
   }
-  auto th = syms.find("tohost");
-  if (th != syms.end()) { rc = set_u64_slots(b, d.tohost, lo, hi, th->second); if (rc) return rc; }
+}
+
+// block = one program: pre-decode its image exactly as wsp_predecode_kernel does
+__global__ void wsp_predecode_many_kernel(const ManyProg* progs, const u8* imgs, u32 isa, Rec* recs)
+{
+  const ManyProg p = progs[blockIdx.x];
+  const u8* img = imgs + p.img_off; Rec* out = recs + p.rec_off;
+  const u64 nslots = p.n_bytes / 2;
+  for (u64 i = threadIdx.x; i < nslots + 2; i += blockDim.x) {
+    const u64 off = i * 2; Rec r;
+    if (off + 2 > p.n_bytes) r = mk(OP_SLOWFETCH, 0, 0, 0, 0);
+    else {
+      const u32 lo = img[off] | ((u32)img[off + 1] << 8);
+      if ((lo & 3) != 3) r = decode16(lo, isa);
+      else if (off + 4 <= p.n_bytes) r = decode32(lo | ((u32)img[off + 2] << 16) | ((u32)img[off + 3] << 24), isa);
+      else { r = mk(OP_SLOWFETCH, 0, 0, 0, 0); r.raw = lo; }
+    }
+    finish_rec(r);
+    out[i] = r;
+  }
+}
+
+extern "C" int wsp_batch_load_elf_many(wsp_batch* b, uint32_t hart_lo, uint32_t count, const void* const* elfs, const size_t* sizes, uint32_t harts_per_elf)
+{
+  if (!b || !elfs || !sizes) return fail(WSP_EINVAL, "null argument");
+  if (count == 0 || harts_per_elf == 0) return fail(WSP_EINVAL, "count and harts_per_elf must be > 0");
+  if ((u64)count * harts_per_elf > 0xffffffffULL - hart_lo) return fail(WSP_ERANGE, "hart range out of bounds");
+  const u32 hart_hi = hart_lo + count * harts_per_elf;
+  int rc = check_range(b, hart_lo, hart_hi); if (rc) return rc;
+  HIPOK(hipSetDevice(b->device));
+  DevState& d = b->d; const size_t S = d.S;
+  std::vector<ParsedElf> pes(count);
+  std::vector<ManySeg> segs; std::vector<ManyProg> mps(count);
+  std::vector<u8> stage, imgs;
+  u64 rec_total = 0;
+  for (u32 i = 0; i < count; ++i) {
+    rc = parse_elf(d, elfs[i], sizes[i], pes[i]);
+    if (rc) { g_err = "ELF " + std::to_string(i) + ": " + g_err; return rc; }
+    const u32 lo = hart_lo + i * harts_per_elf, hi = lo + harts_per_elf;
+    for (auto& sg : pes[i].loads) {
+      segs.push_back({ (u64)stage.size(), sg.paddr - d.mem_base, sg.size, lo, hi });
+      stage.insert(stage.end(), (const u8*)elfs[i] + sg.file_off, (const u8*)elfs[i] + sg.file_off + sg.size);
+    }
+    const u64 nb = pes[i].text.size() & ~(size_t)1;
+    if (nb / 2 >= (1u << 29)) return fail(WSP_ERANGE, "code image of 1 GiB or more");
+    mps[i] = { (u64)imgs.size(), nb, rec_total };
+    imgs.insert(imgs.end(), pes[i].text.begin(), pes[i].text.begin() + nb);
+    rec_total += nb ? nb / 2 + 2 : 0;
+  }
+  DevBuf dstage, dsegs, dimgs, dmps, drecs;
+  if (!segs.empty()) {
+    HIPOK(dstage.alloc(stage.size())); HIPOK(hipMemcpy(dstage.p, stage.data(), stage.size(), hipMemcpyHostToDevice));
+    HIPOK(dsegs.alloc(segs.size() * sizeof(ManySeg))); HIPOK(hipMemcpy(dsegs.p, segs.data(), segs.size() * sizeof(ManySeg), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(wsp_scatter_many_kernel, dim3((unsigned)segs.size()), dim3(256), 0, b->stream, d, dsegs.as<ManySeg>(), dstage.as<u8>());
+    HIPOK(hipGetLastError());
+  }
+  Rec* recs_base = nullptr;
+  if (rec_total) {
+    HIPOK(dimgs.alloc(imgs.size())); HIPOK(hipMemcpy(dimgs.p, imgs.data(), imgs.size(), hipMemcpyHostToDevice));
+    HIPOK(dmps.alloc(count * sizeof(ManyProg))); HIPOK(hipMemcpy(dmps.p, mps.data(), count * sizeof(ManyProg), hipMemcpyHostToDevice));
+    HIPOK(drecs.alloc(rec_total * sizeof(Rec)));
+    hipLaunchKernelGGL(wsp_predecode_many_kernel, dim3(count), dim3(128), 0, b->stream, dmps.as<ManyProg>(), dimgs.as<u8>(), d.isa, drecs.as<Rec>());
+    HIPOK(hipGetLastError());
+    recs_base = drecs.as<Rec>();
+  }
+  HIPOK(hipStreamSynchronize(b->stream));
+  if (recs_base) { b->rec_pools.push_back(recs_base); drecs.p = nullptr; }     // one allocation for all images, owned by the batch
+  // program table + per-hart rows, each uploaded once
+  const u32 id0 = (u32)b->progs.size();
+  for (u32 i = 0; i < count; ++i) {
+    Program p; p.symbols = std::move(pes[i].syms);
+    if (mps[i].n_bytes) { p.text_lo = pes[i].text_lo; p.text_hi = p.text_lo + mps[i].n_bytes; p.d_recs = recs_base + mps[i].rec_off; p.pooled = true; }
+    b->progs.push_back(std::move(p));
+  }
+  rc = upload_progs(b); if (rc) return rc;
+  std::vector<u32> prow(S); std::vector<u64> pcrow(S), throw_(S), gprow(S), tprow(S);
+  HIPOK(hipMemcpy(prow.data(), d.prog, S * 4, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(pcrow.data(), d.hot64 + (size_t)H64_PC * S, S * 8, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(throw_.data(), d.tohost, S * 8, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(gprow.data(), d.x + (size_t)3 * S, S * 8, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(tprow.data(), d.x + (size_t)4 * S, S * 8, hipMemcpyDeviceToHost));
+  for (u32 i = 0; i < count; ++i) {
+    const ParsedElf& pe = pes[i];
+    for (u32 h = hart_lo + i * harts_per_elf; h < hart_lo + (i + 1) * harts_per_elf; ++h) {
+      const u32 s = slot_of(d, h);
+      prow[s] = id0 + i; b->hart_prog[h] = id0 + i;
+      if (pe.entry) pcrow[s] = pe.entry & ~1ULL;
+      if (pe.tohost != ~0ULL) throw_[s] = pe.tohost;
+      if (pe.gp && !gprow[s]) gprow[s] = pe.gp;
+      if (pe.tdata && !tprow[s]) tprow[s] = pe.tdata;
+      if (b->hart_stop_pc[h] != ~0ULL) { rc = patch_stop(b, id0 + i, b->hart_stop_pc[h]); if (rc) return rc; }
+    }
+  }
+  HIPOK(hipMemcpy(d.prog, prow.data(), S * 4, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(d.hot64 + (size_t)H64_PC * S, pcrow.data(), S * 8, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(d.tohost, throw_.data(), S * 8, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(d.x + (size_t)3 * S, gprow.data(), S * 8, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(d.x + (size_t)4 * S, tprow.data(), S * 8, hipMemcpyHostToDevice));
   return WSP_OK;
 }
 
