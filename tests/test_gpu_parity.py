@@ -372,3 +372,121 @@ def test_commit_ring_against_reference_rvv_capture():
             assert img.startswith(v["head"]) and img.endswith(v["tail"])
     finally:
         b.close()
+
+
+def _variant(p, k):
+    """A distinct program from a generated one: the k-th variant XORs k into the immediate field of one 32-bit word of the code
+    (both in the ELF image and in the segment list the oracle loads).  Whatever the patched word decodes to - another immediate,
+    another instruction, an illegal one - device and oracle run the same bytes."""
+    if k == 0:
+        return p
+    import copy
+    paddr, data, flags = p.segments[0]
+    off = (len(data) // 2 + 4 * (k % 17)) & ~3
+    word = int.from_bytes(data[off:off + 4], "little") ^ ((k & 0xfff) << 20)
+    q = copy.copy(p)
+    nd = data[:off] + word.to_bytes(4, "little") + data[off + 4:]
+    q.segments = [(paddr, nd, flags)] + list(p.segments[1:])
+    at = p.elf.find(data)
+    assert at >= 0
+    q.elf = p.elf[:at] + nd + p.elf[at + len(data):]
+    q.name = f"{p.name}.v{k}"
+    return q
+
+
+def test_load_elf_many_equals_one_by_one():
+    """wsp_batch_load_elf_many against wsp_batch_load_elf_mem called per program: same results, hart for hart."""
+    progs = [_variant(WL.sv39_program(s % 8), s // 8) for s in range(64)]
+    p0 = progs[0]
+    res = []
+    for many in (False, True):
+        b = W.Batch(len(progs) * 2, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, tlb_entries=p0.meta.get("tlb_entries", 0))
+        try:
+            if many:
+                b.load_elfs([p.elf for p in progs], harts_per_elf=2)
+            else:
+                for i, p in enumerate(progs):
+                    b.load_elf_bytes(p.elf, 2 * i, 2 * i + 2)
+            b.set_stop(max_inst=p0.max_inst)
+            assert b.run(trace_hash=True) == 0
+            res.append([r.as_dict() for r in b.results()])
+            assert b.symbol(5, "tohost") == progs[2].symbols["tohost"]
+        finally:
+            b.close()
+    assert res[0] == res[1]
+    for i in (0, 9, 63):
+        ro, _, _ = S.run_oracle(progs[i], hart_id=2 * i)
+        assert res[1][2 * i] == ro, progs[i].name
+
+
+def test_fuzz_sv39_100k_distinct_programs():
+    """BASELINE config 4's per-GPU share in kind: 102 400 *distinct* Sv39 fuzz programs (2048 generated programs x 50 code variants),
+    one hart each, loaded in chunks through wsp_batch_load_elf_many, 8-entry TLBs, trace digests on.  The oracle runs a 1 % sample
+    (every 100th program) and every program whose device status is neither a tohost stop nor the instruction limit."""
+    import time
+    nb, nv = 2048, 50
+    t0 = time.time()
+    bases = [WL.sv39_program(s) for s in range(nb)]
+    gen_s = time.time() - t0
+    p0 = bases[0]
+    n = nb * nv
+    b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, tlb_entries=p0.meta.get("tlb_entries", 0))
+    try:
+        t0 = time.time()
+        chunk = 64                                           # bases per call: 3200 programs, ~0.6 GB of ELF bytes
+        for c in range(0, nb, chunk):
+            b.load_elfs([_variant(bases[i], k).elf for i in range(c, c + chunk) for k in range(nv)], lo=c * nv)
+        load_s = time.time() - t0
+        b.set_stop(max_inst=p0.max_inst)
+        t0 = time.time()
+        assert b.run(trace_hash=True) == 0
+        run_s = time.time() - t0
+        secs = b.run_stats()[0]
+        res = [r.as_dict() for r in b.results()]
+    finally:
+        b.close()
+    total = sum(r["exec"] for r in res)
+    print(f"100k distinct sv39 programs: generate {gen_s:.1f} s, load {load_s:.1f} s, run {run_s:.2f} s (kernel {secs:.3f} s), "
+          f"{total} instructions = {total / secs / 1e9:.3f} GIPS")
+    odd = [h for h, r in enumerate(res) if r["status"] not in (W.ST_STOP_TOHOST, W.ST_STOP_LIMIT)]
+    sample = sorted(set(range(0, n, 100)) | set(odd[:200]))
+    assert len(sample) >= n // 100
+    for h in sample:
+        q = _variant(bases[h // nv], h % nv)
+        ro, _, _ = S.run_oracle(q, hart_id=h)
+        assert res[h] == ro, (h, q.name)
+    assert len(set(r["trace_hash"] for r in res)) > n // 2   # the variants really are different programs
+
+
+def test_cli_and_riscof_batch(tmp_path):
+    """Row f4: the whisper-compatible command line (what riscof_whisper.py:152 invokes) and the RISCOF plugin's batched run: every
+    generated arch-test program in one batch, signature files in System::produceTestSignatureFile's format, equal to the oracle's
+    memory; exit status 0 iff the run succeeded."""
+    from whisper_amd import cli
+    from whisper_amd.riscof_plugin import riscof_whisper_amd as RP
+    progs = WL.archtest_suite()[:24]
+    tests = []
+    for i, p in enumerate(progs):
+        e = tmp_path / f"t{i}.elf"; e.write_bytes(p.elf)
+        tests.append((str(e), str(tmp_path / f"t{i}.signature")))
+    assert RP.isa_string("RV64IMAFDCZicsr", "64") == "rv64imafdc_zicsr"
+    assert all(RP.run_batch(tests, progs[0].isa))
+    for (e, s), p in zip(tests, progs):
+        _, h, _ = S.run_oracle(p)
+        lo, hi = p.symbols["begin_signature"], p.symbols["end_signature"]
+        want = h.read_mem(lo, hi - lo)
+        assert open(s).read() == "".join(f"{int.from_bytes(want[k:k + 4], 'little'):08x}\n" for k in range(0, len(want), 4)), p.name
+    # single target through main(): signature, log file, exit status
+    sig, log = tmp_path / "one.sig", tmp_path / "one.log"
+    assert cli.main(["--isa", progs[3].isa, "--target", tests[3][0], "--testsignature", str(sig), "--logfile", str(log), "--quiet"]) == 0
+    assert sig.read_text() == open(tests[3][1]).read()
+    ro, _, olog = S.run_oracle(progs[3], log_cap=100000)
+    lines = log.read_text().splitlines()
+    assert len([ln for ln in lines if not ln.endswith("+")]) == len(olog) == ro["exec"]
+    # a failing program (tohost value 3 = test 1 failed) and the instruction limit under --failoninstlimit
+    rp = WL.readme_program()
+    e = tmp_path / "r.elf"; e.write_bytes(rp.elf)
+    assert cli.main(["--isa", rp.isa, "--target", str(e), "--quiet"]) == 0
+    assert cli.main(["--isa", rp.isa, "--target", str(e), "--maxinst", "3", "--quiet"]) == 0
+    assert cli.main(["--isa", rp.isa, "--target", str(e), "--maxinst", "3", "--failoninstlimit", "--quiet"]) == 1
+    assert cli.main(["--isa", rp.isa, "--target", str(e), "--harts", "5", "--quiet"]) == 0

@@ -1390,9 +1390,27 @@ extern "C" int wsp_batch_load_elf_many(wsp_batch* b, uint32_t hart_lo, uint32_t 
     rc = parse_elf(d, elfs[i], sizes[i], pes[i]);
     if (rc) { g_err = "ELF " + std::to_string(i) + ": " + g_err; return rc; }
     const u32 lo = hart_lo + i * harts_per_elf, hi = lo + harts_per_elf;
-    for (auto& sg : pes[i].loads) {
-      segs.push_back({ (u64)stage.size(), sg.paddr - d.mem_base, sg.size, lo, hi });
-      stage.insert(stage.end(), (const u8*)elfs[i] + sg.file_off, (const u8*)elfs[i] + sg.file_off + sg.size);
+    // Segments are loaded in file order, so where two overlap the later one wins (Memory.cpp:450-489).  All pieces are scattered
+    // by one launch here, in no particular order: keep of every segment only the parts no later segment covers.
+    std::vector<std::pair<u64, u64>> covered;            // [lo, hi) byte ranges of the later segments
+    for (size_t k = pes[i].loads.size(); k-- > 0;) {
+      const ElfSeg& sg = pes[i].loads[k];
+      std::vector<std::pair<u64, u64>> keep{ { sg.paddr, sg.paddr + sg.size } };
+      for (auto& c : covered) {
+        std::vector<std::pair<u64, u64>> nx;
+        for (auto& r : keep) {
+          if (c.second <= r.first || c.first >= r.second) { nx.push_back(r); continue; }
+          if (c.first > r.first) nx.push_back({ r.first, c.first });
+          if (c.second < r.second) nx.push_back({ c.second, r.second });
+        }
+        keep.swap(nx);
+      }
+      for (auto& r : keep) {
+        segs.push_back({ (u64)stage.size(), r.first - d.mem_base, r.second - r.first, lo, hi });
+        const u8* src = (const u8*)elfs[i] + sg.file_off + (r.first - sg.paddr);
+        stage.insert(stage.end(), src, src + (r.second - r.first));
+      }
+      covered.push_back({ sg.paddr, sg.paddr + sg.size });
     }
     const u64 nb = pes[i].text.size() & ~(size_t)1;
     if (nb / 2 >= (1u << 29)) return fail(WSP_ERANGE, "code image of 1 GiB or more");
