@@ -132,6 +132,12 @@ unsigned  rvo_translate_noupdate(rvo_hart* h, uint64_t va, unsigned pm, unsigned
 void      rvo_sfence(rvo_hart* h, int has_addr, uint64_t addr, int has_asid, uint64_t asid);
 /* digest of the TLB contents (same packing as the device) */
 uint64_t  rvo_tlb_hash(const rvo_hart* h);
+/* Test hooks over the vector restatement (rv_oracle_vec.inc) for pinning against the reference's VecRegs / float-util.hpp:
+ * what = 0 dest-active(vd, ix, log2 bytes, masked) -> active, *out = value to write when inactive; 1 valid-index(reg, ix,
+ * groupx8, log2 bytes); 2 elemMax(eew); 3 vlmax; 4 mask bit (reg, ix); 5 write mask bit (reg, ix, v); 6 groupMultiplierX8(gm);
+ * 7 legalConfig(sew, gm); 8 write element (reg, ix, log2 bytes, groupx8) = *out. */
+int       rvo_vec_probe(rvo_hart* h, unsigned what, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t* out);
+uint64_t  rvo_vf_probe(unsigned kind, unsigned esz, uint64_t a, uint64_t b, uint64_t c, unsigned rm, unsigned* flags);
 uint64_t  rvo_fold(uint64_t h, uint64_t w);
 uint64_t  rvo_mix(uint64_t x);
 
