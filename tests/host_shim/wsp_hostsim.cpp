@@ -19,6 +19,9 @@ struct HostMem {
   void wf(u32 r, u64 v) { f[r] = v; }
   u64& cold(u32 i) { return cold_[i]; }
   u64& tlb(u32 i) { return tlb_[i]; }
+  u32 xlane_or(u32 v) const { return v; }            // one lane per hart on the host
+  u32 xlane_min(u32 v) const { return v; }
+  void xlane_fence() const {}
   u64 vld(u32 o, u32 esz) const { u64 v = 0; memcpy(&v, vreg_ + o, (size_t)1 << esz); return v; }
   void vst(u32 o, u32 esz, u64 v) { memcpy(vreg_ + o, &v, (size_t)1 << esz); }
   u8 ld8(u64 o) const { return ram[o]; }
@@ -74,7 +77,7 @@ Sim* hs_create3(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u3
   s->L.m.cold_[CI_VTYPE] = 1ULL << 63;
   s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
   s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
-  s->max_exec = ~0ULL; s->L.stop_pc = ~0ULL;
+  s->max_exec = ~0ULL; s->L.stop_pc = ~0ULL; s->L.vsub = 0; s->L.vgrp = 1;
   return s;
 }
 Sim* hs_create(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id) { return hs_create2(isa, mem_base, mem_size, tohost, hart_id, 0); }

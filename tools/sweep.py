@@ -25,9 +25,11 @@ def main():
     ap.add_argument("--lanes", default="0")
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--workload", default="compute", choices=["compute", "compute_int", "sv39", "rvv", "fuzz"])
+    ap.add_argument("--workload", default="compute", choices=["compute", "compute_int", "sv39", "rvv", "rvvk", "fuzz"])
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--vlenb", type=int, default=64)
+    ap.add_argument("--n", type=int, default=1024, help="rvvk: elements per array")
     args = ap.parse_args()
 
     import whisper_amd as W
@@ -37,6 +39,9 @@ def main():
         for lanes in [int(x) for x in args.lanes.split(",")]:
             if args.workload in ("compute", "compute_int"):
                 prog = WL.compute_kernel(iters=args.iters, fp=args.workload == "compute")
+                progs, reps = [prog], n
+            elif args.workload == "rvvk":
+                prog = WL.rvv_kernel(n=args.n, iters=args.iters, vlenb=args.vlenb)
                 progs, reps = [prog], n
             else:
                 gen = {"sv39": WL.sv39_program, "rvv": WL.rvv_program, "fuzz": lambda s: WL.fuzz_program(s, 400)}[args.workload]
@@ -78,7 +83,7 @@ def main():
                     if not args.trace:
                         ro = dict(ro); ro["trace_hash"] = 0
                     check = ro == res[0].as_dict()
-                print(json.dumps({"workload": args.workload, "harts": n, "lanes_per_wave": lanes, "iters": args.iters, "instructions": insts,
+                print(json.dumps({"workload": args.workload, "vlenb": p0.meta.get("vlenb", 0), "harts": n, "lanes_per_wave": lanes, "iters": args.iters, "instructions": insts,
                                   "kernel_ms": best[0] * 1e3, "wall_ms": best[1] * 1e3, "launches": best[2], "kernel_gips": insts / best[0] / 1e9,
                                   "load_s": load_s, "all_stopped": ok, "oracle_hart0": check, "trace": args.trace}), flush=True)
             finally:

@@ -16,6 +16,11 @@
 #include <stdint.h>
 #include "wsp_softfloat.h"
 
+#ifndef WSP_PROF_ADD
+#define WSP_PROF_ADD(k, v) do { } while (0)
+#define WSP_PROF_T() 0ULL
+#endif
+
 namespace wsp {
 
 typedef uint64_t u64;
@@ -324,7 +329,11 @@ enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, H
              HF_FS_DIRTY = 32 /* mstatus.FS == Dirty: an FP write changes no CSR but fflags (kept by update_hot_flag) */,
              HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */,
              HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */,
-             HF_NOTRACE = 512 /* this run folds no commit records (set per launch): commit() returns at once */ };
+             HF_NOTRACE = 512 /* this run folds no commit records (set per launch): commit() returns at once */,
+             HF_VS_DIRTY = 1024 /* mstatus.VS == Dirty (kept by update_hot_flag): a vector write changes no mstatus bit */,
+             HF_DRY = 2048 /* the vector unit runs for the kernel's vector warm path (vec_call): anything that would trap, stop the
+                              hart or change mstatus raises CH_BAIL instead and changes nothing - the general path then executes the
+                              instruction in full.  Never stored */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -363,7 +372,8 @@ static constexpr u64 MSTATUS_RESET = (3ULL << MST_MPP_SH) | (0xAULL << 32);   //
 enum : u32 {
   CH_IREG = 1, CH_FREG = 2, CH_MEM = 4, CH_GEN = 8, CH_SSTATUS = 16, CH_SEPC = 32, CH_SCAUSE = 64, CH_STVAL = 128,
   CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096,
-  CH_VREG = 8192, CH_VL = 16384, CH_VTYPE = 32768
+  CH_VREG = 8192, CH_VL = 16384, CH_VTYPE = 32768,
+  CH_BAIL = 65536                  // HF_DRY: the instruction was not completed (and changed nothing)
 };
 struct Step {
   u32 chg, ireg, freg, gen_csr;
@@ -390,6 +400,16 @@ template <class MEM> struct Lane {
   u32 tlb_n;                                           // TLB entries (power of two; 0 when the ISA has no S)
   u32 vlenb;                                           // bytes per vector register (0 when the ISA has no V)
   u64* ring_ = nullptr; u32* ring_pos_ = nullptr; u32 ring_cap = 0;   // commit ring of this hart (null: not recording), see commit()
+  // Lanes-per-element mapping of the vector unit (north_star; the element loops of vector.cpp:808-855, vector-float.cpp:667-691,
+  // vector-ls.cpp:156-247).  On the GPU a hart of a V batch is stepped on the general path by a sub-group of vgrp lanes at once,
+  // all holding the same hart state and executing the same instructions in lock step - every store to hart state is the same
+  // value from every lane - except that the element loops marked "lanes" below are split: lane vsub takes the elements
+  // vsub, vsub + vgrp, ...  What the lanes compute apart (exception flags, first faulting element) is combined across the
+  // sub-group (sub_or / sub_min) before it touches hart state, so the replicas stay identical.  vgrp = 1: one lane, serial loops.
+  u32 vsub = 0, vgrp = 1;
+  WSP_HD u32 sub_or(u32 v) { return vgrp > 1 ? m.xlane_or(v) : v; }
+  WSP_HD u32 sub_min(u32 v) { return vgrp > 1 ? m.xlane_min(v) : v; }
+  WSP_HD void sub_fence() { if (vgrp > 1) m.xlane_fence(); }          // element writes of the other lanes are visible after this
 
   WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
   WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
@@ -415,7 +435,7 @@ template <class MEM> struct Lane {
   }
   WSP_HD bool fp_on() const { return ((h.mstatus >> MST_FS_SH) & 3) != 0; }                                  // isFpLegal (F folded into decode)
   WSP_HD void mark_fs_dirty()                                                                               // float.cpp:165-191
-  { if (((h.mstatus >> MST_FS_SH) & 3) != 3) { h.mstatus |= (3ULL << MST_FS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
+  { if (((h.mstatus >> MST_FS_SH) & 3) != 3 && !dry_bail()) { h.mstatus |= (3ULL << MST_FS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
   WSP_HD void or_fflags(u32 f)                                                                              // float.cpp:140-162, Hart.hpp:3821
   {
     u32 prev = h.fcsr & 0x1f, val = prev | (f & 0x1f);
@@ -423,11 +443,13 @@ template <class MEM> struct Lane {
     if (f) mark_fs_dirty();
   }
 
-  WSP_HD void stop(u32 st, u64 v) { h.status = st; h.stop_value = v; }
+  WSP_HD bool dry_bail() { if (h.flags & HF_DRY) { s.chg |= CH_BAIL; return true; } return false; }
+  WSP_HD void stop(u32 st, u64 v) { if (dry_bail()) return; h.status = st; h.stop_value = v; }
 
   // ---- traps: initiateException + initiateTrap (Hart.cpp:3324-3397, 3565-3929)
   WSP_HD void take_exception(u32 cause, u64 epc, u64 tval, bool counts)
   {
+    if (dry_bail()) return;
     if (counts) {   // di == nullptr or illegal: the consecutive-illegal stop heuristic (3329-3340)
       if (h.exec == h.exec_last_ill + 1) h.consec_ill++; else h.consec_ill = 0;
       if (h.consec_ill > 16) { stop(ST_STOP_ILLEGAL, 3); return; }
@@ -569,170 +591,214 @@ template <class MEM> struct Lane {
     }
     h.flags = (h.flags & ~(u32)(HF_PMP_ON | HF_PMP_MLOCK)) | f;
   }
-  // PmpManager::getPmp / accessPmp (PmpManager.hpp:155-177) over regions unpacked as unpackMemoryProtection (:417-468) and
-  // word-aligned as defineRegion (:233-236): r=1 w=2 x=4.  First match in index order; M mode ignores entries that are not
-  // locked; no match: M everything, S/U nothing.
-  WSP_HD u32 pmp_perm(u32 pm, u64 addr)
-  {
-    const u32 dflt = pm == PRV_M ? 7u : 0u;
-    if (!(h.flags & HF_PMP_ON) || (pm == PRV_M && !(h.flags & HF_PMP_MLOCK))) return dflt;
-    for (u32 k = 0; k < 8; ++k) {
-      const u64 w = m.cold(CI_PMPCFG0 + k);
-      if (!(w & 0x1818181818181818ULL)) continue;
-      for (u32 j = 0; j < 8; ++j) {
-        const u32 cfg = (u32)(w >> (8 * j)) & 0xff, type = (cfg >> 3) & 3, ix = 8 * k + j;
-        if (!type) continue;
-        const u64 v = m.cold(CI_PMPADDR0 + ix);
-        u64 lo, hi;
-        if (type == 1) {                                      // TOR
-          lo = (ix ? m.cold(CI_PMPADDR0 + ix - 1) : 0) << 2;
-          hi = v << 2; if (hi > 0) hi -= 1;
-        } else {
-          u64 size_m1 = 3, napot = v;
-          if (type == 3) {                                    // NAPOT (pmpaddr is 54 bits: never all ones)
-            u32 rzi = 0; while (rzi < 64 && ((v >> rzi) & 1)) ++rzi;
-            napot = rzi >= 64 ? 0 : ((v >> rzi) << rzi);
-            size_m1 = rzi + 3 >= 64 ? ~0ULL : ((1ULL << (rzi + 3)) - 1);
+  // ---- The address-translation unit (PMP match, Sv39 walk, TLB) reads the hart but never changes it - its side effects are
+  // TLB words in HBM - so it works on a small by-value context `Vm` instead of the whole Lane.  On the GPU its large, rarely
+  // taken parts (TLB miss + page walk, sfence.vma, translation without update) are out-of-line functions that receive the context
+  // by value: the Lane itself is then never passed by address anywhere, and the general path keeps it in registers.
+  struct Vm {
+    MEM m; u64 mstatus, mem_base, mem_size; u32 flags, tlb_n, isa;
+    WSP_HD bool ext(u32 e) const { return (isa & e) != 0; }
+    WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
+    // PmpManager::getPmp / accessPmp (PmpManager.hpp:155-177) over regions unpacked as unpackMemoryProtection (:417-468) and
+    // word-aligned as defineRegion (:233-236): r=1 w=2 x=4.  First match in index order; M mode ignores entries that are not
+    // locked; no match: M everything, S/U nothing.
+    WSP_HD u32 pmp_perm(u32 pm, u64 addr)
+    {
+      const u32 dflt = pm == PRV_M ? 7u : 0u;
+      if (!(flags & HF_PMP_ON) || (pm == PRV_M && !(flags & HF_PMP_MLOCK))) return dflt;
+      for (u32 k = 0; k < 8; ++k) {
+        const u64 w = m.cold(CI_PMPCFG0 + k);
+        if (!(w & 0x1818181818181818ULL)) continue;
+        for (u32 j = 0; j < 8; ++j) {
+          const u32 cfg = (u32)(w >> (8 * j)) & 0xff, type = (cfg >> 3) & 3, ix = 8 * k + j;
+          if (!type) continue;
+          const u64 v = m.cold(CI_PMPADDR0 + ix);
+          u64 lo, hi;
+          if (type == 1) {                                      // TOR
+            lo = (ix ? m.cold(CI_PMPADDR0 + ix - 1) : 0) << 2;
+            hi = v << 2; if (hi > 0) hi -= 1;
+          } else {
+            u64 size_m1 = 3, napot = v;
+            if (type == 3) {                                    // NAPOT (pmpaddr is 54 bits: never all ones)
+              u32 rzi = 0; while (rzi < 64 && ((v >> rzi) & 1)) ++rzi;
+              napot = rzi >= 64 ? 0 : ((v >> rzi) << rzi);
+              size_m1 = rzi + 3 >= 64 ? ~0ULL : ((1ULL << (rzi + 3)) - 1);
+            }
+            lo = napot << 2; hi = lo + size_m1;
           }
-          lo = napot << 2; hi = lo + size_m1;
+          const u64 a0 = (lo >> 2) << 2, a1 = ((hi >> 2) << 2) + 3;
+          if (addr >= a0 && addr <= a1) return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u);
         }
-        const u64 a0 = (lo >> 2) << 2, a1 = ((hi >> 2) << 2) + 3;
-        if (addr >= a0 && addr <= a1) return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u);
       }
+      return dflt;
     }
-    return dflt;
-  }
-  // ---- Sv39 + TLB (virtual_memory/VirtMem.cpp, Tlb.hpp, Tlb.cpp): single stage, no Svadu (an access that would need to
-  // set A or D page-faults, VirtMem.hpp:1159), no Svpbmt / Svnapot / shadow stack.  The reference's PTE cache is coherent
-  // with stores and flushed on sfence / satp / PMP changes, so it is not modelled.
+    // ---- Sv39 + TLB (virtual_memory/VirtMem.cpp, Tlb.hpp, Tlb.cpp): single stage, no Svadu (an access that would need to
+    // set A or D page-faults, VirtMem.hpp:1159), no Svpbmt / Svnapot / shadow stack.  The reference's PTE cache is coherent
+    // with stores and flushed on sfence / satp / PMP changes, so it is not modelled.
+    WSP_HD bool paging_on(u32 pm) { return ext(ISA_S) && pm != PRV_M && (m.cold(CI_SATP) >> 60) == 8; }
+    WSP_HD static u32 pf_cause(u32 acc) { return acc == 4 ? 12u : acc == 1 ? 13u : 15u; }      // stage1PageFaultType (VirtMem.cpp:31-40)
+    WSP_HD static u32 af_cause(u32 acc) { return acc == 4 ? 1u : acc == 1 ? 5u : 7u; }         // accessFaultType (VirtMem.cpp:57-66)
+    // VirtMem::pageTableWalk<Pte39, Va39> (VirtMem.cpp:694-892) behind the canonical-address check (:393-397).
+    // acc: 1 read 2 write 4 exec.  On success pa and the new TLB entry words.
+    WSP_HD u32 page_walk(u64 va, u32 pm, u32 acc, bool ad_check, u64& pa, u64& e0, u64& e1)
+    {
+      const u32 pf = pf_cause(acc);
+      if ((u64)(((i64)va << 25) >> 25) != va) return pf;
+      const bool sum = (mstatus & MST_SUM) != 0, mxr = (mstatus & MST_MXR) != 0;
+      const u64 satp = m.cold(CI_SATP);
+      u64 root = (satp & 0xfffffffffffULL) << 12, pte = 0;
+      int ii = 2; u32 global = 0;
+      for (;;) {
+        const u64 pte_addr = root + ((va >> (12 + 9 * ii)) & 0x1ff) * 8;
+        // isAddrReadable: PMP as Supervisor (Hart.cpp:424-441); memRead: PMA read (Hart.cpp:337-339)
+        if (!(pmp_perm(PRV_S, pte_addr) & 1) || !in_mem(pte_addr, 8)) return af_cause(acc);
+        pte = m.ld64(pte_addr - mem_base);
+        if (pte >> 63) return pf;                                                   // N without Svnapot (VirtMem.hpp:1090)
+        if (!(pte & 1) || (!(pte & 2) && (pte & 4)) || ((pte >> 54) & 0x7f)) return pf;   // isValidPte (VirtMem.hpp:558)
+        global |= (u32)(pte >> 5) & 1;
+        if (!(pte & 0xe)) {                                                         // next level (:747-756)
+          if ((pte & 0xd0) || ((pte >> 61) & 3)) return pf;
+          if (--ii < 0) return pf;
+          root = ((pte >> 10) & 0xfffffffffffULL) << 12;
+          continue;
+        }
+        if ((pte >> 61) & 3) return pf;                                             // Svpbmt off (:772-773)
+        const bool u = (pte >> 4) & 1, r = (pte >> 1) & 1, w = (pte >> 2) & 1, x = (pte >> 3) & 1;
+        if (pm == PRV_U && !u) return pf;
+        if (pm == PRV_S && u && (!sum || acc == 4)) return pf;
+        if ((acc == 1 && !(r || (mxr && x))) || (acc == 2 && !w) || (acc == 4 && !x)) return pf;
+        for (int j = 0; j < ii; ++j) if ((pte >> (10 + 9 * j)) & 0x1ff) return pf;  // misaligned superpage (:804-806)
+        if (ad_check && (!((pte >> 6) & 1) || (acc == 2 && !((pte >> 7) & 1)))) return pf;   // faultOnFirstAccess_ (:809-814)
+        break;
+      }
+      u64 a = va & 0xfff;                                                           // computePhysAddr (VirtMem.cpp:665-689)
+      for (int j = 0; j < ii; ++j) a |= ((va >> (12 + 9 * j)) & 0x1ff) << (12 + 9 * j);
+      for (int j = ii; j < 3; ++j) a |= ((pte >> (10 + 9 * j)) & (j == 2 ? 0x3ffffffULL : 0x1ffULL)) << (12 + 9 * j);
+      pa = a;
+      const u64 fl = TE_VALID | (global ? TE_GLOBAL : 0) | ((pte & 16) ? TE_USER : 0) | ((pte & 2) ? TE_R : 0) | ((pte & 4) ? TE_W : 0) |
+                     ((pte & 8) ? TE_X : 0) | ((pte & 64) ? TE_A : 0) | ((pte & 128) ? TE_D : 0);
+      e0 = (va >> 12) | ((u64)(1 + ii) << 52) | (fl << 56);
+      e1 = (a >> 12) | (((satp >> 44) & 0xffff) << 44);
+      return 0;
+    }
+    // Tlb::findEntry (Tlb.hpp:63-71) on the packed words
+    WSP_HD static bool tlb_match(u64 e0, u64 e1, u64 vpn, u64 satp)
+    { return ((e0 >> 56) & TE_VALID) && (e0 & TE_VPN_MASK) == vpn && (((e0 >> 56) & TE_GLOBAL) || ((e1 >> 44) & 0xffff) == ((satp >> 44) & 0xffff)); }
+    // permission part of a TLB hit (VirtMem.cpp:283-310)
+    WSP_HD bool tlb_hit_ok(u32 fl, u32 pm, u32 acc) const
+    {
+      const bool sum = (mstatus & MST_SUM) != 0, mxr = (mstatus & MST_MXR) != 0;
+      if (pm == PRV_U && !(fl & TE_USER)) return false;
+      if (pm == PRV_S && (fl & TE_USER) && (acc == 4 || !sum)) return false;
+      if ((acc == 1 && !((fl & TE_R) || (mxr && (fl & TE_X)))) || (acc == 2 && !(fl & TE_W)) || (acc == 4 && !(fl & TE_X))) return false;
+      return true;
+    }
+    // VirtMem::translate (VirtMem.cpp:261-329): 0 or the exception cause
+    WSP_HD u32 translate_miss(u64 va, u32 pm, u32 acc, u64& pa)
+    {
+      pa = va;
+      const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
+      const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
+      u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
+      if (tlb_match(e0, e1, vpn, satp)) {
+        e0 = (e0 & ~(3ULL << 54)) | ((((e0 >> 54) + 1) & 3) << 54);                 // findEntryUpdateTime (Tlb.hpp:91-100)
+        const u32 fl = (u32)(e0 >> 56);
+        if (!tlb_hit_ok(fl, pm, acc)) { m.tlb(ix) = e0; return pf_cause(acc); }
+        if ((fl & TE_A) && (acc != 2 || (fl & TE_D))) { m.tlb(ix) = e0; pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff); return 0; }
+        e0 &= ~((u64)TE_VALID << 56);                                               // :311-312 forget the entry, walk again
+        m.tlb(ix) = e0;
+      }
+      u64 n0, n1;
+      const u32 cause = page_walk(va, pm, acc, true, pa, n0, n1);
+      if (cause) { pa = va; return cause; }
+      if (((e0 >> 56) & TE_VALID) && ((e0 >> 54) & 2)) m.tlb(ix) = e0 - (1ULL << 54);   // Tlb::insertEntry (Tlb.cpp:74-92): busy slot, age it
+      else { m.tlb(ix) = n0; m.tlb(ix + 1) = n1; }
+      return 0;
+    }
+    // VirtMem::transAddrNoUpdate (VirtMem.cpp:143-205)
+    WSP_HD u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa)
+    {
+      pa = va;
+      const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
+      const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
+      const u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
+      if (tlb_match(e0, e1, vpn, satp)) {
+        if (!tlb_hit_ok((u32)(e0 >> 56), pm, acc)) return pf_cause(acc);
+        pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff);
+        return 0;
+      }
+      u64 n0, n1;
+      const u32 cause = page_walk(va, pm, acc, false, pa, n0, n1);
+      if (cause) pa = va;
+      return cause;
+    }
+    // Tlb::setMode on a satp.MODE change (Tlb.hpp:378-383) / Tlb::invalidate: valid and counter cleared, the rest kept
+    WSP_HD void tlb_invalidate_all() { for (u32 i = 0; i < tlb_n; ++i) m.tlb(2 * i) &= ~((3ULL << 54) | ((u64)TE_VALID << 56)); }
+    // execSfence_vma's TLB part (Hart.cpp:12139-12173; Tlb.hpp:176-284): entries are matched whether or not they are valid
+    WSP_HD void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v)
+    {
+      const u64 KEEP = ~((3ULL << 54) | ((u64)TE_VALID << 56));
+      const u64 asid = asid_v & 0xffffffffULL, vpn = addr >> 12;
+      const bool sv39 = (m.cold(CI_SATP) >> 60) == 8;                                // Tlb::mode_: sizeIn4kBytes(Bare) = 0
+      if (!has_addr) {
+        for (u32 i = 0; i < tlb_n; ++i) {
+          const u64 e0 = m.tlb(2 * i);
+          if (!has_asid || (!((e0 >> 56) & TE_GLOBAL) && ((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid)) m.tlb(2 * i) = e0 & KEEP;
+        }
+        return;
+      }
+      u64 max_size = 0, vpn_of_max = 0;
+      for (u32 i = 0; i < tlb_n; ++i) {
+        const u64 e0 = m.tlb(2 * i), evpn = e0 & TE_VPN_MASK; const u32 level = (u32)(e0 >> 52) & 3;
+        const u64 size = !sv39 ? 0 : level <= 1 ? 1 : level == 2 ? 512 : 262144;
+        const u64 pn = (!sv39 || level <= 1) ? evpn : level == 2 ? (evpn >> 9) << 9 : (evpn >> 18) << 18;
+        if (pn <= vpn && vpn < pn + size && (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL)))) {
+          if (size > max_size) { max_size = size; vpn_of_max = evpn; }
+          m.tlb(2 * i) = e0 & KEEP;
+        }
+      }
+      if (max_size > 1 && vpn_of_max <= vpn && vpn < vpn_of_max + max_size)          // "subpages covered by super-page"
+        for (u32 i = 0; i < tlb_n; ++i) {
+          const u64 e0 = m.tlb(2 * i);
+          if (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL))) m.tlb(2 * i) = e0 & KEEP;
+        }
+    }
+
+  };
+  struct TrRes { u64 pa; u32 cause; };
+  WSP_HD Vm vm() const { Vm v; v.m = m; v.mstatus = h.mstatus; v.mem_base = mem_base; v.mem_size = mem_size; v.flags = h.flags; v.tlb_n = tlb_n; v.isa = isa; return v; }
+  static WSP_HDN TrRes vm_translate_miss(Vm v, u64 va, u32 pm, u32 acc) { TrRes r; r.cause = v.translate_miss(va, pm, acc, r.pa); return r; }
+  static WSP_HDN TrRes vm_translate_noupdate(Vm v, u64 va, u32 pm, u32 acc) { TrRes r; r.cause = v.translate_noupdate(va, pm, acc, r.pa); return r; }
+  static WSP_HDN void vm_tlb_invalidate_all(Vm v) { v.tlb_invalidate_all(); }
+  static WSP_HDN void vm_sfence(Vm v, bool has_addr, u64 addr, bool has_asid, u64 asid_v) { v.sfence(has_addr, addr, has_asid, asid_v); }
+  WSP_HD u32 pmp_perm(u32 pm, u64 addr) { return vm().pmp_perm(pm, addr); }
   WSP_HD bool paging_on(u32 pm) { return ext(ISA_S) && pm != PRV_M && (m.cold(CI_SATP) >> 60) == 8; }
   WSP_HD static u32 pf_cause(u32 acc) { return acc == 4 ? 12u : acc == 1 ? 13u : 15u; }      // stage1PageFaultType (VirtMem.cpp:31-40)
-  WSP_HD static u32 af_cause(u32 acc) { return acc == 4 ? 1u : acc == 1 ? 5u : 7u; }         // accessFaultType (VirtMem.cpp:57-66)
-  // VirtMem::pageTableWalk<Pte39, Va39> (VirtMem.cpp:694-892) behind the canonical-address check (:393-397).
-  // acc: 1 read 2 write 4 exec.  On success pa and the new TLB entry words.
-  WSP_HDN u32 page_walk(u64 va, u32 pm, u32 acc, bool ad_check, u64& pa, u64& e0, u64& e1)
+  // VirtMem::translate (VirtMem.cpp:261-329): 0 or the exception cause.  The TLB hit is inline (one 16-byte entry, the
+  // permission test, the replacement counter's store); everything else goes out of line.
+  WSP_HD u32 translate(u64 va, u32 pm, u32 acc, u64& pa)
   {
-    const u32 pf = pf_cause(acc);
-    if ((u64)(((i64)va << 25) >> 25) != va) return pf;
-    const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
-    const u64 satp = m.cold(CI_SATP);
-    u64 root = (satp & 0xfffffffffffULL) << 12, pte = 0;
-    int ii = 2; u32 global = 0;
-    for (;;) {
-      const u64 pte_addr = root + ((va >> (12 + 9 * ii)) & 0x1ff) * 8;
-      // isAddrReadable: PMP as Supervisor (Hart.cpp:424-441); memRead: PMA read (Hart.cpp:337-339)
-      if (!(pmp_perm(PRV_S, pte_addr) & 1) || !in_mem(pte_addr, 8)) return af_cause(acc);
-      pte = m.ld64(pte_addr - mem_base);
-      if (pte >> 63) return pf;                                                   // N without Svnapot (VirtMem.hpp:1090)
-      if (!(pte & 1) || (!(pte & 2) && (pte & 4)) || ((pte >> 54) & 0x7f)) return pf;   // isValidPte (VirtMem.hpp:558)
-      global |= (u32)(pte >> 5) & 1;
-      if (!(pte & 0xe)) {                                                         // next level (:747-756)
-        if ((pte & 0xd0) || ((pte >> 61) & 3)) return pf;
-        if (--ii < 0) return pf;
-        root = ((pte >> 10) & 0xfffffffffffULL) << 12;
-        continue;
-      }
-      if ((pte >> 61) & 3) return pf;                                             // Svpbmt off (:772-773)
-      const bool u = (pte >> 4) & 1, r = (pte >> 1) & 1, w = (pte >> 2) & 1, x = (pte >> 3) & 1;
-      if (pm == PRV_U && !u) return pf;
-      if (pm == PRV_S && u && (!sum || acc == 4)) return pf;
-      if ((acc == 1 && !(r || (mxr && x))) || (acc == 2 && !w) || (acc == 4 && !x)) return pf;
-      for (int j = 0; j < ii; ++j) if ((pte >> (10 + 9 * j)) & 0x1ff) return pf;  // misaligned superpage (:804-806)
-      if (ad_check && (!((pte >> 6) & 1) || (acc == 2 && !((pte >> 7) & 1)))) return pf;   // faultOnFirstAccess_ (:809-814)
-      break;
-    }
-    u64 a = va & 0xfff;                                                           // computePhysAddr (VirtMem.cpp:665-689)
-    for (int j = 0; j < ii; ++j) a |= ((va >> (12 + 9 * j)) & 0x1ff) << (12 + 9 * j);
-    for (int j = ii; j < 3; ++j) a |= ((pte >> (10 + 9 * j)) & (j == 2 ? 0x3ffffffULL : 0x1ffULL)) << (12 + 9 * j);
-    pa = a;
-    const u64 fl = TE_VALID | (global ? TE_GLOBAL : 0) | ((pte & 16) ? TE_USER : 0) | ((pte & 2) ? TE_R : 0) | ((pte & 4) ? TE_W : 0) |
-                   ((pte & 8) ? TE_X : 0) | ((pte & 64) ? TE_A : 0) | ((pte & 128) ? TE_D : 0);
-    e0 = (va >> 12) | ((u64)(1 + ii) << 52) | (fl << 56);
-    e1 = (a >> 12) | (((satp >> 44) & 0xffff) << 44);
-    return 0;
-  }
-  // Tlb::findEntry (Tlb.hpp:63-71) on the packed words
-  WSP_HD static bool tlb_match(u64 e0, u64 e1, u64 vpn, u64 satp)
-  { return ((e0 >> 56) & TE_VALID) && (e0 & TE_VPN_MASK) == vpn && (((e0 >> 56) & TE_GLOBAL) || ((e1 >> 44) & 0xffff) == ((satp >> 44) & 0xffff)); }
-  // permission part of a TLB hit (VirtMem.cpp:283-310)
-  WSP_HD bool tlb_hit_ok(u32 fl, u32 pm, u32 acc) const
-  {
-    const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
-    if (pm == PRV_U && !(fl & TE_USER)) return false;
-    if (pm == PRV_S && (fl & TE_USER) && (acc == 4 || !sum)) return false;
-    if ((acc == 1 && !((fl & TE_R) || (mxr && (fl & TE_X)))) || (acc == 2 && !(fl & TE_W)) || (acc == 4 && !(fl & TE_X))) return false;
-    return true;
-  }
-  // VirtMem::translate (VirtMem.cpp:261-329): 0 or the exception cause
-  WSP_HDN u32 translate(u64 va, u32 pm, u32 acc, u64& pa)
-  {
-    pa = va;
-    const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
-    const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
-    u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
-    if (tlb_match(e0, e1, vpn, satp)) {
-      e0 = (e0 & ~(3ULL << 54)) | ((((e0 >> 54) + 1) & 3) << 54);                 // findEntryUpdateTime (Tlb.hpp:91-100)
-      const u32 fl = (u32)(e0 >> 56);
-      if (!tlb_hit_ok(fl, pm, acc)) { m.tlb(ix) = e0; return pf_cause(acc); }
-      if ((fl & TE_A) && (acc != 2 || (fl & TE_D))) { m.tlb(ix) = e0; pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff); return 0; }
-      e0 &= ~((u64)TE_VALID << 56);                                               // :311-312 forget the entry, walk again
-      m.tlb(ix) = e0;
-    }
-    u64 n0, n1;
-    const u32 cause = page_walk(va, pm, acc, true, pa, n0, n1);
-    if (cause) { pa = va; return cause; }
-    if (((e0 >> 56) & TE_VALID) && ((e0 >> 54) & 2)) m.tlb(ix) = e0 - (1ULL << 54);   // Tlb::insertEntry (Tlb.cpp:74-92): busy slot, age it
-    else { m.tlb(ix) = n0; m.tlb(ix + 1) = n1; }
-    return 0;
-  }
-  // VirtMem::transAddrNoUpdate (VirtMem.cpp:143-205)
-  WSP_HDN u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa)
-  {
-    pa = va;
     const u64 vpn = va >> 12, satp = m.cold(CI_SATP);
     const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
     const u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
-    if (tlb_match(e0, e1, vpn, satp)) {
-      if (!tlb_hit_ok((u32)(e0 >> 56), pm, acc)) return pf_cause(acc);
-      pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff);
-      return 0;
+    if (Vm::tlb_match(e0, e1, vpn, satp)) {
+      const u32 fl = (u32)(e0 >> 56);
+      const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
+      const bool bad = (pm == PRV_U && !(fl & TE_USER)) || (pm == PRV_S && (fl & TE_USER) && (acc == 4 || !sum)) ||
+                       (acc == 1 && !((fl & TE_R) || (mxr && (fl & TE_X)))) || (acc == 2 && !(fl & TE_W)) || (acc == 4 && !(fl & TE_X));
+      if (!bad && (fl & TE_A) && (acc != 2 || (fl & TE_D))) {
+        m.tlb(ix) = (e0 & ~(3ULL << 54)) | ((((e0 >> 54) + 1) & 3) << 54);          // findEntryUpdateTime (Tlb.hpp:91-100)
+        pa = ((e1 & 0xfffffffffffULL) << 12) | (va & 0xfff);
+        return 0;
+      }
     }
-    u64 n0, n1;
-    const u32 cause = page_walk(va, pm, acc, false, pa, n0, n1);
-    if (cause) pa = va;
-    return cause;
+    const TrRes r = vm_translate_miss(vm(), va, pm, acc);
+    pa = r.pa;
+    return r.cause;
   }
-  // Tlb::setMode on a satp.MODE change (Tlb.hpp:378-383) / Tlb::invalidate: valid and counter cleared, the rest kept
-  WSP_HDN void tlb_invalidate_all() { for (u32 i = 0; i < tlb_n; ++i) m.tlb(2 * i) &= ~((3ULL << 54) | ((u64)TE_VALID << 56)); }
-  // execSfence_vma's TLB part (Hart.cpp:12139-12173; Tlb.hpp:176-284): entries are matched whether or not they are valid
-  WSP_HDN void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v)
-  {
-    const u64 KEEP = ~((3ULL << 54) | ((u64)TE_VALID << 56));
-    const u64 asid = asid_v & 0xffffffffULL, vpn = addr >> 12;
-    const bool sv39 = (m.cold(CI_SATP) >> 60) == 8;                                // Tlb::mode_: sizeIn4kBytes(Bare) = 0
-    if (!has_addr) {
-      for (u32 i = 0; i < tlb_n; ++i) {
-        const u64 e0 = m.tlb(2 * i);
-        if (!has_asid || (!((e0 >> 56) & TE_GLOBAL) && ((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid)) m.tlb(2 * i) = e0 & KEEP;
-      }
-      return;
-    }
-    u64 max_size = 0, vpn_of_max = 0;
-    for (u32 i = 0; i < tlb_n; ++i) {
-      const u64 e0 = m.tlb(2 * i), evpn = e0 & TE_VPN_MASK; const u32 level = (u32)(e0 >> 52) & 3;
-      const u64 size = !sv39 ? 0 : level <= 1 ? 1 : level == 2 ? 512 : 262144;
-      const u64 pn = (!sv39 || level <= 1) ? evpn : level == 2 ? (evpn >> 9) << 9 : (evpn >> 18) << 18;
-      if (pn <= vpn && vpn < pn + size && (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL)))) {
-        if (size > max_size) { max_size = size; vpn_of_max = evpn; }
-        m.tlb(2 * i) = e0 & KEEP;
-      }
-    }
-    if (max_size > 1 && vpn_of_max <= vpn && vpn < vpn_of_max + max_size)          // "subpages covered by super-page"
-      for (u32 i = 0; i < tlb_n; ++i) {
-        const u64 e0 = m.tlb(2 * i);
-        if (!has_asid || (((m.tlb(2 * i + 1) >> 44) & 0xffff) == asid && !((e0 >> 56) & TE_GLOBAL))) m.tlb(2 * i) = e0 & KEEP;
-      }
-  }
+  WSP_HD u32 translate_noupdate(u64 va, u32 pm, u32 acc, u64& pa) { const TrRes r = vm_translate_noupdate(vm(), va, pm, acc); pa = r.pa; return r.cause; }
+  WSP_HD void tlb_invalidate_all() { vm_tlb_invalidate_all(vm()); }
+  WSP_HD void sfence(bool has_addr, u64 addr, bool has_asid, u64 asid_v) { vm_sfence(vm(), has_addr, addr, has_asid, asid_v); }
 
   // determineLoadException / determineStoreException (Hart.cpp:1988-2154, 13786-13935).  need: 1 load / LR, 2 store / SC / AMO
   // (validateAmoAddr checks write permission only, amo.cpp:28-56).  0 and the physical addresses of the (up to two) parts,
@@ -1165,7 +1231,7 @@ template <class MEM> struct Lane {
   WSP_HD static u32 gm_x8(u32 gm) { return gm < 4 ? 8u << gm : gm > 4 ? 8u >> (8 - gm) : 0; }                 // VecRegs.hpp:354-361
   WSP_HD static u64 ones_of(u32 esz) { return esz == 3 ? ~0ULL : (1ULL << (8u << esz)) - 1; }
   WSP_HD bool vec_on() const { return ext(ISA_V) && ((h.mstatus >> MST_VS_SH) & 3) != 0; }                    // isVecLegal
-  WSP_HD void mark_vs_dirty() { if (((h.mstatus >> MST_VS_SH) & 3) != 3) { h.mstatus |= (3ULL << MST_VS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
+  WSP_HD void mark_vs_dirty() { if (((h.mstatus >> MST_VS_SH) & 3) != 3 && !dry_bail()) { h.mstatus |= (3ULL << MST_VS_SH) | MST_SD; s.chg |= CH_MSTATUS; } }
   WSP_HD u64 vrd(u32 reg, u32 ix, u32 esz) { return m.vld(reg * vlenb + (ix << esz), esz); }
   WSP_HD i64 vrd_s(u32 reg, u32 ix, u32 esz) { const u32 sh = 64 - (8u << esz); return (i64)(vrd(reg, ix, esz) << sh) >> sh; }
   // VecRegs::write (VecRegs.hpp:190-211): the first write fixes the group the commit record reports
@@ -1174,6 +1240,8 @@ template <class MEM> struct Lane {
     if (s.vgroup == 0) { s.vgroup = groupx8 >= 8 ? groupx8 / 8 : 1; s.chg |= CH_VREG; }
     m.vst(reg * vlenb + (ix << esz), esz, v);
   }
+  // a split loop may leave this lane without an element: the bookkeeping of "a register group was written" is done up front
+  WSP_HD void v_note_write(u32 groupx8) { if (s.vgroup == 0) { s.vgroup = groupx8 >= 8 ? groupx8 / 8 : 1; s.chg |= CH_VREG; } }
   WSP_HD bool v_mask_bit(u32 ix) { return (m.vld(ix >> 3, 0) >> (ix & 7)) & 1; }                               // isActive(0, ix)
   struct VCfg { u32 esz, gx8, vl, elem_max; bool ta, ma, vill; };
   WSP_HD VCfg vcfg()
@@ -1274,6 +1342,7 @@ template <class MEM> struct Lane {
   }
   WSP_HD void v_ldst_fault(u32 cause, u32 ix, u64 tval, u64 cur_pc)             // :213-243, :395-403
   {
+    if (dry_bail()) return;
     mark_vs_dirty();
     m.cold(CI_VSTART) = ix & (vlenb * 8 - 1); s.chg |= CH_GEN; s.gen_csr = C_VSTART;
     take_exception(cause, cur_pc, tval, false);
@@ -1285,6 +1354,8 @@ template <class MEM> struct Lane {
     c.vl = (c.vl + 7) / 8; c.esz = 0; c.gx8 = 8; c.ta = true; c.ma = false;
     return true;
   }
+  // the address checks of a vector memory instruction have no side effects: bare translation (the TLB model is order dependent)
+  WSP_HD bool v_ldst_pure() { return !(ext(ISA_S) && eff_priv() != PRV_M && (m.cold(CI_SATP) >> 60) != 0); }
   WSP_HD void v_load_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided, bool mask_ls = false)
   {
     VCfg c = vcfg();
@@ -1298,6 +1369,40 @@ template <class MEM> struct Lane {
     const u64 stride = strided ? stride_reg : esz;                              // vector-ls.cpp:939-1040: the same loop stepping by x[rs2]
     u64 addr = base + (u64)start * stride;
     if (gx8 < 8) gx8 = 8;
+    const bool dry = (h.flags & HF_DRY) != 0;
+    if ((vgrp > 1 || dry) && v_ldst_pure()) {
+      // lanes.  Pass 1 finds the first element that faults (the checks have no side effect without paging), pass 2 loads the
+      // elements before it, then every lane takes that element's trap: what the serial loop leaves behind.
+      if (start < c.vl) {
+        u32 first = ~0u;
+        for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
+          if (masked && !v_mask_bit(ix)) continue;
+          u64 pa1, pa2, tval;
+          if (ldst_addr(base + (u64)ix * stride, esz, 1, pa1, pa2, tval)) { first = ix; break; }
+        }
+        first = sub_min(first);
+        if (dry && first != ~0u) { dry_bail(); return; }                          // a faulting access: the general path's business
+        const u32 lim = first < elem_max ? first : elem_max;
+        if (lim > start) v_note_write(gx8);
+        for (u32 ix = start + vsub; ix < lim; ix += vgrp) {
+          u64 elem;
+          if (v_dest_active(c, vd, ix, eew, masked, elem)) {
+            u64 pa1, pa2, tval;
+            ldst_addr(base + (u64)ix * stride, esz, 1, pa1, pa2, tval);
+            elem = pa1 == tohost ? 0 : mem_read2(pa1, pa2, esz);
+          }
+          vwr(vd, ix, eew, gx8, elem);
+        }
+        sub_fence();
+        if (first != ~0u) {
+          u64 pa1, pa2, tval = 0;
+          const u32 cause = ldst_addr(base + (u64)first * stride, esz, 1, pa1, pa2, tval);
+          v_ldst_fault(cause, first, tval, cur_pc); return;
+        }
+      }
+      vec_success();
+      return;
+    }
     if (start < c.vl)
       for (u32 ix = start; ix < elem_max; ++ix, addr += stride) {
         u64 elem;
@@ -1322,6 +1427,41 @@ template <class MEM> struct Lane {
     const u32 esz = 1u << eew, start = (u32)m.cold(CI_VSTART);
     const u64 stride = strided ? stride_reg : esz;
     u64 addr = base + (u64)start * stride;
+    const u64 astride = (i64)stride < 0 ? 0 - stride : stride;                     // elements that overlap in memory are stored in order
+    const bool dry = (h.flags & HF_DRY) != 0;
+    if (dry && !(v_ldst_pure() && astride >= esz)) { dry_bail(); return; }
+    if ((vgrp > 1 || dry) && v_ldst_pure() && astride >= esz) {
+      // lanes, as in v_load_unit; an element that lands in the code image or on tohost has side effects on hart state beyond
+      // memory (v_store_elem): any such element sends the instruction through the serial loop below, on every lane alike.
+      u32 first = ~0u, special = 0;
+      for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
+        if (masked && !v_mask_bit(ix)) continue;
+        u64 pa1, pa2, tval;
+        if (ldst_addr(base + (u64)ix * stride, esz, 2, pa1, pa2, tval)) { first = ix; break; }
+        special |= (pa1 + esz > text_lo && pa1 < text_hi) || (pa2 + esz > text_lo && pa2 < text_hi) ||
+                   (tohost != ~0ULL && (pa1 - tohost < 8 || pa2 - tohost < 8 || tohost - pa1 < 8 || tohost - pa2 < 8));
+      }
+      first = sub_min(first);
+      special = sub_or(special);
+      if (dry && (special || first != ~0u)) { dry_bail(); return; }
+      if (!special) {
+        const u32 lim = first < c.vl ? first : c.vl;
+        for (u32 ix = start + vsub; ix < lim; ix += vgrp) {
+          if (masked && !v_mask_bit(ix)) continue;
+          u64 pa1, pa2, tval;
+          ldst_addr(base + (u64)ix * stride, esz, 2, pa1, pa2, tval);
+          mem_write2(pa1, pa2, esz, vrd(vd, ix, eew));
+        }
+        sub_fence();
+        if (first != ~0u) {
+          u64 pa1, pa2, tval = 0;
+          const u32 cause = ldst_addr(base + (u64)first * stride, esz, 2, pa1, pa2, tval);
+          v_ldst_fault(cause, first, tval, cur_pc); return;
+        }
+        vec_success();
+        return;
+      }
+    }
     for (u32 ix = start; ix < c.vl; ++ix, addr += stride) {
       if (masked && !v_mask_bit(ix)) continue;
       const u64 elem = vrd(vd, ix, eew);
@@ -1516,12 +1656,15 @@ template <class MEM> struct Lane {
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+    if (0 < c.vl) {
+      v_note_write(dg);
+      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
         u64 d;
         if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = vi_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
         vwr(vd, ix, c.esz, dg, d);
       }
+      sub_fence();
+    }
     vec_success();
   }
   // vmacc / vnmsac / vmadd / vnmsub (vector.cpp:4836-5290): k 0 macc, 1 nmsac, 2 madd, 3 nmsub
@@ -1532,8 +1675,9 @@ template <class MEM> struct Lane {
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, vx ? 0 : vs1)) return;
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+    if (0 < c.vl) {
+      v_note_write(dg);
+      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
         u64 d;
         if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
           const u64 e1 = vx ? xs : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz), dd = vrd(vd, ix, c.esz);
@@ -1541,6 +1685,8 @@ template <class MEM> struct Lane {
         }
         vwr(vd, ix, c.esz, dg, d);
       }
+      sub_fence();
+    }
     vec_success();
   }
   // vmerge.vvm / vxm / vim, vmv.v.v / x / i (vector.cpp:7815-7970, 8098-8260)
@@ -2107,8 +2253,9 @@ template <class MEM> struct Lane {
     const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0, sign = c.esz == 2 ? 0x80000000ull : 0x8000000000000000ull;
     const bool w = c.esz == 2;
     unsigned fl = 0;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
+    if (0 < c.vl) {
+      v_note_write(dg);
+      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
         u64 d;
         if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
           u64 e1 = vf ? sc : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz);
@@ -2130,7 +2277,9 @@ template <class MEM> struct Lane {
         }
         vwr(vd, ix, c.esz, dg, d);
       }
-    or_fflags(fl);                                                              // updateAccruedFpBits
+      sub_fence();
+    }
+    or_fflags(sub_or(fl));                                                      // updateAccruedFpBits: flags accumulate over all elements
     vec_success();
   }
   // vmfeq / vmfle / vmflt / vmfne .vv / .vf, vmfgt / vmfge .vf (:4219-4925) behind checkVecFpMaskInst (:335-395).  op: 0 eq 1 le 2 lt 3 ne 4 gt 5 ge
@@ -2402,7 +2551,7 @@ template <class MEM> struct Lane {
     return true;
   }
   // dispatch: OP-V.  a = x[rs1], b = x[rs2]
-  WSP_HDN void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc)
+  WSP_HD void exec_vector_body(const Rec& r, u64 a, u64 b, u64 cur_pc)
   {
     const u32 inst = r.raw, f3 = (inst >> 12) & 7, f6 = inst >> 26, rd = (inst >> 7) & 31, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31;
     const bool vm = (inst >> 25) & 1;
@@ -2591,12 +2740,14 @@ template <class MEM> struct Lane {
     vec_unsupported(inst);
   }
   // vector loads / stores: unit-stride and strided, nf = 0, mew = 0 only.  a = x[rs1], b = x[rs2]
-  WSP_HDN void exec_vector_ldst(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store)
+  WSP_HD void exec_vector_ldst_body(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store)
   {
     const u32 inst = r.raw, f3 = (inst >> 12) & 7, mop = (inst >> 26) & 3;
     s.vreg = (inst >> 7) & 31;
     const u32 lumop = (inst >> 20) & 31, nf = inst >> 29, mew = (inst >> 28) & 1;
     const u32 eew = f3 == 0 ? 0 : f3 - 4;
+    // the warm path takes unit-stride, strided and mask loads / stores (their fault scan comes before the first write)
+    if ((h.flags & HF_DRY) && !(mew == 0 && nf == 0 && ((mop == 0 && (lumop == 0 || lumop == 0xb)) || mop == 2))) { dry_bail(); return; }
     if (mop == 0 && lumop == 8) {                                               // whole registers (Decoder.cpp:949-967, 1184-1195)
       if (store) { if (mew || f3 != 0 || (nf != 0 && nf != 1 && nf != 3 && nf != 7)) { illegal(r, cur_pc); return; } }
       else if (mew) { vec_fail(r, cur_pc); return; }
@@ -2630,6 +2781,7 @@ template <class MEM> struct Lane {
                (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
     h.flags = hot ? (h.flags | HF_HOT) : (h.flags & ~(u32)HF_HOT);
     h.flags = (((h.mstatus >> MST_FS_SH) & 3) == 3) ? (h.flags | HF_FS_DIRTY) : (h.flags & ~(u32)HF_FS_DIRTY);
+    h.flags = (((h.mstatus >> MST_VS_SH) & 3) == 3) ? (h.flags | HF_VS_DIRTY) : (h.flags & ~(u32)HF_VS_DIRTY);
   }
   template <bool TRACE> WSP_HD void wx_fast(u32 rd, u64 v)
   {
@@ -2721,6 +2873,29 @@ template <class MEM> struct Lane {
     t = fold(t, k); t = fold(t, v);
     h.thash = t;
   }
+
+  // The vector unit is large: out of line on the GPU, ONE compiled copy for both of its callers.  The hart goes in by value and
+  // what the unit can change (the hot registers and the commit bookkeeping; everything else it changes is in LDS / HBM) comes
+  // back by value: no address of the caller's Lane is taken (inside the unit the copy is a private object that the LDS / HBM
+  // stores of the element loops cannot alias).  mode bits 1:0: 0 OP-V, 1 vector load, 2 vector store.  Bit 2: the call comes from
+  // the kernel's vector warm path (HF_DRY is set in L.h.flags): a completed instruction's commit record is folded here.
+  struct VecRet { Hot h; Step s; };
+  static WSP_HDN VecRet vec_call(Lane L, Rec r, u64 a, u64 b, u64 cur_pc, u32 mode)
+  {
+    const u32 kind = mode & 3;
+    if (kind == 0) L.exec_vector_body(r, a, b, cur_pc); else L.exec_vector_ldst_body(r, a, b, cur_pc, kind == 2);
+    if ((mode & 4) && !(L.s.chg & CH_BAIL)) L.template commit<true>(cur_pc, r.raw, 4, PRV_M, 0);
+    VecRet o; o.h = L.h; o.s = L.s; return o;
+  }
+#if defined(__HIPCC__)
+  WSP_HD void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc)
+  { const unsigned long long t0 = WSP_PROF_T(); const VecRet o = vec_call(*this, r, a, b, cur_pc, 0); h = o.h; s = o.s; WSP_PROF_ADD(5, WSP_PROF_T() - t0); WSP_PROF_ADD(4, 1); }
+  WSP_HD void exec_vector_ldst(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store)
+  { const unsigned long long t0 = WSP_PROF_T(); const VecRet o = vec_call(*this, r, a, b, cur_pc, store ? 2u : 1u); h = o.h; s = o.s; WSP_PROF_ADD(8, WSP_PROF_T() - t0); WSP_PROF_ADD(7, 1); }
+#else
+  WSP_HD void exec_vector(const Rec& r, u64 a, u64 b, u64 cur_pc) { exec_vector_body(r, a, b, cur_pc); }
+  WSP_HD void exec_vector_ldst(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store) { exec_vector_ldst_body(r, a, b, cur_pc, store); }
+#endif
 
   // ---- one decoded instruction. `op` is passed separately so the GPU kernel can hand in a
   // wave-uniform copy (scalar branch over the switch); a = x[rs1], b = second operand.

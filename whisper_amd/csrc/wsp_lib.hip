@@ -16,6 +16,15 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+// -DWSP_PROF: cycle accounting of the step kernel's paths (tuning builds only; read back with wsp_debug_prof)
+#ifdef WSP_PROF
+__device__ unsigned long long wsp_prof[16];
+#define WSP_PROF_ADD(k, v) do { if ((int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&wsp_prof[k], (unsigned long long)(v)); } while (0)
+#define WSP_PROF_T() ((unsigned long long)clock64())
+#else
+#define WSP_PROF_ADD(k, v) do { } while (0)
+#define WSP_PROF_T() 0ULL
+#endif
 #include "wsp_core.h"
 #include "wsp_config.h"
 #include "../../include/whisper_amd.h"
@@ -55,8 +64,14 @@ __host__ __device__ static inline size_t arena_off(const DevState& d, u32 hart, 
 // writes rd = x0 results there unconditionally), slot 32 is the constant zero that every read of x0 is redirected to
 // (pre-decoded operand offsets, Rec.pad).  The f block uses slots 0..31.
 #define WSP_XSLOTS 33
+extern __shared__ __align__(16) u64 wsp_lds[];
+// The vector register files of a wave's harts live in LDS while the step kernel runs (behind the x and f blocks; copied in from
+// DevState::vreg at kernel start and back at the end): an element access of the vector unit's loops costs an LDS round trip
+// instead of a dependent trip to HBM / L2.  Addressed as an LDS offset so that the accesses compile to ds_read / ds_write.
+__device__ __forceinline__ u8* wsp_vreg_lds(u32 off) { return (u8*)wsp_lds + off; }
 struct DevMem {
-  u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* vreg_; u8* arena; u32 S, lpw_shift;
+  u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* arena; u32 S, lpw_shift;
+  u32 voff;            // byte offset in LDS of this hart's vector register file ([32][vlenb], element 0 first)
   __device__ __forceinline__ u64 rx(u32 r) const { return xs[r ? r : 32]; }
   __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r] = v; }
   __device__ __forceinline__ u64 rf(u32 r) const { return fs[r]; }
@@ -65,9 +80,16 @@ struct DevMem {
   __device__ __forceinline__ u64& tlb(u32 i) { return tlb_[i]; }
   // element of 1 << esz bytes at byte offset o (a multiple of the size) of this hart's vector register file
   __device__ __forceinline__ u64 vld(u32 o, u32 esz) const
-  { const u8* q = vreg_ + o; return esz == 0 ? *q : esz == 1 ? *(const u16*)q : esz == 2 ? *(const u32*)q : *(const u64*)q; }
+  { const u8* q = wsp_vreg_lds(voff + o); return esz == 0 ? *q : esz == 1 ? *(const u16*)q : esz == 2 ? *(const u32*)q : *(const u64*)q; }
   __device__ __forceinline__ void vst(u32 o, u32 esz, u64 v)
-  { u8* q = vreg_ + o; if (esz == 0) *q = (u8)v; else if (esz == 1) *(u16*)q = (u16)v; else if (esz == 2) *(u32*)q = (u32)v; else *(u64*)q = v; }
+  { u8* q = wsp_vreg_lds(voff + o); if (esz == 0) *q = (u8)v; else if (esz == 1) *(u16*)q = (u16)v; else if (esz == 2) *(u32*)q = (u32)v; else *(u64*)q = v; }
+  // Sub-group of a hart in a V batch (Lane::vgrp lanes: this hart's lane l and the lanes l + lpw, l + 2 lpw, ... of the wave, all
+  // executing the same instruction): combine a value over it.  Only ever called with the whole sub-group active.
+  __device__ __forceinline__ u32 xlane_or(u32 v) const
+  { for (u32 o = 1u << lpw_shift; o < 64; o <<= 1) v |= (u32)__shfl_xor((int)v, (int)o, 64); return v; }
+  __device__ __forceinline__ u32 xlane_min(u32 v) const
+  { for (u32 o = 1u << lpw_shift; o < 64; o <<= 1) { const u32 t = (u32)__shfl_xor((int)v, (int)o, 64); v = t < v ? t : v; } return v; }
+  __device__ __forceinline__ void xlane_fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
   __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
   __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
   __device__ __forceinline__ u16 ld16(u64 o) const { return *(const u16*)p(o); }
@@ -88,7 +110,6 @@ struct DevMem {
 #ifndef WSP_CONVERGED_LOOP
 #define WSP_CONVERGED_LOOP 1
 #endif
-extern __shared__ __align__(16) u64 wsp_lds[];
 
 __device__ __forceinline__ u32 ln_of(const DevState& d)
 { const u32 lane = threadIdx.x; return (lane < d.lpw && blockIdx.x * d.lpw + lane < d.n_harts) ? lane : 0; }
@@ -99,7 +120,7 @@ __device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& 
   L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot;
   L.m.tlb_ = d.tlb + (size_t)(wave * d.lpw + ln) * 2 * d.tlb_n; L.tlb_n = d.tlb_n;
-  L.m.vreg_ = d.vreg + (size_t)(wave * d.lpw + ln) * 32 * d.vlenb; L.vlenb = d.vlenb;
+  L.m.voff = d.lpw * (2 * WSP_XSLOTS * 8) + ln * 32 * d.vlenb; L.vlenb = d.vlenb;
   if (d.ring) { L.ring_ = d.ring + (size_t)(wave * d.lpw + ln) * d.ring_cap; L.ring_pos_ = d.ring_pos + wave * d.lpw + ln; L.ring_cap = d.ring_cap; }
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
@@ -164,6 +185,7 @@ __device__ __forceinline__ u64 wsp_stop_at(u64 slice_end, u64 max_exec, u64 max_
 __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
 {
   const DevState& d = *dp;
+  const unsigned long long pt0 = WSP_PROF_T();
   const u32 wave = blockIdx.x, ln = ln_of(d);
   const u32 slot = wave * 64 + ln;
   Lane<DevMem> L; const Rec* recs;
@@ -175,14 +197,17 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
   const u64 max_exec = d.max_exec[slot], max_ret = d.max_ret[slot];
   u64 stop_at = hr.stop_at;
   u32 k = 0;
+  const unsigned long long pt1 = WSP_PROF_T();
   do {
     L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
     L.template cold_step<true>(recs);
     stop_at = wsp_stop_at(hr.slice_end, max_exec, max_ret, L.h.exec, L.h.retired);
   } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < stop_at &&
            !((L.h.flags & HF_HOT) && L.h.pc - L.text_lo < L.text_hi - L.text_lo));
+  WSP_PROF_ADD(3, WSP_PROF_T() - pt1); WSP_PROF_ADD(6, k);
   wsp_store_hot(L, d, slot);
   HotRegs r; r.pc = L.h.pc; r.exec = L.h.exec; r.thash = L.h.thash; r.stop_at = stop_at; r.slice_end = hr.slice_end; r.flags = L.h.flags; r.status = L.h.status; r.fcsr = L.h.fcsr;
+  WSP_PROF_ADD(2, WSP_PROF_T() - pt0); WSP_PROF_ADD(1, 1);
   return r;
 }
 
@@ -197,7 +222,7 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
 {
   Lane<DevMem> L;
   L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.vreg_ = nullptr; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
@@ -211,6 +236,37 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   L.exec_fp(rec, L.m.rx(rec_rs1(rec)), pc);
   L.template commit<TRACE>(pc, raw, (w0 & F_SIZE4) ? 4 : 2, PRV_M, 0);
   r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = 1;
+  return r;
+}
+
+// The vector warm path: one vector instruction (OP-V, unit-stride / strided / mask load or store) of a hart that is hot and whose
+// mstatus.VS is already Dirty, executed by the hart's whole SUB-GROUP - its own lane l and the otherwise idle lanes l + lpw,
+// l + 2 lpw, ... of the wave (64 / lpw lanes; V batches run at most 16 harts per wave).  Every lane of the sub-group builds the
+// same minimal hart (registers only: no HBM state is loaded or stored, the vector registers are in LDS) and runs the vector unit
+// (Lane::vec_call) in lock step; the unit's element loops marked "lanes" are split, lane k of the sub-group taking the elements
+// k, k + vgrp, ... (the lanes-per-element mapping of the reference's loops, vector.cpp:808-855, vector-float.cpp:667-691,
+// vector-ls.cpp:156-247).  The unit runs dry (HF_DRY): whatever would trap, stop the hart or change mstatus changes nothing and
+// comes back as handled = 0; the general path then executes that instruction in full.  mstatus is synthetic: M mode, VS Dirty, FS
+// Dirty or Off (Off sends an FP vector instruction of a hart whose FS is not Dirty yet to the general path).
+template <bool TRACE>
+__device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
+{
+  const DevState& d = *dp;
+  const u32 wave = blockIdx.x, ln = threadIdx.x & (d.lpw - 1), slot = wave * 64 + ln;
+  Lane<DevMem> L; const Rec* recs;
+  wsp_lane_setup(L, d, wave, ln, slot, recs);
+  L.ring_ = nullptr; L.ring_pos_ = nullptr; L.ring_cap = 0;      // (no ring on this path: HF_RING keeps a hart off it)
+  L.vsub = threadIdx.x >> d.lpw_shift; L.vgrp = 64u >> d.lpw_shift;
+  L.h.pc = pc + 4; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_VS_SH) | ((flags & HF_FS_DIRTY) ? (3ULL << MST_FS_SH) : 0) | MST_SD;
+  L.h.cycle = 0; L.h.instret = 0; L.h.exec = 0; L.h.retired = 0; L.h.thash = thash; L.h.lr_addr = 0; L.h.exec_last_ill = 0; L.h.stop_value = 0;
+  L.h.fcsr = fcsr; L.h.priv = PRV_M; L.h.status = ST_RUNNING; L.h.consec_ill = 0; L.h.htif_dev = 0;
+  L.h.flags = flags | HF_DRY | (TRACE ? 0u : (u32)HF_NOTRACE);
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
+  const u32 op = w0 & 0xff;
+  const u64 a = L.m.rx(rec_rs1(rec)), b = (w0 & F_IMM) ? (u64)(i64)imm : L.m.rx(rec_rs2(rec));
+  const Lane<DevMem>::VecRet o = Lane<DevMem>::vec_call(L, rec, a, b, pc, (op == OP_VEC ? 0u : op == OP_VLD ? 1u : 2u) | 4u);
+  WarmRet r; r.thash = o.h.thash; r.fcsr = o.h.fcsr; r.handled = (o.s.chg & CH_BAIL) ? 0u : 1u;
   return r;
 }
 
@@ -248,6 +304,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   // host picks it, wsp_batch_run).  Every other untraced batch runs the TRACE = true kernel with notrace set: one compiled body of
   // the divergent dispatch loop for traced and untraced runs, so the traced parity tests cover what untraced runs execute.
   const bool tr = TRACE && !notrace;
+  const unsigned long long pk0 = WSP_PROF_T();
   const u32 lane = threadIdx.x, wave = blockIdx.x;
   const u32 hart = wave * d.lpw + lane;
   const bool active = lane < d.lpw && hart < d.n_harts;
@@ -281,6 +338,11 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
       for (u32 r = 0; r < 32; ++r) L.m.wf(r, d.f[(size_t)r * S + slot]);
     }
   }
+  // vector register files of the wave's harts: one contiguous run in HBM -> LDS, all 64 lanes copying
+  const u32 vwords = d.vreg ? (min(d.n_harts - wave * d.lpw, d.lpw) * 32 * d.vlenb) >> 3 : 0;
+  u64* const vlds = wsp_lds + d.lpw * (2 * WSP_XSLOTS);
+  u64* const vhbm = (u64*)(d.vreg + (size_t)wave * d.lpw * 32 * d.vlenb);
+  for (u32 i = lane; i < vwords; i += 64) vlds[i] = vhbm[i];
   __syncthreads();
 
   const bool zca = (d.isa & ISA_C) != 0;                 // without C, taken control transfers can trap: general path
@@ -649,6 +711,32 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         }
       }
     }
+    if (d.vreg) {
+      // Vector warm path (wsp_vwarm): hot harts with VS Dirty at a vector instruction; the idle lanes l + lpw, l + 2 lpw, ... join
+      // hart l as its sub-group and get the instruction and the hart's live registers from its lane.
+      Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+      bool cand = need_cold && active && (L.h.flags & (HF_HOT | HF_VS_DIRTY | HF_RING)) == (HF_HOT | HF_VS_DIRTY) && L.hot_fetch(recs, rec);
+      cand = cand && (rec.w0 & 0xff) >= OP_VEC && (rec.w0 & 0xff) <= OP_VST;
+      const unsigned long long cm = __ballot(cand);
+      if (cm) {
+        const int owner = (int)(lane & (d.lpw - 1));
+        const bool helper = lane >= d.lpw && ((cm >> owner) & 1);
+        u64 vpc = L.h.pc, vth = L.h.thash; u32 vfcsr = L.h.fcsr, vfl = L.h.flags, vw0 = rec.w0, vraw = rec.raw; i32 vimm = rec.imm;
+#define WSP_FROM_OWNER64(x) do { const u32 lo_ = (u32)__shfl((int)(u32)x, owner, 64), hi_ = (u32)__shfl((int)(u32)(x >> 32), owner, 64); if (helper) x = (u64)lo_ | ((u64)hi_ << 32); } while (0)
+#define WSP_FROM_OWNER32(x) do { const u32 v_ = (u32)__shfl((int)x, owner, 64); if (helper) x = v_; } while (0)
+        WSP_FROM_OWNER64(vpc); WSP_FROM_OWNER64(vth); WSP_FROM_OWNER32(vfcsr); WSP_FROM_OWNER32(vfl); WSP_FROM_OWNER32(vw0); WSP_FROM_OWNER32(vraw);
+        { u32 t_ = (u32)vimm; WSP_FROM_OWNER32(t_); vimm = (i32)t_; }
+#undef WSP_FROM_OWNER64
+#undef WSP_FROM_OWNER32
+        if (cand || helper) {
+          // one call site for the hart's lane and its helpers: they execute the call together
+          const unsigned long long pv0 = WSP_PROF_T();
+          const WarmRet w = (TRACE && tr) ? wsp_vwarm<true>(dp, vw0, vimm, vraw, vpc, vth, vfcsr, vfl) : wsp_vwarm<false>(dp, vw0, vimm, vraw, vpc, vth, vfcsr, vfl);
+          WSP_PROF_ADD(10, WSP_PROF_T() - pv0); WSP_PROF_ADD(9, 1); WSP_PROF_ADD(11, __popcll(__ballot(cand && w.handled)));
+          if (cand && w.handled) { L.h.pc += 4; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; need_cold = false; }
+        }
+      }
+    }
     if (need_cold) {
       // A cold call is a context switch: every per-lane value of the hot loop is either passed through HotRegs or
       // rebuilt from the kernel arguments afterwards.
@@ -663,6 +751,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   }
 
   __syncthreads();
+  for (u32 i = lane; i < vwords; i += 64) vhbm[i] = vlds[i];
   if (active) {
     for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
     if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
@@ -674,6 +763,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     d.hot64[H64_EXEC * S + slot] = L.h.exec; d.hot64[H64_PC * S + slot] = L.h.pc; d.hot64[H64_THASH * S + slot] = L.h.thash;
     d.hot32[H32_FLAGS * S + slot] = L.h.flags; d.hot32[H32_STATUS * S + slot] = L.h.status; d.hot32[H32_FCSR * S + slot] = L.h.fcsr;
   }
+  WSP_PROF_ADD(0, WSP_PROF_T() - pk0);
   const unsigned long long still = __ballot(active && L.h.status == ST_RUNNING);
   if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
 }
@@ -1034,8 +1124,16 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     // 13.5 / 13.7 GIPS, 16384 harts lpw 4/16/64 -> 36 / 55 / 57, 65536 harts lpw 16/64 -> 140 / 207).
     lpw = 1;
     while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 1024) lpw <<= 1;
+    // V batches keep lanes free for the vector unit's element loops: at least 8 lanes per hart (the hart's sub-group, wsp_cold)
+    if ((isa & ISA_V) && lpw > 8) lpw = 8;
   }
   if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
+  if (isa & ISA_V) {
+    // the vector register files of a wave's harts are staged in LDS (wsp_vreg_lds): the wave's block must fit the 64 KiB a
+    // workgroup gets without asking for more; a larger request is lowered (16 at VLEN 512, 32 at VLEN 256 / 128)
+    const u32 vb = desc->vlen_bytes ? desc->vlen_bytes : cfg.vlen_bytes ? cfg.vlen_bytes : 64u;
+    while (lpw > 1 && (size_t)lpw * (2 * WSP_XSLOTS * 8 + 32 * vb) > 65536) lpw >>= 1;
+  }
   wsp_batch* b = new wsp_batch();
   b->device = dev;
   DevState& d = b->d;
@@ -1652,6 +1750,7 @@ template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 s
 {
   DevState& d = b->d;
   size_t lds = (size_t)d.lpw * WSP_XSLOTS * 8 * (FP ? 2 : 1);
+  if (d.vreg) lds = (size_t)d.lpw * (2 * WSP_XSLOTS * 8 + 32 * d.vlenb);     // x block, f block, vector register files
   hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps, notrace);
@@ -1694,6 +1793,17 @@ extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flag
   } while (running && remaining);
   return (int64_t)running;
 }
+
+#ifdef WSP_PROF
+extern "C" int wsp_debug_prof(uint64_t* out, int reset)
+{
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wsp_prof), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out[i] = h[i];
+  if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(wsp_prof), h, sizeof h); }
+  return 0;
+}
+#endif
 
 extern "C" int wsp_batch_last_run_stats(wsp_batch* b, double* s, uint32_t* launches)
 { if (!b) return fail(WSP_EINVAL, "null batch"); if (s) *s = b->last_kernel_s; if (launches) *launches = b->last_launches; return WSP_OK; }

@@ -1314,3 +1314,140 @@ def rvv_program(seed: int, n: int = 160, vlenb: int = 64) -> Program:
     _exit_tohost(a, S["tohost"], tmp1=30, tmp2=31)
     assert a.here() < data_base
     return _finish(a, f"rvv-{seed}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=1 << 16, max_inst=40000, meta=dict(seed=seed, vlenb=vlenb))
+
+
+def rvv_kernel(n: int = 1024, iters: int = 2, vlenb: int = 64) -> Program:
+    """BASELINE config 3 workload ("RVV vector kernels at VLEN 256 / 512, 16k harts"): the strip-mined loops of a vector
+    library, per-instance data from the seed in a0 (xorshift-filled arrays).  Per pass: saxpy (e32, vfmacc.vf), daxpy (e64,
+    vfmadd.vv with a splat), an integer pipeline (e32: vmul.vx, vadd.vv, vsrl.vi, vxor.vv, vmax.vv; e8: vadd / vand / vsub at
+    LMUL 8), a masked update (vmslt.vx -> vmerge / masked vadd), a dot product (vfmul + vfredusum) and an integer checksum
+    (vredsum).  Results go to `results`; exit by writing 1 to tohost.  Almost every dynamic instruction of the loops is a
+    vector instruction or its scalar strip-mining companion (slli / add / sub / bnez)."""
+    import struct
+    data_base = BASE + 0x1000
+    a = Asm(BASE)
+    d = Asm(data_base)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("seed"); d.dword(0)
+    d.label("results"); d.zeros(8 * 16)
+    d.label("fconst"); d.data(struct.pack("<f", 1.25)); d.data(struct.pack("<f", 0.5)); d.data(struct.pack("<d", 0.75)); d.data(struct.pack("<d", 1.0 / 1024))
+    d.align_data(64)
+    d.label("xs"); d.zeros(4 * n)
+    d.label("ys"); d.zeros(4 * n)
+    d.label("xd"); d.zeros(8 * n)
+    d.label("yd"); d.zeros(8 * n)
+    d.label("bi"); d.zeros(4 * n)
+    d.label("bb"); d.zeros(4 * n)
+    S = d.symbols
+    SEED, RES, N, PX, PY, VL, T0, T1, T2, ITER = 10, 11, 12, 13, 14, 15, 5, 6, 7, 18
+
+    def strip(sew, lmul, body, px=None, py=None, ta=True, ma=True):
+        """for (n = N; n; n -= vl) { vl = vsetvli(n); body(); px += vl * sew / 8; py += ... }"""
+        a.li(N, n)
+        if px is not None: a.li(PX, S[px])
+        if py is not None: a.li(PY, S[py])
+        top = a.here()
+        a.vsetvli(VL, N, Asm.vtype(sew, lmul, ta=ta, ma=ma))
+        body()
+        a.slli(T0, VL, {8: 0, 16: 1, 32: 2, 64: 3}[sew])
+        if px is not None: a.add(PX, PX, T0)
+        if py is not None: a.add(PY, PY, T0)
+        a.sub(N, N, VL)
+        a.bnez(N, top)
+
+    a.label("_start")
+    a.li(T0, 0x6600); a.csrs(CSR["mstatus"], T0)                               # FS and VS on
+    a.li(RES, S["results"])
+    a.li(T0, S["seed"]); a.ld(T1, 0, T0); a.xor(SEED, SEED, T1); a.ori(SEED, SEED, 1)
+    # fill the integer arrays (and through them the FP ones) with a hash of (element index, seed): vid.v, multiply / shift / xor
+    a.li(T1, 0x9E3779B1); a.li(T2, 0)
+    def fill():
+        a.vop(0x14, 2, 8, 0, 0x11)                                             # vid.v v8
+        a.vop(0x00, 4, 8, 8, T2)                                               # vadd.vx v8, v8, t2 (index of the strip's first element)
+        a.vop(_V_MUL["vmul"], 6, 8, 8, SEED)                                   # vmul.vx v8, v8, seed
+        a.vop(0x28, 3, 16, 8, 15); a.vop(0x0B, 0, 8, 8, 16)                    # v8 ^= v8 >> 15
+        a.vop(_V_MUL["vmul"], 6, 8, 8, T1)                                     # vmul.vx v8, v8, golden
+        a.vop(0x28, 3, 16, 8, 13); a.vop(0x0B, 0, 8, 8, 16)                    # v8 ^= v8 >> 13
+        a.vse(32, 8, PX); a.add(T2, T2, VL)
+    strip(32, 8, fill, "bi"); strip(32, 8, fill, "bb")
+    a.li(T0, S["fconst"]); a.flw(1, 0, T0); a.flw(2, 4, T0); a.fld(3, 8, T0); a.fld(4, 16, T0)
+    # xs / ys = float(int32 >> 8), xd / yd = double(int32) / 1024: vector conversions
+    def cvt32():
+        a.vle(32, 8, PX); a.vop(0x29, 3, 8, 8, 8)                              # vsra.vi v8, v8, 8
+        a.vop(0x12, 1, 16, 8, 3)                                               # vfcvt.f.x.v v16, v8
+        a.vse(32, 16, PY)
+    strip(32, 8, cvt32, "bi", "xs"); strip(32, 8, cvt32, "bb", "ys")
+    def cvt64(src):
+        def f():
+            a.vle(32, 8, PX); a.vop(0x12, 1, 16, 8, 0x0B)                      # vfwcvt.f.x.v v16, v8 (e32 -> e64)
+            a.vsetvli(0, 0, Asm.vtype(64, 8, ta=True, ma=True))                # same vl at e64, LMUL 8
+            a.vop(0x24, 5, 16, 16, 4)                                          # vfmul.vf v16, v16, f4
+            a.vse(64, 16, PY)
+            a.slli(T0, VL, 2); a.add(PY, PY, T0)                               # py advances by 8 bytes per element: the other half here
+        return f
+    strip(32, 4, cvt64("bi"), "bi", "xd"); strip(32, 4, cvt64("bb"), "bb", "yd")
+    a.li(ITER, iters)
+    a.label("outer")
+    # ---- saxpy: ys += f1 * xs
+    def saxpy():
+        a.vle(32, 8, PX); a.vle(32, 16, PY); a.vop(_V_FP["vfmacc"], 5, 16, 8, 1); a.vse(32, 16, PY)
+    strip(32, 8, saxpy, "xs", "ys")
+    # ---- daxpy with a splat: yd = f3 * xd + yd
+    def daxpy():
+        a.vle(64, 8, PX); a.vle(64, 16, PY); a.vop(0x17, 5, 24, 0, 3)          # vfmv.v.f v24, f3
+        a.vop(_V_FP["vfmadd"], 1, 8, 16, 24)                                   # vfmadd.vv v8, v24, v16: v8 = v8 * v24 + v16
+        a.vse(64, 8, PY)
+    strip(64, 8, daxpy, "xd", "yd")
+    # ---- integer pipeline, e32
+    def ipipe():
+        a.vle(32, 8, PX); a.vle(32, 16, PY)
+        a.vop(_V_MUL["vmul"], 6, 24, 8, SEED)                                  # vmul.vx v24, v8, seed
+        a.vop(0x00, 0, 24, 24, 16)                                             # vadd.vv
+        a.vop(0x28, 3, 8, 24, 7)                                               # vsrl.vi v8, v24, 7
+        a.vop(0x0B, 0, 24, 24, 8)                                              # vxor.vv
+        a.vop(0x07, 0, 16, 24, 16)                                             # vmax.vv v16, v24, v16
+        a.vse(32, 16, PY)
+    strip(32, 8, ipipe, "bi", "bb")
+    # ---- bytes at LMUL 8
+    def bytes8():
+        a.vle(8, 8, PX); a.vle(8, 16, PY); a.vop(0x00, 0, 24, 8, 16); a.vop(0x09, 4, 24, 24, SEED); a.vop(0x02, 0, 16, 24, 8); a.vse(8, 16, PY)
+    a.li(N, 4 * n); a.li(PX, S["bi"]); a.li(PY, S["bb"])
+    top = a.here()
+    a.vsetvli(VL, N, Asm.vtype(8, 8, ta=True, ma=False)); bytes8(); a.add(PX, PX, VL); a.add(PY, PY, VL); a.sub(N, N, VL); a.bnez(N, top)
+    # ---- masked update: where bi < 0: bb = bb + bi (masked, mask undisturbed), then merge with a scalar
+    def masked():
+        a.vle(32, 8, PX); a.vle(32, 16, PY)
+        a.vop(0x1B, 4, 0, 8, 0)                                                # vmslt.vx v0, v8, x0
+        a.vop(0x00, 0, 16, 16, 8, 0)                                           # vadd.vv v16, v16, v8, v0.t
+        a.vop(0x17, 4, 16, 16, ITER, 0)                                        # vmerge.vxm v16, v16, iter, v0
+        a.vse(32, 16, PY)
+    strip(32, 8, masked, "bi", "bb", ta=False, ma=False)
+    # ---- dot product xs . ys (vfmul + unordered sum per strip, accumulated in f5) and integer checksum of bb
+    a.fmv_w_x(5, 0)
+    def dot():
+        a.vle(32, 8, PX); a.vle(32, 16, PY); a.vop(_V_FP["vfmul"], 1, 8, 8, 16)
+        a.vop(0x10, 5, 24, 0, 5)                                               # vfmv.s.f v24, f5
+        a.vop(0x01, 1, 24, 8, 24)                                              # vfredusum.vs v24, v8, v24
+        a.vop(0x10, 1, 5, 24, 0)                                               # vfmv.f.s f5, v24
+    strip(32, 8, dot, "xs", "ys")
+    a.fsw(5, 0, RES)
+    a.li(T2, 0)
+    def isum():
+        a.vle(32, 8, PX); a.vop(0x10, 6, 24, 0, T2)                            # vmv.s.x v24, t2
+        a.vop(0x00, 2, 24, 8, 24)                                              # vredsum.vs v24, v8, v24
+        a.vop(0x10, 2, T2, 24, 0)                                              # vmv.x.s t2, v24
+    strip(32, 8, isum, "bb")
+    a.sd(T2, 8, RES)
+    a.addi(ITER, ITER, -1)
+    a.beqz(ITER, "done")
+    a.j("outer")
+    a.label("done")
+    a.csrr(T0, CSR["fcsr"]); a.sd(T0, 16, RES)
+    a.csrr(T0, CSR["minstret"]); a.sd(T0, 24, RES)
+    _exit_tohost(a, S["tohost"])
+    assert a.here() < data_base
+    size = 1 << 16
+    while data_base + 0x100 + 32 * n > BASE + size:
+        size <<= 1
+    return _finish(a, f"rvvk-{n}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=size, max_inst=1 << 26, meta=dict(n=n, iters=iters, vlenb=vlenb))
