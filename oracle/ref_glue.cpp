@@ -136,6 +136,46 @@ int ref_csr_name(unsigned num, char* buf, int n)
 
 }
 
+// The same for System<uint32_t>: CsRegs<uint32_t> (RV32 presence, reset values and masks).
+namespace {
+struct OpenCsRegs32 : CsRegs<uint32_t> {
+  using Base = CsRegs<uint32_t>;
+  using Base::Base;
+  using Base::peek; using Base::poke; using Base::reset; using Base::enableSupervisorMode; using Base::enableUserMode;
+  using Base::enableRvc; using Base::enableRvf; using Base::enableZicntr; using Base::enableHypervisorMode; using Base::enableVector;
+};
+struct CsrBox32 {
+  PmpManager pmp;
+  PmaManager pma;
+  OpenCsRegs32 regs;
+  explicit CsrBox32(uint64_t mem) : pma(mem), regs(pmp, pma) {}
+};
+}
+extern "C" {
+void* ref_csr32_new(int rvs, int rvu, int rvf, int rvc, int zicntr)
+{
+  auto* b = new CsrBox32(uint64_t(1) << 32);
+  b->regs.enableSupervisorMode(rvs);
+  b->regs.enableUserMode(rvu);
+  b->regs.enableHypervisorMode(false);
+  b->regs.enableRvc(rvc);
+  b->regs.enableRvf(rvf);
+  b->regs.enableVector(false);
+  b->regs.enableZicntr(zicntr);
+  b->regs.reset();
+  return b;
+}
+void ref_csr32_free(void* p) { delete static_cast<CsrBox32*>(p); }
+int ref_csr32_read(void* p, unsigned num, unsigned priv, uint32_t* v)
+{ return static_cast<CsrBox32*>(p)->regs.read(CsrNumber(num), PrivilegeMode(priv), *v); }
+int ref_csr32_write(void* p, unsigned num, unsigned priv, uint32_t v)
+{ return static_cast<CsrBox32*>(p)->regs.write(CsrNumber(num), PrivilegeMode(priv), v); }
+int ref_csr32_peek(void* p, unsigned num, uint32_t* v)
+{ return static_cast<CsrBox32*>(p)->regs.peek(CsrNumber(num), *v); }
+int ref_csr32_implemented(void* p, unsigned num)
+{ auto* c = static_cast<CsrBox32*>(p)->regs.findCsr(CsrNumber(num)); return c && c->isImplemented(); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The reference's PmpManager (PmpManager.hpp, header only) driven the way Hart::updateMemoryProtection does
 // (Hart.cpp:842-899): 8 pmpcfg values (pmpcfg0,2,..14) and 64 pmpaddr values in, permission bits out.

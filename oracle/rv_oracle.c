@@ -157,6 +157,7 @@ struct rvo_tlbe { u64 vpn, ppn; u32 asid; uint8_t counter, valid, global, user, 
 
 struct rvo_hart {
   rvo_config cfg;
+  int rv32;                  /* System<uint32_t> (Session.cpp:1373-1424): x registers are held sign-extended in 64 bits, the pc zero-extended */
   uint8_t* mem;
   u64 x[32], f[32];
   u64 pc, curr_pc;
@@ -196,13 +197,16 @@ static inline int ext(const rvo_hart* h, unsigned e) { return (h->cfg.isa & e) !
 
 rvo_hart* rvo_create(const rvo_config* cfg)
 {
-  if (cfg->xlen != 64 || (cfg->mem_size & 7) || cfg->mem_size == 0) return NULL;
+  if ((cfg->xlen != 64 && cfg->xlen != 32) || (cfg->mem_size & 7) || cfg->mem_size == 0) return NULL;
+  /* RV32 is modelled for M / U mode integer, A, F, D and C code: no S mode (Sv32) and no V */
+  if (cfg->xlen == 32 && ((cfg->isa & (RVO_ISA_S | RVO_ISA_V)) || cfg->mem_base + cfg->mem_size > (1ULL << 32))) return NULL;
   rvo_hart* h = (rvo_hart*)calloc(1, sizeof(*h));
   h->cfg = *cfg;
+  h->rv32 = cfg->xlen == 32;
   h->mem = (uint8_t*)calloc(1, cfg->mem_size);
   h->priv = PRV_M;
   /* reset mstatus: MPP=M, SXL=UXL=2 (CsRegs.cpp:4705-4710); FS/VS Off */
-  h->mstatus = (3ULL << MST_MPP_SH) | (0xAULL << 32);
+  h->mstatus = (3ULL << MST_MPP_SH) | (h->rv32 ? 0 : (0xAULL << 32));   /* RV32: no SXL / UXL fields (mstatus = 0x1800) */
   h->pc = cfg->reset_pc;
   h->vlenb = cfg->vlenb ? cfg->vlenb : 64;                                   /* Hart.cpp:1081 */
   if (h->vlenb != 16 && h->vlenb != 32 && h->vlenb != 64) { free(h->mem); free(h); return NULL; }
@@ -223,10 +227,10 @@ int rvo_write_mem(rvo_hart* h, u64 addr, const void* src, size_t n)
 { if (!in_mem(h, addr, n)) return -1; memcpy(h->mem + (addr - h->cfg.mem_base), src, n); return 0; }
 int rvo_read_mem(const rvo_hart* h, u64 addr, void* dst, size_t n)
 { if (!in_mem(h, addr, n)) return -1; memcpy(dst, h->mem + (addr - h->cfg.mem_base), n); return 0; }
-void rvo_set_pc(rvo_hart* h, u64 pc) { h->pc = pc & ~1ULL; }
+void rvo_set_pc(rvo_hart* h, u64 pc) { h->pc = pc & ~1ULL; if (h->rv32) h->pc &= 0xffffffffULL; }
 u64  rvo_get_pc(const rvo_hart* h) { return h->pc; }
-void rvo_set_x(rvo_hart* h, unsigned i, u64 v) { if (i && i < 32) h->x[i] = v; }
-u64  rvo_get_x(const rvo_hart* h, unsigned i) { return h->x[i & 31]; }
+void rvo_set_x(rvo_hart* h, unsigned i, u64 v) { if (i && i < 32) h->x[i] = h->rv32 ? (u64)(i64)(int32_t)v : v; }
+u64  rvo_get_x(const rvo_hart* h, unsigned i) { return h->rv32 ? (uint32_t)h->x[i & 31] : h->x[i & 31]; }
 void rvo_set_f(rvo_hart* h, unsigned i, u64 v) { h->f[i & 31] = v; }
 u64  rvo_get_f(const rvo_hart* h, unsigned i) { return h->f[i & 31]; }
 unsigned rvo_priv(const rvo_hart* h) { return h->priv; }
@@ -242,7 +246,7 @@ static u64 ld_le(const uint8_t* p, unsigned n) { u64 v = 0; memcpy(&v, p, n); re
 static void st_le(uint8_t* p, u64 v, unsigned n) { memcpy(p, &v, n); }
 
 /* ------------------------------------------------------------------ CSR file */
-static u64 misa_value(void) { return 0x800000000034112dULL; }  /* CsRegs.cpp:4721-4724: reset, read-only */
+static u64 misa_value(void) { return 0x800000000034112dULL; }  /* CsRegs.cpp:4721-4724: reset, read-only; RV32 reads 0x4034112d */
 
 /* CsRegs::legalizeMstatus (CsRegs.cpp:2617-2648) */
 static u64 legalize_mstatus(const rvo_hart* h, u64 v)
@@ -303,6 +307,12 @@ static int csr_class(const rvo_hart* h, unsigned num)
     case C_VSTART: case C_VXSAT: case C_VXRM: case C_VCSR: case C_VL: case C_VTYPE: case C_VLENB: return ext(h, RVO_ISA_V) ? 1 : 0;   /* CsRegs::enableVector (CsRegs.cpp:2240) */
     default: break;
   }
+  if (h->rv32) {   /* CsRegs<uint32_t>: the high halves exist, and so do the odd pmpcfg registers (pinned by tests/test_oracle_rv32.py) */
+    if (num == 0x310 || num == 0x31A || num == 0xB80 || num == 0xB82) return 1;          /* mstatush menvcfgh mcycleh minstreth */
+    if (num >= 0xC80 && num <= 0xC82) return ext(h, RVO_ISA_ZICNTR) ? 1 : 0;             /* cycleh timeh instreth */
+    if (num >= 0x3A0 && num <= 0x3EF) return 1;
+    if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || num == 0x7C7 || (num >= 0xB83 && num <= 0xB9F)) return -1;   /* mhpmevent<n>h mseccfgh mhpmcounter<n>h */
+  }
   /* Implemented in the reference's default configuration but not modelled here. */
   if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   /* pmpcfg (even only on rv64), pmpaddr0..63 */
   if (num >= 0xB03 && num <= 0xB1F) return -1;      /* mhpmcounter3..31 */
@@ -312,7 +322,7 @@ static int csr_class(const rvo_hart* h, unsigned num)
   return 0;
 }
 
-static u64 csr_peek(const rvo_hart* h, unsigned num)
+static u64 csr_peek64(const rvo_hart* h, unsigned num)
 {
   switch (num) {
     case C_FFLAGS: return h->fcsr & 0x1f;
@@ -342,6 +352,26 @@ static u64 csr_peek(const rvo_hart* h, unsigned num)
       if (num >= 0x3A0 && num <= 0x3AF) return h->pmpcfg[(num - 0x3A0) >> 1];
       if (num >= 0x3B0 && num <= 0x3EF) return h->pmpaddr[num - 0x3B0];    /* grain G = 0: read value = stored value */
       return 0;
+  }
+}
+
+/* The CSR file is kept in its RV64 shape; an RV32 hart sees 32-bit views of it (CsRegs<uint32_t>): the low half of each
+ * register with mstatus.SD and the interrupt bit of the cause registers at bit 31, the high halves under their own numbers,
+ * pmpcfg<2k+1> = the upper half of row k. */
+static u64 csr_peek(const rvo_hart* h, unsigned num)
+{
+  if (!h->rv32) return csr_peek64(h, num);
+  switch (num) {
+    case C_MSTATUS: case C_SSTATUS: case C_MCAUSE: case C_SCAUSE: { u64 v = csr_peek64(h, num); return (v & 0x7fffffffULL) | ((v >> 63) << 31); }
+    case C_MISA: return 0x4034112dULL;
+    case 0x310: return 0;                                                    /* mstatush: MBE / SBE hardwired zero */
+    case 0x31A: return csr_peek64(h, C_MENVCFG) >> 32;
+    case 0xB80: case 0xC80: return h->cycle >> 32;
+    case 0xB82: case 0xC82: return h->instret >> 32;
+    case 0xC81: return h->time_ >> 32;
+    default:
+      if (num >= 0x3A0 && num <= 0x3AF) return (h->pmpcfg[(num - 0x3A0) >> 1] >> (32 * (num & 1))) & 0xffffffffULL;
+      return csr_peek64(h, num) & 0xffffffffULL;
   }
 }
 
@@ -428,6 +458,29 @@ int rvo_poke_csr(rvo_hart* h, unsigned num, u64 v)
 /* Value update of CsRegs::write (CsRegs.cpp:3908-4165) for the modelled subset. */
 static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
 {
+  if (h->rv32) {                                       /* a 32-bit write, brought into the RV64 shape of the file */
+    v &= 0xffffffffULL;
+    switch (num) {
+      case C_MCAUSE: case C_SCAUSE: v = (v & 0x7fffffffULL) | ((v >> 31) << 63); break;
+      case C_MENVCFG: v |= h->menvcfg & ~0xffffffffULL; break;
+      case 0x31A: num = C_MENVCFG; v = (v << 32) | (h->menvcfg & 0xffffffffULL); if (record) record_csr(h, 0x31A); record = 0; break;
+      case 0x310: if (record) record_csr(h, num); return;                    /* mstatush: nothing writable */
+      case C_MCYCLE: v |= h->cycle & ~0xffffffffULL; break;
+      case C_MINSTRET: v |= h->instret & ~0xffffffffULL; break;
+      case 0xB80: h->cycle = (h->cycle & 0xffffffffULL) | (v << 32); if (record) record_csr(h, num); return;
+      case 0xB82: h->instret = (h->instret & 0xffffffffULL) | (v << 32); if (record) record_csr(h, num); return;
+      default:
+        if (num >= 0x3A0 && num <= 0x3AF) {              /* pmpcfg<n>: four entries, half of row n / 2 */
+          const unsigned k = (num - 0x3A0) >> 1, sh = 32 * (num & 1);
+          const u64 keep = h->pmpcfg[k] & ~(0xffffffffULL << sh);
+          h->pmpcfg[k] = legalize_pmpcfg(h->pmpcfg[k], keep | (v << sh)) & 0x9f9f9f9f9f9f9f9fULL;
+          h->pmp_on = 0; for (unsigned i = 0; i < 8; ++i) if (h->pmpcfg[i] & 0x1818181818181818ULL) h->pmp_on = 1;
+          if (record) record_csr(h, num);
+          return;
+        }
+        break;
+    }
+  }
   switch (num) {
     case C_FFLAGS: h->fcsr = (h->fcsr & ~0x1fULL) | (v & 0x1f); break;         /* CsRegs.cpp:4462-4472 */
     case C_FRM:    h->fcsr = (h->fcsr & ~0xe0ULL) | ((v & 7) << 5); break;
@@ -490,7 +543,7 @@ static void begin_inst(rvo_hart* h)
 }
 
 static inline void wx(rvo_hart* h, unsigned rd, u64 v)
-{ if (rd) h->x[rd] = v; h->ch_ireg = (int)rd; }      /* IntRegs.hpp:58-64: x0 write still recorded */
+{ if (rd) h->x[rd] = h->rv32 ? (u64)(i64)(int32_t)v : v; h->ch_ireg = (int)rd; }      /* IntRegs.hpp:58-64: x0 write still recorded */
 
 static void mark_fs_dirty(rvo_hart* h)
 {
@@ -511,7 +564,7 @@ static void finish_commit(rvo_hart* h, u32 inst, unsigned size, unsigned priv, i
   c.tag = h->exec_count; c.pc = h->curr_pc; c.inst = inst; c.size = (uint8_t)size;
   c.priv = (uint8_t)priv; c.trap = (uint8_t)trap;
   unsigned k = 0;
-  if (h->ch_ireg > 0) { c.ch[k].kind = RVO_CH_R; c.ch[k].key = (u64)h->ch_ireg; c.ch[k].val = h->x[h->ch_ireg]; ++k; }
+  if (h->ch_ireg > 0) { c.ch[k].kind = RVO_CH_R; c.ch[k].key = (u64)h->ch_ireg; c.ch[k].val = h->rv32 ? (uint32_t)h->x[h->ch_ireg] : h->x[h->ch_ireg]; ++k; }
   if (h->ch_freg >= 0) { c.ch[k].kind = RVO_CH_F; c.ch[k].key = (u64)h->ch_freg; c.ch[k].val = h->f[h->ch_freg]; ++k; }
   /* vector group (printTrace.cpp:424-441; Hart::lastVecReg Hart.cpp:5753): one v line per register of the group starting at
    * operand 0; the record carries a digest of the register's bytes */
@@ -868,6 +921,7 @@ static int ldst_translate_unsupported(rvo_hart* h)
 static int do_load(rvo_hart* h, u64 va, unsigned size, u64* out)
 {
   u64 tval, pa1, pa2;
+  if (h->rv32) va &= 0xffffffffULL;
   if (ldst_translate_unsupported(h)) return 0;
   unsigned c = ldst_addr(h, va, size, 1, &pa1, &pa2, &tval);
   if (c) { ldst_exception(h, c, tval); return 0; }
@@ -895,6 +949,7 @@ static void store_tohost(rvo_hart* h, u64 pa, u64 val, unsigned size)
 static int do_store(rvo_hart* h, u64 va, unsigned size, u64 val)
 {
   u64 tval, pa1, pa2;
+  if (h->rv32) va &= 0xffffffffULL;
   if (ldst_translate_unsupported(h)) return 0;
   unsigned c = ldst_addr(h, va, size, 2, &pa1, &pa2, &tval);
   if (c) { ldst_exception(h, c, tval); return 0; }
@@ -1020,8 +1075,9 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   if (!do_write) { wx(h, rd, prev); return; }
   u64 next = op == 1 ? src : op == 2 ? (prev | src) : (prev & ~src);
   /* doCsrWrite: counters pre-increment so the loop's own increment is cancelled (13251-13255) */
-  if (num == C_MINSTRET && !(h->mcountinhibit & 4)) h->instret++;
-  if (num == C_MCYCLE) h->cycle++;
+  const int w_ir = (num == C_MINSTRET || (h->rv32 && num == 0xB82)) && !(h->mcountinhibit & 4), w_cy = num == C_MCYCLE || (h->rv32 && num == 0xB80);
+  if (w_ir) h->instret++;
+  if (w_cy) h->cycle++;
   wx(h, rd, prev);
   if (num == C_SATP) {
     unsigned mode = (unsigned)(next >> 60);
@@ -1042,8 +1098,8 @@ static void exec_csr(rvo_hart* h, u32 inst, unsigned op, unsigned rd, unsigned n
   if (num == C_VSTART || num == C_VXSAT || num == C_VXRM || num == C_VCSR)   /* postCsrUpdate: markVsDirty (Hart.cpp:4731-4734) */
     if (((h->mstatus >> MST_VS_SH) & 3) != 3) write_mstatus_raw(h, h->mstatus | (3ULL << MST_VS_SH) | MST_SD);
 done:
-  if (num == C_MINSTRET && !(h->mcountinhibit & 4)) h->instret--;
-  if (num == C_MCYCLE) h->cycle--;
+  if (w_ir) h->instret--;
+  if (w_cy) h->cycle--;
 }
 
 /* ------------------------------------------------------------------ 16-bit expansion */
@@ -1059,7 +1115,7 @@ static u32 enc_j(u32 rd, i32 off)
 { u32 i = (u32)off; return (((i >> 20) & 1) << 31) | (((i >> 1) & 0x3ff) << 21) | (((i >> 11) & 1) << 20) | (((i >> 12) & 0xff) << 12) | (rd << 7) | 0x6f; }
 static i32 sx(u32 v, unsigned bits) { return (i32)(v << (32 - bits)) >> (32 - bits); }
 
-static u32 expand16(u32 c)
+static u32 expand16(u32 c, int rv32)
 {
   u32 q = c & 3, f3 = (c >> 13) & 7;
   u32 rdp = 8 + ((c >> 2) & 7), rs1p = 8 + ((c >> 7) & 7);
@@ -1075,17 +1131,27 @@ static u32 expand16(u32 c)
         return enc_i(0x13, 0, rdp, 2, (i32)imm); }
       case 1: return enc_i(0x07, 3, rdp, rs1p, (i32)uimm_d);          /* c.fld */
       case 2: return enc_i(0x03, 2, rdp, rs1p, (i32)uimm_w);          /* c.lw */
-      case 3: return enc_i(0x03, 3, rdp, rs1p, (i32)uimm_d);          /* c.ld */
+      case 3: if (rv32) return enc_s(0x23, 2, rs1p, rdp, 0);          /* RV32: the reference hands back its c.sw entry with the offset operand left
+                                                                         at zero for this code point (Decoder.cpp:1491-1502) */
+              return enc_i(0x03, 3, rdp, rs1p, (i32)uimm_d);          /* c.ld */
       case 5: return enc_s(0x27, 3, rs1p, rdp, (i32)uimm_d);          /* c.fsd */
       case 6: return enc_s(0x23, 2, rs1p, rdp, (i32)uimm_w);          /* c.sw */
-      case 7: return enc_s(0x23, 3, rs1p, rdp, (i32)uimm_d);          /* c.sd */
+      case 7: if (rv32) return enc_s(0x27, 2, rs1p, rdp, (i32)uimm_w);   /* c.fsw (Decoder.cpp:1548-1556) */
+              return enc_s(0x23, 3, rs1p, rdp, (i32)uimm_d);          /* c.sd */
       default: return 0;
     }
   }
   if (q == 1) {
     switch (f3) {
       case 0: return enc_i(0x13, 0, rd, rd, imm6);                    /* c.addi / c.nop */
-      case 1: if (rd == 0) return 0; return enc_i(0x1b, 0, rd, rd, imm6);  /* c.addiw */
+      case 1:
+        if (rv32) {                                                   /* c.jal (Decoder.cpp:1573-1588) */
+          i32 off = sx((((c >> 12) & 1) << 11) | (((c >> 11) & 1) << 4) | (((c >> 9) & 3) << 8) | (((c >> 8) & 1) << 10) |
+                       (((c >> 7) & 1) << 6) | (((c >> 6) & 1) << 7) | (((c >> 3) & 7) << 1) | (((c >> 2) & 1) << 5), 12);
+          return enc_j(1, off);
+        }
+        if (rd == 0) return 0;
+        return enc_i(0x1b, 0, rd, rd, imm6);  /* c.addiw */
       case 2: return enc_i(0x13, 0, rd, 0, imm6);                     /* c.li */
       case 3: {
         if (imm6 == 0) return 0;                                      /* reserved / c.mop */
@@ -1096,6 +1162,7 @@ static u32 expand16(u32 c)
         return ((u32)imm6 << 12) | (rd << 7) | 0x37; }                /* c.lui (sign-extended to 20 bits by the shift) */
       case 4: {
         u32 f2 = (c >> 10) & 3, sh = (((c >> 12) & 1) << 5) | ((c >> 2) & 31);
+        if (rv32 && f2 < 2 && (sh & 32)) return 0;                    /* Decoder.cpp:1628, 1635 */
         if (f2 == 0) return (0x00u << 26) | (sh << 20) | (rs1p << 15) | (5 << 12) | (rs1p << 7) | 0x13;
         if (f2 == 1) return (0x10u << 26) | (sh << 20) | (rs1p << 15) | (5 << 12) | (rs1p << 7) | 0x13;
         if (f2 == 2) return enc_i(0x13, 7, rs1p, rs1p, imm6);
@@ -1104,6 +1171,7 @@ static u32 expand16(u32 c)
           static const u32 f3s[4] = { 0, 4, 6, 7 };
           return enc_r(0x33, f3s[k], k == 0 ? 0x20 : 0, rs1p, rs1p, rdp);
         }
+        if (rv32) return 0;                                           /* Decoder.cpp:1686 */
         if (k == 0) return enc_r(0x3b, 0, 0x20, rs1p, rs1p, rdp);     /* c.subw */
         if (k == 1) return enc_r(0x3b, 0, 0, rs1p, rs1p, rdp);        /* c.addw */
         return 0; }                                                   /* c.mul / Zcb */
@@ -1119,10 +1187,13 @@ static u32 expand16(u32 c)
   if (q == 2) {
     u32 b12 = (c >> 12) & 1;
     switch (f3) {
-      case 0: return ((b12 << 5 | rs2) << 20) | (rd << 15) | (1 << 12) | (rd << 7) | 0x13;   /* c.slli */
+      case 0: if (rv32 && b12) return 0;                                                      /* Decoder.cpp:1719 */
+              return ((b12 << 5 | rs2) << 20) | (rd << 15) | (1 << 12) | (rd << 7) | 0x13;   /* c.slli */
       case 1: return enc_i(0x07, 3, rd, 2, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6)));   /* c.fldsp */
       case 2: if (rd == 0) return 0; return enc_i(0x03, 2, rd, 2, (i32)((b12 << 5) | (((c >> 4) & 7) << 2) | (((c >> 2) & 3) << 6)));
-      case 3: if (rd == 0) return 0; return enc_i(0x03, 3, rd, 2, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6)));
+      case 3: if (rv32) return enc_i(0x07, 2, rd, 2, (i32)((b12 << 5) | (((c >> 4) & 7) << 2) | (((c >> 2) & 3) << 6)));   /* c.flwsp (Decoder.cpp:1746-1757) */
+              if (rd == 0) return 0;
+              return enc_i(0x03, 3, rd, 2, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6)));
       case 4:
         if (!b12) {
           if (rs2 == 0) { if (rd == 0) return 0; return enc_i(0x67, 0, 0, rd, 0); }   /* c.jr */
@@ -1132,7 +1203,8 @@ static u32 expand16(u32 c)
         return enc_r(0x33, 0, 0, rd, rd, rs2);                                       /* c.add */
       case 5: return enc_s(0x27, 3, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6)));   /* c.fsdsp */
       case 6: return enc_s(0x23, 2, 2, rs2, (i32)((((c >> 9) & 0xf) << 2) | (((c >> 7) & 3) << 6)));  /* c.swsp */
-      default: return enc_s(0x23, 3, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6)));  /* c.sdsp */
+      default: if (rv32) return enc_s(0x27, 2, 2, rs2, (i32)((((c >> 9) & 0xf) << 2) | (((c >> 7) & 3) << 6)));   /* c.fswsp (Decoder.cpp:1804-1815) */
+               return enc_s(0x23, 3, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6)));  /* c.sdsp */
     }
   }
   return 0;
@@ -1155,17 +1227,23 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
   i64 immi = (i32)inst >> 20;
   u64 a = h->x[rs1], b = h->x[rs2];
   int zca = ext(h, RVO_ISA_C);
+  const int rv32 = h->rv32;
+  const u64 pcm = rv32 ? 0xffffffffULL : ~0ULL;          /* RV32: pc and addresses wrap at 32 bits */
+  if (rv32) {                                            /* encodings that exist on RV64 only */
+    if (op == 0x1b || op == 0x3b || (op == 0x03 && (f3 == 3 || f3 == 6)) || (op == 0x23 && f3 == 3)) goto ill;
+    if (op == 0x13 && (f3 == 1 || f3 == 5) && (inst & (1u << 25))) goto ill;         /* shamt[5] (Hart.cpp:11736-11746) */
+  }
   switch (op) {
     case 0x37: wx(h, rd, (u64)(i64)(i32)(inst & 0xfffff000u)); return;
     case 0x17: wx(h, rd, h->curr_pc + (u64)(i64)(i32)(inst & 0xfffff000u)); return;
     case 0x6f: {
       i64 off = ((i64)(i32)(inst & 0x80000000u) >> 11) | (inst & 0xff000) | ((inst >> 9) & 0x800) | ((inst >> 20) & 0x7fe);
-      u64 t = h->curr_pc + (u64)off;
+      u64 t = (h->curr_pc + (u64)off) & pcm;
       if (!zca && (t & 3)) { take_exception(h, 0, h->curr_pc, t); return; }          /* Hart.cpp:11687-11690 */
       wx(h, rd, h->curr_pc + size); h->pc = t & ~1ULL; return; }
     case 0x67: {
       if (f3 != 0) break;
-      u64 t = (a + (u64)immi) & ~1ULL;
+      u64 t = (a + (u64)immi) & ~1ULL & pcm;
       if (!zca && (t & 3)) { take_exception(h, 0, h->curr_pc, t); return; }          /* Hart.cpp:11711-11714 */
       wx(h, rd, h->curr_pc + size); h->pc = t; return; }
     case 0x63: {
@@ -1178,7 +1256,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
       }
       if (take) {
         i64 off = ((i64)(i32)(inst & 0x80000000u) >> 19) | ((inst & 0x80) << 4) | ((inst >> 20) & 0x7e0) | ((inst >> 7) & 0x1e);
-        u64 t = h->curr_pc + (u64)off;
+        u64 t = (h->curr_pc + (u64)off) & pcm;
         if (!zca && (t & 3)) { take_exception(h, 0, h->curr_pc, t); return; }        /* Hart.cpp:1652-1656 */
         h->pc = t & ~1ULL;
       }
@@ -1198,11 +1276,11 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
       u64 r; unsigned sh = (inst >> 20) & 63;
       switch (f3) {
         case 0: r = a + (u64)immi; break;
-        case 1: if ((inst >> 26) != 0) goto ill; r = a << sh; break;                  /* Hart.cpp:11736-11746 */
+        case 1: if ((inst >> 26) != 0) goto ill; r = a << sh; break;                  /* Hart.cpp:11736-11746 (RV32: wx keeps the low word) */
         case 2: r = (i64)a < immi; break;
         case 3: r = a < (u64)immi; break;
         case 4: r = a ^ (u64)immi; break;
-        case 5: if ((inst >> 26) == 0) r = a >> sh; else if ((inst >> 26) == 0x10) r = (u64)((i64)a >> sh); else goto ill; break;
+        case 5: if ((inst >> 26) == 0) r = (rv32 ? (u64)(u32)a : a) >> sh; else if ((inst >> 26) == 0x10) r = (u64)((i64)a >> sh); else goto ill; break;
         case 6: r = a | (u64)immi; break;
         default: r = a & (u64)immi; break;
       }
@@ -1220,6 +1298,19 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
       u64 r;
       if (f7 == 1) {
         if (!ext(h, RVO_ISA_M)) goto ill;                                            /* Hart.cpp:13966,14103 */
+        if (rv32) {                                                                  /* Hart<uint32_t>: 32-bit operands (Hart.cpp:13964-14170) */
+          const u32 aw = (u32)a, bw = (u32)b;
+          switch (f3) {
+            case 0: r = (u64)(aw * bw); break;
+            case 1: r = (u64)(((i64)(i32)aw * (i64)(i32)bw) >> 32); break;
+            case 2: r = (u64)(((i64)(i32)aw * (i64)(u64)bw) >> 32); break;
+            case 3: r = ((u64)aw * (u64)bw) >> 32; break;
+            case 4: r = bw == 0 ? ~0u : ((i32)aw == INT32_MIN && (i32)bw == -1) ? aw : (u32)((i32)aw / (i32)bw); break;
+            case 5: r = bw == 0 ? ~0u : aw / bw; break;
+            case 6: r = bw == 0 ? aw : ((i32)aw == INT32_MIN && (i32)bw == -1) ? 0 : (u32)((i32)aw % (i32)bw); break;
+            default: r = bw == 0 ? aw : aw % bw; break;
+          }
+        } else
         switch (f3) {
           case 0: r = a * b; break;
           case 1: r = (u64)(((i128)(i64)a * (i128)(i64)b) >> 64); break;
@@ -1232,12 +1323,12 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
         }
       } else if (f7 == 0) {
         switch (f3) {
-          case 0: r = a + b; break; case 1: r = a << (b & 63); break; case 2: r = (i64)a < (i64)b; break;
-          case 3: r = a < b; break; case 4: r = a ^ b; break; case 5: r = a >> (b & 63); break;
+          case 0: r = a + b; break; case 1: r = a << (b & (rv32 ? 31 : 63)); break; case 2: r = (i64)a < (i64)b; break;
+          case 3: r = a < b; break; case 4: r = a ^ b; break; case 5: r = rv32 ? (u64)((u32)a >> (b & 31)) : a >> (b & 63); break;
           case 6: r = a | b; break; default: r = a & b; break;
         }
       } else if (f7 == 0x20) {
-        if (f3 == 0) r = a - b; else if (f3 == 5) r = (u64)((i64)a >> (b & 63)); else goto ill;
+        if (f3 == 0) r = a - b; else if (f3 == 5) r = (u64)((i64)a >> (b & (rv32 ? 31 : 63))); else goto ill;
       } else goto ill;
       wx(h, rd, r); return; }
     case 0x3b: {
@@ -1304,7 +1395,7 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
         break;
       }
       if (f3 == 4) break;
-      { unsigned csrop = f3 & 3; u64 src = (f3 & 4) ? (u64)rs1 : a;
+      { unsigned csrop = f3 & 3; u64 src = (f3 & 4) ? (u64)rs1 : (rv32 ? (u64)(u32)a : a);
         exec_csr(h, raw, csrop, rd, inst >> 20, src, rs1 != 0); }
       return; }
     case 0x2f: exec_amo(h, inst, raw); return;
@@ -1323,9 +1414,9 @@ ill:
 static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
 {
   u32 rd = (inst >> 7) & 31, f3 = (inst >> 12) & 7, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31, f5 = inst >> 27;
-  if (!ext(h, RVO_ISA_A) || (f3 != 2 && f3 != 3)) { illegal(h, raw); return; }
+  if (!ext(h, RVO_ISA_A) || (f3 != 2 && f3 != 3) || (h->rv32 && f3 == 3)) { illegal(h, raw); return; }   /* .d forms: RV64 only (amo.cpp:886, 918, 964) */
   unsigned size = f3 == 2 ? 4 : 8;
-  u64 va = h->x[rs1], tval;
+  u64 va = h->rv32 ? (u64)(u32)h->x[rs1] : h->x[rs1], tval;
   if (f5 == 2) {                                            /* lr: amo.cpp:142-266 */
     if (rs2 != 0) { illegal(h, raw); return; }
     if (ldst_translate_unsupported(h)) return;
@@ -1491,7 +1582,7 @@ static void exec_fp(rvo_hart* h, u32 inst, u32 raw)
       }
       wx(h, rd, r); return; }
     case 0x18: {                                              /* fcvt.{w,wu,l,lu}.{s,d} : float.cpp:639-669, 898-948 */
-      if (rs2 > 3) goto ill;
+      if (rs2 > 3 || (h->rv32 && rs2 > 1)) goto ill;              /* the l / lu forms: RV64 only (float.cpp:900, 931, 1599, 1631) */
       if (!(dbl ? dp_legal(h) : fp_legal(h)) || !fp_begin(h, f3)) goto ill;
       uint_fast8_t rm = *SF.rm; u64 r;
       if (!dbl) {
@@ -1503,7 +1594,7 @@ static void exec_fp(rvo_hart* h, u32 inst, u32 raw)
       }
       wx(h, rd, r); fp_accrue(h); return; }
     case 0x1a: {                                              /* fcvt.{s,d}.{w,wu,l,lu} */
-      if (rs2 > 3) goto ill;
+      if (rs2 > 3 || (h->rv32 && rs2 > 1)) goto ill;              /* float.cpp:963, 996, 1655, 1680 */
       if (!(dbl ? dp_legal(h) : fp_legal(h)) || !fp_begin(h, f3)) goto ill;
       if (!dbl) {
         sf32 r = rs2 == 0 ? SF.i32_to_f32((i32)xa) : rs2 == 1 ? SF.ui32_to_f32((u32)xa) : rs2 == 2 ? SF.i64_to_f32((i64)xa) : SF.ui64_to_f32(xa);
@@ -1517,7 +1608,7 @@ static void exec_fp(rvo_hart* h, u32 inst, u32 raw)
       if (rs2 != 0) goto ill;
       if (f3 == 0) {
         if (!dbl) { if (!fp_legal(h)) goto ill; wx(h, rd, (u64)(i64)(i32)(u32)h->f[rs1]); }     /* raw bits: float.cpp:682-688 */
-        else { if (!dp_legal(h)) goto ill; wx(h, rd, h->f[rs1]); }
+        else { if (!dp_legal(h) || h->rv32) goto ill; wx(h, rd, h->f[rs1]); }                   /* fmv.x.d: RV64 only (float.cpp:1705) */
         return;
       }
       if (f3 == 1) {
@@ -1529,7 +1620,7 @@ static void exec_fp(rvo_hart* h, u32 inst, u32 raw)
     case 0x1e:                                                /* fmv.w.x / fmv.d.x */
       if (rs2 != 0 || f3 != 0) goto ill;
       if (!dbl) { if (!fp_legal(h)) goto ill; wr_s(h, rd, (u32)xa); }
-      else { if (!dp_legal(h)) goto ill; wf(h, rd, xa); }
+      else { if (!dp_legal(h) || h->rv32) goto ill; wf(h, rd, xa); }                            /* fmv.d.x: RV64 only (float.cpp:1732) */
       mark_fs_dirty(h); return;
     default: break;
   }
@@ -1624,8 +1715,9 @@ int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)
     }
     unsigned size = (inst & 3) == 3 ? 4 : 2;
     h->pc += size;                                           /* Hart.cpp:6120 */
+    if (h->rv32) h->pc &= 0xffffffffULL;
     if (size == 2) {
-      u32 e = ext(h, RVO_ISA_C) ? expand16(inst) : 0;
+      u32 e = ext(h, RVO_ISA_C) ? expand16(inst, h->rv32) : 0;
       if (e == 0) illegal(h, inst); else execute(h, e, inst, 2);
     } else
       execute(h, inst, inst, 4);
@@ -1666,7 +1758,7 @@ u64 rvo_state_hash(const rvo_hart* h)
       case C_SENVCFG: v = h->senvcfg; break; case C_SSCRATCH: v = h->sscratch; break; case C_SEPC: v = h->sepc; break;
       case C_SCAUSE: v = h->scause; break; case C_STVAL: v = h->stval; break; case C_SATP: v = h->satp; break;
       case C_MSTATUS: v = h->mstatus; break; case C_MCOUNTEREN: v = h->mcounteren; break; case C_MEPC: v = h->mepc; break;
-      default: v = csr_peek(h, num); break;
+      default: v = csr_peek64(h, num); break;          /* (an RV32 hart's file is digested in its RV64 shape, x registers sign-extended) */
     }
     s = rvo_fold(s, v);
   }

@@ -125,7 +125,8 @@ class Hart:
                  hart_id=0, reset_pc=None, tlb_entries=0, vlenb=0, features=0):
         """features: RVO_CFG_* configuration switches (same bit positions as wsp_config_info.features)."""
         self.L = lib()
-        cfg = Config(64, isa_flags(isa) | features, mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
+        self.xlen = 32 if isa.lower().startswith("rv32") else 64              # Session.cpp:1373-1424: the ISA string decides
+        cfg = Config(self.xlen, isa_flags(isa) | features, mem_base, mem_size, tohost or 0, 1 if tohost is not None else 0, hart_id,
                      mem_base if reset_pc is None else reset_pc, tlb_entries, vlenb)
         self.h = self.L.rvo_create(C.byref(cfg))
         if not self.h:

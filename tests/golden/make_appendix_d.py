@@ -61,6 +61,18 @@ def main():
         if m:
             vlines.append(dict(tag=int(m.group(1)), pc=int(m.group(4), 16), op=m.group(5), reg=int(m.group(6), 16), head=m.group(7), tail=m.group(8),
                                text=m.group(9)))
+    # RV32 sample (System<uint32_t>, rv32imc): the RV32 column layout - 8-digit pc, 2-digit register, 8-digit value
+    rv32_recs = []
+    for ln in bl[3].splitlines():
+        m = re.match(r"^#(\d+) (\d+) +([MSU]) ([0-9a-f]{8}) +([0-9a-f]{4,8}) ([rm]) ([0-9a-f]{2,8}) +([0-9a-f]{8})  (.*)$", ln.rstrip())
+        if m:
+            rv32_recs.append(dict(tag=int(m.group(1)), priv=m.group(3), pc=int(m.group(4), 16), op=m.group(5), kind=m.group(6), key=int(m.group(7), 16),
+                                  val=int(m.group(8), 16), text=m.group(9).strip(), line=ln.rstrip()))
+    rv32_final = {}
+    for ln in bl[3].splitlines():
+        if "final:" in ln:
+            for k, v in re.findall(r"(\w+)=([0-9a-f]+)", ln[ln.index("final:"):]):
+                rv32_final[k] = int(v, 16)
     out = {
         "source": "SURVEY.md Appendix D (reference Whisper v1.861, captured by the survey session)",
         "fp_trap": {"isa": "rv64imafdcv_zicsr", "base": 0x80000000, "words": [words[a] for a in sorted(words)],
@@ -76,6 +88,9 @@ def main():
                  "pokes": {"mstatus_mpp": 1, "mepc": 0x40000100, "satp": (8 << 60) | 0x80002, "pmpaddr0": (1 << 54) - 1, "pmpcfg0": 0x1f},
                  "mem": {"0x80002008": 0x200000cf}, "tohost": 0x80003000, "va_to_pa": 0x40000000,
                  "stop": "Successful stop: Hart 0: write to to-host"},
+        # RV32 sample: 16-bit parcels as the survey's caption lists them, poked at 0x80000000; the store goes to tohost = 0x1000
+        "rv32": {"isa": "rv32imc", "base": 0x80000000, "parcels": [0x4505, 0x4589, 0x952e, 0x12b7, 0x0000, 0x4305, 0xa023, 0x0062],
+                 "tohost": 0x1000, "records": rv32_recs, "final": rv32_final, "stop": "Successful stop: Hart 0: write to to-host"},
     }
     with open(os.path.join(HERE, "appendix_d.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -76,7 +76,7 @@ Sim* hs_create3(u32 isa, u64 mem_base, u64 mem_size, u64 tohost, u32 hart_id, u3
   s->L.m.vreg_ = s->vreg.data();
   s->L.m.cold_[CI_VTYPE] = 1ULL << 63;
   s->L.mem_base = mem_base; s->L.mem_size = mem_size; s->L.tohost = tohost; s->L.isa = isa; s->L.hart_id = hart_id;
-  s->L.h.pc = mem_base; s->L.h.mstatus = MSTATUS_RESET; s->L.h.priv = PRV_M;
+  s->L.h.pc = mem_base; s->L.h.mstatus = (isa & ISA_RV32) ? (3ULL << MST_MPP_SH) : MSTATUS_RESET; s->L.h.priv = PRV_M;
   s->max_exec = ~0ULL; s->L.stop_pc = ~0ULL; s->L.vsub = 0; s->L.vgrp = 1;
   return s;
 }
@@ -104,8 +104,8 @@ void hs_predecode(Sim* s, u64 addr, u64 n)
 void hs_use_fast(Sim* s, int f) { s->use_fast = f; }
 void hs_set_stop(Sim* s, u64 max_ret, u64 stop_pc) { s->max_ret = max_ret; s->L.stop_pc = stop_pc; }
 void hs_set_pc(Sim* s, u64 pc) { s->L.h.pc = pc & ~1ULL; }
-void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = v; }
-u64 hs_get_x(Sim* s, u32 i) { return s->L.m.x[i & 31]; }
+void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = s->L.rv32() ? (u64)(i64)(i32)v : v; }
+u64 hs_get_x(Sim* s, u32 i) { return s->L.rv32() ? (u32)s->L.m.x[i & 31] : s->L.m.x[i & 31]; }
 u64 hs_get_f(Sim* s, u32 i) { return s->L.m.f[i & 31]; }
 void hs_set_f(Sim* s, u32 i, u64 v) { s->L.m.f[i & 31] = v; }
 u64 hs_get_pc(Sim* s) { return s->L.h.pc; }

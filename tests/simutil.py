@@ -92,7 +92,7 @@ def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart
 
 def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0, features=0, max_ret=None, stop_pc=None):
     L = shim()
-    s = L.hs_create3(rvoracle.isa_flags(prog.isa) | (features or prog.meta.get("features", 0)), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
+    s = L.hs_create3(rvoracle.isa_flags(prog.isa) | (512 if prog.isa.lower().startswith("rv32") else 0) | (features or prog.meta.get("features", 0)), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
                      prog.meta.get("tlb_entries", 0), prog.meta.get("vlenb", 0))
     try:
         for paddr, data, _ in prog.segments:

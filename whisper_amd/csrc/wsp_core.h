@@ -31,7 +31,13 @@ typedef uint16_t u16;
 typedef uint8_t  u8;
 
 // ---------------------------------------------------------------------------------- constants
-enum { ISA_M = 1, ISA_A = 2, ISA_F = 4, ISA_D = 8, ISA_C = 16, ISA_S = 32, ISA_U = 64, ISA_V = 128, ISA_ZICNTR = 256 };
+enum { ISA_M = 1, ISA_A = 2, ISA_F = 4, ISA_D = 8, ISA_C = 16, ISA_S = 32, ISA_U = 64, ISA_V = 128, ISA_ZICNTR = 256,
+       // System<uint32_t> (Session.cpp:1373-1424).  An RV32 hart keeps its x registers SIGN-EXTENDED in the 64-bit register file and
+       // its pc zero-extended; the decoder lowers the RV32 integer operations onto the RV64 W-forms, which compute exactly the RV32
+       // results in that representation (add -> addw, sll -> sllw, mul -> mulw, div -> divw, ...; slt / sltu / and / or / xor are
+       // the same on sign-extended values), addresses wrap at 32 bits, and the CSR file is kept in its RV64 shape behind 32-bit
+       // views (csr_peek / csr_store).  Modelled for M / U mode with I M A F D C Zicsr Zicntr: no S mode (Sv32) and no V.
+       ISA_RV32 = 512 };
 // Configuration switches (HartConfig::applyConfig tags, HartConfig.cpp:2085-2958) travel in the same word as the ISA bits: they are
 // fixed for the lifetime of a batch exactly as the ISA is.  All zero = the reference's defaults.
 enum : u32 {
@@ -105,6 +111,19 @@ static constexpr u64 GOLDEN = 0x9E3779B97F4A7C15ULL;
 // ---------------------------------------------------------------------------------- decode
 WSP_HD i32 sx(u32 v, unsigned bits) { return (i32)(v << (32 - bits)) >> (32 - bits); }
 
+// RV32: the integer operations that differ between the two widths are executed as the RV64 W-forms (see ISA_RV32)
+WSP_HD Rec lower_rv32(Rec r)
+{
+  u32 op = r.w0 & 0xff, n = op;
+  switch (op) {
+    case OP_ADD: n = OP_ADDW; break; case OP_SUB: n = OP_SUBW; break; case OP_SLL: n = OP_SLLW; break; case OP_SRL: n = OP_SRLW; break;
+    case OP_SRA: n = OP_SRAW; break; case OP_MUL: n = OP_MULW; break; case OP_DIV: n = OP_DIVW; break; case OP_DIVU: n = OP_DIVUW; break;
+    case OP_REM: n = OP_REMW; break; case OP_REMU: n = OP_REMUW; break; default: break;
+  }
+  r.w0 = (r.w0 & ~0xffu) | n;
+  return r;
+}
+
 // 32-bit encodings (Decoder.cpp:2232). Extension gating that the reference performs at execute
 // time against the (read-only) misa/--isa configuration is folded in here because the ISA is
 // fixed for the lifetime of a batch; mstatus.FS-dependent legality stays in exec.
@@ -115,6 +134,8 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
   i32 immi = (i32)inst >> 20;
   Rec ill = mk(OP_ILLEGAL, 0, 0, 0, 0, F_SIZE4);
   Rec r = ill;
+  const bool rv32 = (isa & ISA_RV32) != 0;
+  if (rv32 && (op == 0x1b || op == 0x3b)) op = 0x7f;       // OP-IMM-32 / OP-32: RV64 only
   switch (op) {
     case 0x37: r = mk(OP_ADD, rd, 0, 0, (i32)(inst & 0xfffff000u), F_IMM); break;
     case 0x17: r = mk(OP_AUIPC, rd, 0, 0, (i32)(inst & 0xfffff000u)); break;
@@ -127,10 +148,11 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
       u32 o = f3 == 0 ? OP_BEQ : f3 == 1 ? OP_BNE : f3 == 4 ? OP_BLT : f3 == 5 ? OP_BGE : f3 == 6 ? OP_BLTU : f3 == 7 ? OP_BGEU : (u32)OP_ILLEGAL;
       if (o != OP_ILLEGAL) r = mk(o, 0, rs1, rs2, off);
       break; }
-    case 0x03: if (f3 != 7) r = mk(OP_LB + f3, rd, rs1, 0, immi); break;
-    case 0x23: if (f3 <= 3) r = mk(OP_SB + f3, 0, rs1, rs2, ((i32)(inst & 0xfe000000u) >> 20) | (i32)((inst >> 7) & 31)); break;
+    case 0x03: if (f3 != 7 && !(rv32 && (f3 == 3 || f3 == 6))) r = mk(OP_LB + f3, rd, rs1, 0, immi); break;      // ld / lwu: RV64 only
+    case 0x23: if (f3 <= 3 && !(rv32 && f3 == 3)) r = mk(OP_SB + f3, 0, rs1, rs2, ((i32)(inst & 0xfe000000u) >> 20) | (i32)((inst >> 7) & 31)); break;
     case 0x13: {
       u32 sh = (inst >> 20) & 63, top6 = inst >> 26;
+      if (rv32 && sh >= 32 && (f3 == 1 || f3 == 5)) break;                 // shamt[5] must be zero on RV32 (Hart.cpp:11736-11746)
       switch (f3) {
         case 0: r = mk(OP_ADD, rd, rs1, 0, immi, F_IMM); break;
         case 1: if (top6 == 0) r = mk(OP_SLL, rd, rs1, 0, (i32)sh, F_IMM); break;
@@ -176,7 +198,7 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
       break;
     case 0x2f: {
       u32 f5 = inst >> 27;
-      if (!(isa & ISA_A) || (f3 != 2 && f3 != 3)) break;
+      if (!(isa & ISA_A) || (f3 != 2 && f3 != 3) || (rv32 && f3 == 3)) break;      // .d forms: RV64 only (amo.cpp:886, 918, 964)
       u32 fl = f3 == 3 ? F_DBL : 0;
       if (f5 == 2) { if (rs2 == 0) r = mk(OP_LR, rd, rs1, 0, 0, fl); }
       else if (f5 == 3) r = mk(OP_SC, rd, rs1, rs2, 0, fl);
@@ -217,15 +239,16 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
           else if (dbl && rs2 == 0) r = mk(OP_FCVT_FF, rd, rs1, 0, (i32)f3, F_DBL);   // fcvt.d.s
           break;
         case 0x14: if (f3 <= 2) r = mk(OP_FCMP, rd, rs1, rs2, (i32)f3, dbl); break;
-        case 0x18: if (rs2 <= 3) r = mk(OP_FCVT_F2I, rd, rs1, rs2, (i32)f3, dbl); break;
-        case 0x1a: if (rs2 <= 3) r = mk(OP_FCVT_I2F, rd, rs1, rs2, (i32)f3, dbl); break;
-        case 0x1c: if (rs2 == 0) { if (f3 == 0) r = mk(OP_FMV_F2X, rd, rs1, 0, 0, dbl); else if (f3 == 1) r = mk(OP_FCLASS, rd, rs1, 0, 0, dbl); } break;
-        case 0x1e: if (rs2 == 0 && f3 == 0) r = mk(OP_FMV_X2F, rd, rs1, 0, 0, dbl); break;
+        case 0x18: if (rs2 <= (rv32 ? 1u : 3u)) r = mk(OP_FCVT_F2I, rd, rs1, rs2, (i32)f3, dbl); break;             // l / lu forms: RV64 only (float.cpp:900-996)
+        case 0x1a: if (rs2 <= (rv32 ? 1u : 3u)) r = mk(OP_FCVT_I2F, rd, rs1, rs2, (i32)f3, dbl); break;
+        case 0x1c: if (rs2 == 0) { if (f3 == 0) { if (!(rv32 && dbl)) r = mk(OP_FMV_F2X, rd, rs1, 0, 0, dbl); } else if (f3 == 1) r = mk(OP_FCLASS, rd, rs1, 0, 0, dbl); } break;   // fmv.x.d: RV64 only (float.cpp:1705)
+        case 0x1e: if (rs2 == 0 && f3 == 0 && !(rv32 && dbl)) r = mk(OP_FMV_X2F, rd, rs1, 0, 0, dbl); break;
         default: break;
       }
       break; }
     default: break;
   }
+  if (rv32) r = lower_rv32(r);
   r.w0 |= F_SIZE4;
   r.raw = inst;
   return r;
@@ -242,6 +265,7 @@ WSP_HD Rec decode16(u32 c, u32 isa)
   i32 imm6 = sx((b12 << 5) | ((c >> 2) & 31), 6);
   Rec r = mk(OP_ILLEGAL, 0, 0, 0, 0);
   bool fd = (isa & ISA_D) != 0;                 // Zcd = C + D (Hart.cpp:800-802)
+  const bool rv32 = (isa & ISA_RV32) != 0, ff = (isa & ISA_F) != 0;              // Zcf = C + F on RV32
   if (!(isa & ISA_C)) { r.raw = c; return r; }
   if (q == 0) {
     u32 ud = (((c >> 10) & 7) << 3) | (((c >> 5) & 3) << 6);
@@ -253,16 +277,26 @@ WSP_HD Rec decode16(u32 c, u32 isa)
         break; }
       case 1: if (fd) r = mk(OP_FLD, rdp, rs1p, 0, (i32)ud); break;
       case 2: r = mk(OP_LW, rdp, rs1p, 0, (i32)uw); break;
-      case 3: r = mk(OP_LD, rdp, rs1p, 0, (i32)ud); break;
+      case 3: if (rv32) r = mk(OP_SW, 0, rs1p, rdp, 0);                    // RV32: the reference hands back its c.sw entry with the offset operand
+              else r = mk(OP_LD, rdp, rs1p, 0, (i32)ud);                   // left at zero for this code point (Decoder.cpp:1491-1502)
+              break;
       case 5: if (fd) r = mk(OP_FSD, 0, rs1p, rdp, (i32)ud); break;
       case 6: r = mk(OP_SW, 0, rs1p, rdp, (i32)uw); break;
-      case 7: r = mk(OP_SD, 0, rs1p, rdp, (i32)ud); break;
+      case 7: if (rv32) { if (ff) r = mk(OP_FSW, 0, rs1p, rdp, (i32)uw); }  // c.fsw (Decoder.cpp:1548-1556)
+              else r = mk(OP_SD, 0, rs1p, rdp, (i32)ud);
+              break;
       default: break;
     }
   } else if (q == 1) {
     switch (f3) {
       case 0: r = mk(OP_ADD, rd, rd, 0, imm6, F_IMM); break;
-      case 1: if (rd != 0) r = mk(OP_ADDW, rd, rd, 0, imm6, F_IMM); break;
+      case 1:
+        if (rv32) {                                                        // c.jal (Decoder.cpp:1573-1588)
+          i32 off = sx((b12 << 11) | (((c >> 11) & 1) << 4) | (((c >> 9) & 3) << 8) | (((c >> 8) & 1) << 10) |
+                       (((c >> 7) & 1) << 6) | (((c >> 6) & 1) << 7) | (((c >> 3) & 7) << 1) | (((c >> 2) & 1) << 5), 12);
+          r = mk(OP_JAL, 1, 0, 0, off);
+        } else if (rd != 0) r = mk(OP_ADDW, rd, rd, 0, imm6, F_IMM);
+        break;
       case 2: r = mk(OP_ADD, rd, 0, 0, imm6, F_IMM); break;
       case 3:
         if (imm6 == 0) break;
@@ -273,6 +307,7 @@ WSP_HD Rec decode16(u32 c, u32 isa)
         break;
       case 4: {
         u32 f2 = (c >> 10) & 3, sh = (b12 << 5) | ((c >> 2) & 31), k = (c >> 5) & 3;
+        if (rv32 && b12 && f2 != 2) break;                                 // shamt[5] / c.subw / c.addw: RV64 only (Decoder.cpp:1628, 1635, 1686)
         if (f2 == 0) r = mk(OP_SRL, rs1p, rs1p, 0, (i32)sh, F_IMM);
         else if (f2 == 1) r = mk(OP_SRA, rs1p, rs1p, 0, (i32)sh, F_IMM);
         else if (f2 == 2) r = mk(OP_AND, rs1p, rs1p, 0, imm6, F_IMM);
@@ -290,10 +325,12 @@ WSP_HD Rec decode16(u32 c, u32 isa)
     }
   } else if (q == 2) {
     switch (f3) {
-      case 0: r = mk(OP_SLL, rd, rd, 0, (i32)((b12 << 5) | rs2), F_IMM); break;
+      case 0: if (!(rv32 && b12)) r = mk(OP_SLL, rd, rd, 0, (i32)((b12 << 5) | rs2), F_IMM); break;                  // Decoder.cpp:1719
       case 1: if (fd) r = mk(OP_FLD, rd, 2, 0, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6))); break;
       case 2: if (rd != 0) r = mk(OP_LW, rd, 2, 0, (i32)((b12 << 5) | (((c >> 4) & 7) << 2) | (((c >> 2) & 3) << 6))); break;
-      case 3: if (rd != 0) r = mk(OP_LD, rd, 2, 0, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6))); break;
+      case 3: if (rv32) { if (ff) r = mk(OP_FLW, rd, 2, 0, (i32)((b12 << 5) | (((c >> 4) & 7) << 2) | (((c >> 2) & 3) << 6))); }   // c.flwsp (Decoder.cpp:1746-1757)
+              else if (rd != 0) r = mk(OP_LD, rd, 2, 0, (i32)((b12 << 5) | (((c >> 5) & 3) << 3) | (((c >> 2) & 7) << 6)));
+              break;
       case 4:
         if (!b12) { if (rs2 == 0) { if (rd != 0) r = mk(OP_JALR, 0, rd, 0, 0); } else r = mk(OP_ADD, rd, 0, rs2, 0); }
         else if (rs2 == 0) { if (rd == 0) r = mk(OP_EBREAK, 0, 0, 0, 0); else r = mk(OP_JALR, 1, rd, 0, 0); }
@@ -301,9 +338,12 @@ WSP_HD Rec decode16(u32 c, u32 isa)
         break;
       case 5: if (fd) r = mk(OP_FSD, 0, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6))); break;
       case 6: r = mk(OP_SW, 0, 2, rs2, (i32)((((c >> 9) & 0xf) << 2) | (((c >> 7) & 3) << 6))); break;
-      default: r = mk(OP_SD, 0, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6))); break;
+      default: if (rv32) { if (ff) r = mk(OP_FSW, 0, 2, rs2, (i32)((((c >> 9) & 0xf) << 2) | (((c >> 7) & 3) << 6))); }             // c.fswsp (Decoder.cpp:1804-1815)
+               else r = mk(OP_SD, 0, 2, rs2, (i32)((((c >> 10) & 7) << 3) | (((c >> 7) & 7) << 6)));
+               break;
     }
   }
+  if (rv32) r = lower_rv32(r);
   r.raw = c;
   return r;
 }
@@ -330,10 +370,7 @@ enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, H
              HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */,
              HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */,
              HF_NOTRACE = 512 /* this run folds no commit records (set per launch): commit() returns at once */,
-             HF_VS_DIRTY = 1024 /* mstatus.VS == Dirty (kept by update_hot_flag): a vector write changes no mstatus bit */,
-             HF_DRY = 2048 /* the vector unit runs for the kernel's vector warm path (vec_call): anything that would trap, stop the
-                              hart or change mstatus raises CH_BAIL instead and changes nothing - the general path then executes the
-                              instruction in full.  Never stored */ };
+             HF_VS_DIRTY = 1024 /* mstatus.VS == Dirty (kept by update_hot_flag): a vector write changes no mstatus bit */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -373,7 +410,7 @@ enum : u32 {
   CH_IREG = 1, CH_FREG = 2, CH_MEM = 4, CH_GEN = 8, CH_SSTATUS = 16, CH_SEPC = 32, CH_SCAUSE = 64, CH_STVAL = 128,
   CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096,
   CH_VREG = 8192, CH_VL = 16384, CH_VTYPE = 32768,
-  CH_BAIL = 65536                  // HF_DRY: the instruction was not completed (and changed nothing)
+  CH_BAIL = 65536                  // Lane<MEM, DRY = true>: the instruction was not completed (and changed nothing)
 };
 struct Step {
   u32 chg, ireg, freg, gen_csr;
@@ -390,7 +427,10 @@ struct Step {
 //   word 1: ppn[43:0] | asid[59:44]
 enum : u32 { TE_VALID = 1, TE_GLOBAL = 2, TE_USER = 4, TE_R = 8, TE_W = 16, TE_X = 32, TE_A = 64, TE_D = 128 };
 static constexpr u64 TE_VPN_MASK = 0xfffffffffffffULL;
-template <class MEM> struct Lane {
+// DRY = true: the instantiation the kernel's vector warm path runs (wsp_vwarm): anything that would trap, stop the hart or change
+// mstatus raises CH_BAIL instead and changes nothing - the general path then executes the instruction in full.  A compile-time
+// switch, so that the trap / stop bodies and every hart register only they use drop out of the warm function.
+template <class MEM, bool DRY = false> struct Lane {
   Hot h;
   Step s;
   MEM m;
@@ -415,7 +455,12 @@ template <class MEM> struct Lane {
   WSP_HD bool in_mem(u64 a, u64 n) const { u64 off = a - mem_base; return a >= mem_base && off <= mem_size - n; }
 
   // ---- integer / fp register writes with trace capture
-  WSP_HD void wx(u32 rd, u64 v) { if (rd) m.wx(rd, v); s.chg |= CH_IREG; s.ireg = rd; s.ival = v; }
+  // RV32 (ISA_RV32): registers hold the 32-bit value sign-extended, the commit record carries it zero-extended; the pc and every
+  // address wrap at 32 bits
+  WSP_HD bool rv32() const { return (isa & ISA_RV32) != 0; }
+  WSP_HD u64 amask() const { return rv32() ? 0xffffffffULL : ~0ULL; }
+  WSP_HD void wx(u32 rd, u64 v)
+  { if (rv32()) { if (rd) m.wx(rd, (u64)(i64)(i32)v); s.ival = (u32)v; } else { if (rd) m.wx(rd, v); s.ival = v; } s.chg |= CH_IREG; s.ireg = rd; }
   WSP_HD void wf(u32 rd, u64 v) { m.wf(rd, v); s.chg |= CH_FREG; s.freg = rd; s.fval = v; }
   WSP_HD void wf_s(u32 rd, u32 v) { wf(rd, ext(ISA_D) ? (0xffffffff00000000ULL | v) : (u64)v); }          // FpRegs.hpp:248-269
   WSP_HD u32 rf_s(u32 r) { u64 v = m.rf(r); return (ext(ISA_D) && (v >> 32) != 0xffffffffu) ? 0x7fc00000u : (u32)v; }  // FpRegs.hpp:285-295
@@ -443,7 +488,7 @@ template <class MEM> struct Lane {
     if (f) mark_fs_dirty();
   }
 
-  WSP_HD bool dry_bail() { if (h.flags & HF_DRY) { s.chg |= CH_BAIL; return true; } return false; }
+  WSP_HD bool dry_bail() { if (DRY) { s.chg |= CH_BAIL; return true; } return false; }
   WSP_HD void stop(u32 st, u64 v) { if (dry_bail()) return; h.status = st; h.stop_value = v; }
 
   // ---- traps: initiateException + initiateTrap (Hart.cpp:3324-3397, 3565-3929)
@@ -872,6 +917,7 @@ template <class MEM> struct Lane {
   WSP_HD bool do_load(u64 va, u32 size, u64 cur_pc, u64& out)
   {
     u64 tval, pa1, pa2;
+    va &= amask();
     if (paging_unsupported()) return false;
     const u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
     if (c) { take_exception(c, cur_pc, tval, false); return false; }
@@ -883,6 +929,7 @@ template <class MEM> struct Lane {
   WSP_HD bool do_store(u64 va, u32 size, u64 val, u64 cur_pc)
   {
     u64 tval, pa1, pa2;
+    va &= amask();
     if (paging_unsupported()) return false;
     const u32 c = ldst_addr(va, size, 2, pa1, pa2, tval);
     if (c) { take_exception(c, cur_pc, tval, false); return false; }
@@ -918,6 +965,12 @@ template <class MEM> struct Lane {
       case C_VSTART: case C_VXSAT: case C_VXRM: case C_VCSR: case C_VL: case C_VTYPE: case C_VLENB: return ext(ISA_V) ? 1 : 0;   // CsRegs::enableVector
       default: break;
     }
+    if (rv32()) {   // CsRegs<uint32_t>: the high halves exist, and so do the odd pmpcfg registers
+      if (num == 0x310 || num == 0x31A || num == 0xB80 || num == 0xB82) return 1;                                  // mstatush menvcfgh mcycleh minstreth
+      if (num >= 0xC80 && num <= 0xC82) return ext(ISA_ZICNTR) ? 1 : 0;                                            // cycleh timeh instreth
+      if (num >= 0x3A0 && num <= 0x3EF) return 1;
+      if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || num == 0x7C7 || (num >= 0xB83 && num <= 0xB9F)) return -1;   // mhpmevent<n>h mseccfgh mhpmcounter<n>h
+    }
     if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   // pmpcfg (even only on rv64), pmpaddr0..63
     if (num >= 0xB03 && num <= 0xB1F) return -1;
     if (num >= 0x323 && num <= 0x33F) return -1;
@@ -930,7 +983,26 @@ template <class MEM> struct Lane {
   WSP_HD u64 epc_rmask() const { return ext(ISA_C) ? ~1ULL : ~3ULL; }
   // CsRegs::legalizeEnvcfg (CsRegs.cpp:6719): a reserved CBIE (2) keeps the previous field value
   WSP_HD static u64 legalize_envcfg(u64 prev, u64 next) { return ((next >> 4) & 3) == 2 ? (next & ~0x30ULL) | (prev & 0x30) : next; }
+  // The CSR file is kept in its RV64 shape; an RV32 hart sees 32-bit views of it (CsRegs<uint32_t>): the low half of each
+  // register with mstatus.SD and the interrupt bit of the cause registers at bit 31, the high halves under their own numbers,
+  // pmpcfg<2k+1> = the upper half of row k.
   WSP_HD u64 csr_peek(u32 num)
+  {
+    if (!rv32()) return csr_peek64(num);
+    switch (num) {
+      case C_MSTATUS: case C_SSTATUS: case C_MCAUSE: case C_SCAUSE: { const u64 v = csr_peek64(num); return (v & 0x7fffffffULL) | ((v >> 63) << 31); }
+      case C_MISA: return 0x4034112dULL;
+      case 0x310: return 0;                                                    // mstatush: MBE / SBE hardwired zero
+      case 0x31A: return csr_peek64(C_MENVCFG) >> 32;
+      case 0xB80: case 0xC80: return h.cycle >> 32;
+      case 0xB82: case 0xC82: return h.instret >> 32;
+      case 0xC81: return h.exec >> 32;
+      default:
+        if (num >= 0x3A0 && num <= 0x3AF) return (m.cold(CI_PMPCFG0 + ((num - 0x3A0) >> 1)) >> (32 * (num & 1))) & 0xffffffffULL;
+        return csr_peek64(num) & 0xffffffffULL;
+    }
+  }
+  WSP_HD u64 csr_peek64(u32 num)
   {
     switch (num) {
       case C_FFLAGS: return h.fcsr & 0x1f;
@@ -965,6 +1037,28 @@ template <class MEM> struct Lane {
   WSP_HD void csr_store(u32 num, u64 v)
   {
     bool sup = ext(ISA_S);
+    if (rv32()) {                                          // a 32-bit write, brought into the RV64 shape of the file
+      v &= 0xffffffffULL;
+      switch (num) {
+        case C_MCAUSE: case C_SCAUSE: v = (v & 0x7fffffffULL) | ((v >> 31) << 63); break;
+        case C_MENVCFG: v |= m.cold(CI_MENVCFG) & ~0xffffffffULL; break;
+        case 0x31A: num = C_MENVCFG; v = (v << 32) | (m.cold(CI_MENVCFG) & 0xffffffffULL); break;
+        case 0x310: return;                                                    // mstatush: nothing writable
+        case C_MCYCLE: v |= h.cycle & ~0xffffffffULL; break;
+        case C_MINSTRET: v |= h.instret & ~0xffffffffULL; break;
+        case 0xB80: h.cycle = (h.cycle & 0xffffffffULL) | (v << 32); return;
+        case 0xB82: h.instret = (h.instret & 0xffffffffULL) | (v << 32); return;
+        default:
+          if (num >= 0x3A0 && num <= 0x3AF) {              // pmpcfg<n>: four entries, half of row n / 2
+            const u32 k = CI_PMPCFG0 + ((num - 0x3A0) >> 1), sh = 32 * (num & 1);
+            const u64 keep = m.cold(k) & ~(0xffffffffULL << sh);
+            m.cold(k) = legalize_pmpcfg(m.cold(k), keep | (v << sh)) & 0x9f9f9f9f9f9f9f9fULL;
+            update_pmp_flags();
+            return;
+          }
+          break;
+      }
+    }
     switch (num) {
       case C_FFLAGS: h.fcsr = (h.fcsr & ~0x1fu) | (u32)(v & 0x1f); break;
       case C_FRM: h.fcsr = (h.fcsr & ~0xe0u) | (u32)((v & 7) << 5); break;
@@ -1048,7 +1142,9 @@ template <class MEM> struct Lane {
     u64 next = op == 0 ? src : op == 1 ? (prev | src) : (prev & ~src);
     // the reference pre-increments then post-decrements the counter being written so that the run
     // loop's own increment is cancelled (Hart.cpp:13251-13255, 13354-13360)
-    bool w_ir = num == C_MINSTRET && !(h.flags & HF_INH_IR), w_cy = num == C_MCYCLE;
+    bool w_ir = (num == C_MINSTRET || (rv32() && num == 0xB82)) && !(h.flags & HF_INH_IR), w_cy = num == C_MCYCLE || (rv32() && num == 0xB80);
+    if (w_ir) h.instret++;
+    if (w_cy) h.cycle++;
     wx(rd, prev);
     if (num == C_SATP) {
       u32 mode = (u32)(next >> 60);
@@ -1369,7 +1465,7 @@ template <class MEM> struct Lane {
     const u64 stride = strided ? stride_reg : esz;                              // vector-ls.cpp:939-1040: the same loop stepping by x[rs2]
     u64 addr = base + (u64)start * stride;
     if (gx8 < 8) gx8 = 8;
-    const bool dry = (h.flags & HF_DRY) != 0;
+    const bool dry = DRY;
     if ((vgrp > 1 || dry) && v_ldst_pure()) {
       // lanes.  Pass 1 finds the first element that faults (the checks have no side effect without paging), pass 2 loads the
       // elements before it, then every lane takes that element's trap: what the serial loop leaves behind.
@@ -1428,7 +1524,7 @@ template <class MEM> struct Lane {
     const u64 stride = strided ? stride_reg : esz;
     u64 addr = base + (u64)start * stride;
     const u64 astride = (i64)stride < 0 ? 0 - stride : stride;                     // elements that overlap in memory are stored in order
-    const bool dry = (h.flags & HF_DRY) != 0;
+    const bool dry = DRY;
     if (dry && !(v_ldst_pure() && astride >= esz)) { dry_bail(); return; }
     if ((vgrp > 1 || dry) && v_ldst_pure() && astride >= esz) {
       // lanes, as in v_load_unit; an element that lands in the code image or on tohost has side effects on hart state beyond
@@ -2747,7 +2843,7 @@ template <class MEM> struct Lane {
     const u32 lumop = (inst >> 20) & 31, nf = inst >> 29, mew = (inst >> 28) & 1;
     const u32 eew = f3 == 0 ? 0 : f3 - 4;
     // the warm path takes unit-stride, strided and mask loads / stores (their fault scan comes before the first write)
-    if ((h.flags & HF_DRY) && !(mew == 0 && nf == 0 && ((mop == 0 && (lumop == 0 || lumop == 0xb)) || mop == 2))) { dry_bail(); return; }
+    if (DRY && !(mew == 0 && nf == 0 && ((mop == 0 && (lumop == 0 || lumop == 0xb)) || mop == 2))) { dry_bail(); return; }
     if (mop == 0 && lumop == 8) {                                               // whole registers (Decoder.cpp:949-967, 1184-1195)
       if (store) { if (mew || f3 != 0 || (nf != 0 && nf != 1 && nf != 3 && nf != 7)) { illegal(r, cur_pc); return; } }
       else if (mew) { vec_fail(r, cur_pc); return; }
@@ -2785,8 +2881,9 @@ template <class MEM> struct Lane {
   }
   template <bool TRACE> WSP_HD void wx_fast(u32 rd, u64 v)
   {
+    if (rv32()) v = (u64)(i64)(i32)v;
     m.wx(rd, rd ? v : 0);                       // x0 slot always holds zero: no branch
-    if (TRACE) { s.chg = CH_IREG; s.ireg = rd; s.ival = v; }
+    if (TRACE) { s.chg = CH_IREG; s.ireg = rd; s.ival = rv32() ? (u64)(u32)v : v; }
   }
   // pre-decoded fetch: false when the slot is not trustworthy (outside the decoded text, straddling)
   WSP_HD bool hot_fetch(const Rec* recs, Rec& rec) const
@@ -2827,19 +2924,19 @@ template <class MEM> struct Lane {
       case OP_NOP: return true;
       case OP_JAL: {
         if (!ext(ISA_C)) return false;
-        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL; return true; }
+        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL & amask(); return true; }
       case OP_JALR: {
         if (!ext(ISA_C)) return false;
-        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (a + (u64)(i64)r.imm) & ~1ULL; return true; }
+        wx_fast<TRACE>(rd, cur_pc + ((r.w0 & F_SIZE4) ? 4 : 2)); h.pc = (a + (u64)(i64)r.imm) & ~1ULL & amask(); return true; }
       case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
         if (!ext(ISA_C)) return false;
         bool take = op == OP_BEQ ? a == b : op == OP_BNE ? a != b : op == OP_BLT ? (i64)a < (i64)b
                   : op == OP_BGE ? (i64)a >= (i64)b : op == OP_BLTU ? a < b : a >= b;
-        if (take) h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL;
+        if (take) h.pc = (cur_pc + (u64)(i64)r.imm) & ~1ULL & amask();
         return true; }
       case OP_LB: case OP_LH: case OP_LW: case OP_LD: case OP_LBU: case OP_LHU: case OP_LWU: {
         const u32 k = op - OP_LB, sz = 1u << (k & 3);
-        const u64 va = a + (u64)(i64)r.imm;
+        const u64 va = (a + (u64)(i64)r.imm) & amask();
         if ((va & (sz - 1)) || !in_mem(va, sz) || va == tohost) return false;
         const u64 off = va - mem_base; u64 v;
         switch (k) {
@@ -2850,7 +2947,7 @@ template <class MEM> struct Lane {
         wx_fast<TRACE>(rd, v); return true; }
       case OP_SB: case OP_SH: case OP_SW: case OP_SD: {
         const u32 k = op - OP_SB, sz = 1u << k;
-        const u64 va = a + (u64)(i64)r.imm;
+        const u64 va = (a + (u64)(i64)r.imm) & amask();
         if ((va & (sz - 1)) || !in_mem(va, sz) || va == tohost || va == tohost + 4 || (va + sz > text_lo && va < text_hi)) return false;
         const u64 off = va - mem_base;
         const u64 sv = k == 3 ? b : (b & ((1ULL << (8 * sz)) - 1));
@@ -2874,17 +2971,14 @@ template <class MEM> struct Lane {
     h.thash = t;
   }
 
-  // The vector unit is large: out of line on the GPU, ONE compiled copy for both of its callers.  The hart goes in by value and
-  // what the unit can change (the hot registers and the commit bookkeeping; everything else it changes is in LDS / HBM) comes
-  // back by value: no address of the caller's Lane is taken (inside the unit the copy is a private object that the LDS / HBM
-  // stores of the element loops cannot alias).  mode bits 1:0: 0 OP-V, 1 vector load, 2 vector store.  Bit 2: the call comes from
-  // the kernel's vector warm path (HF_DRY is set in L.h.flags): a completed instruction's commit record is folded here.
+  // The vector unit is large: out of line on the GPU.  For the general path the hart goes in by value and what the unit can
+  // change (the hot registers and the commit bookkeeping; everything else it changes is in LDS / HBM) comes back by value: no
+  // address of the caller's Lane is taken.  kind: 0 OP-V, 1 vector load, 2 vector store.  (The vector warm path has its own
+  // copy of the unit, compiled for DRY = true inside wsp_vwarm.)
   struct VecRet { Hot h; Step s; };
-  static WSP_HDN VecRet vec_call(Lane L, Rec r, u64 a, u64 b, u64 cur_pc, u32 mode)
+  static WSP_HDN VecRet vec_call(Lane L, Rec r, u64 a, u64 b, u64 cur_pc, u32 kind)
   {
-    const u32 kind = mode & 3;
     if (kind == 0) L.exec_vector_body(r, a, b, cur_pc); else L.exec_vector_ldst_body(r, a, b, cur_pc, kind == 2);
-    if ((mode & 4) && !(L.s.chg & CH_BAIL)) L.template commit<true>(cur_pc, r.raw, 4, PRV_M, 0);
     VecRet o; o.h = L.h; o.s = L.s; return o;
   }
 #if defined(__HIPCC__)
@@ -2921,9 +3015,16 @@ template <class MEM> struct Lane {
       case OP_SRLW: wx(rd, (u64)(i64)(i32)((u32)a >> (b & 31))); break;
       case OP_SRAW: wx(rd, (u64)(i64)((i32)a >> (b & 31))); break;
       case OP_MUL: wx(rd, a * b); break;                                                     // Hart.cpp:13964-14100
-      case OP_MULH: { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; wx(rd, hi); break; }
-      case OP_MULHSU: { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; wx(rd, hi); break; }
-      case OP_MULHU: wx(rd, wsf::mul64x64(a, b).hi); break;
+      case OP_MULH: case OP_MULHSU: case OP_MULHU:
+        if (rv32()) {                                                                        // Hart<uint32_t>: 32-bit operands
+          const u32 aw = (u32)a, bw = (u32)b;
+          wx(rd, op == OP_MULH ? (u64)(((i64)(i32)aw * (i64)(i32)bw) >> 32) : op == OP_MULHSU ? (u64)(((i64)(i32)aw * (i64)(u64)bw) >> 32) : ((u64)aw * (u64)bw) >> 32);
+          break;
+        }
+        if (op == OP_MULH) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; wx(rd, hi); }
+        else if (op == OP_MULHSU) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; wx(rd, hi); }
+        else wx(rd, wsf::mul64x64(a, b).hi);
+        break;
       case OP_DIV: wx(rd, b == 0 ? ~0ULL : ((i64)a == INT64_MIN && (i64)b == -1) ? a : (u64)((i64)a / (i64)b)); break;   // Hart.cpp:14111-14170
       case OP_DIVU: wx(rd, b == 0 ? ~0ULL : a / b); break;
       case OP_REM: wx(rd, b == 0 ? a : ((i64)a == INT64_MIN && (i64)b == -1) ? 0 : (u64)((i64)a % (i64)b)); break;
@@ -2935,18 +3036,18 @@ template <class MEM> struct Lane {
       case OP_REMUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? x : x % y)); break; }
       case OP_AUIPC: wx(rd, cur_pc + (u64)(i64)r.imm); break;
       case OP_JAL: {
-        u64 t = cur_pc + (u64)(i64)r.imm;
+        u64 t = (cur_pc + (u64)(i64)r.imm) & amask();
         if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                  // Hart.cpp:11687-11690
         wx(rd, cur_pc + size); h.pc = t & ~1ULL; break; }
       case OP_JALR: {
-        u64 t = (a + (u64)(i64)r.imm) & ~1ULL;
+        u64 t = (a + (u64)(i64)r.imm) & ~1ULL & amask();
         if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                  // Hart.cpp:11711-11714
         wx(rd, cur_pc + size); h.pc = t; break; }
       case OP_BEQ: case OP_BNE: case OP_BLT: case OP_BGE: case OP_BLTU: case OP_BGEU: {
         bool take = op == OP_BEQ ? a == b : op == OP_BNE ? a != b : op == OP_BLT ? (i64)a < (i64)b
                   : op == OP_BGE ? (i64)a >= (i64)b : op == OP_BLTU ? a < b : a >= b;
         if (take) {
-          u64 t = cur_pc + (u64)(i64)r.imm;
+          u64 t = (cur_pc + (u64)(i64)r.imm) & amask();
           if (!zca && (t & 3)) { take_exception(0, cur_pc, t, true); break; }                // Hart.cpp:1652-1656
           h.pc = t & ~1ULL;
         }
@@ -2985,8 +3086,8 @@ template <class MEM> struct Lane {
         if (h.priv == PRV_U || (h.priv == PRV_S && (h.mstatus & MST_TVM))) { illegal(r, cur_pc); break; }
         sfence(rec_rs1(r) != 0, a, rec_rs2(r) != 0, b);                                      // by register number (Hart.cpp:12139-12173)
         break;
-      case OP_CSRRW: case OP_CSRRS: case OP_CSRRC: exec_csr(r, op - OP_CSRRW, (r.w0 & F_IMM) ? (u64)rec_rs1(r) : a, cur_pc); break;
-      case OP_LR: case OP_SC: case OP_AMO: exec_atomic(r, a, b, cur_pc); break;
+      case OP_CSRRW: case OP_CSRRS: case OP_CSRRC: exec_csr(r, op - OP_CSRRW, (r.w0 & F_IMM) ? (u64)rec_rs1(r) : (a & amask()), cur_pc); break;
+      case OP_LR: case OP_SC: case OP_AMO: exec_atomic(r, a & amask(), b, cur_pc); break;
       case OP_FLW: case OP_FLD: {                                                            // float.cpp:281-298, 1019-1036
         if (!fp_on()) { illegal(r, cur_pc); break; }
         u64 v;
@@ -3067,7 +3168,7 @@ template <class MEM> struct Lane {
       return false;
     }
     if (fr != 0) return false;
-    h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);   // Hart.cpp:6120
+    h.pc = (cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2)) & amask();   // Hart.cpp:6120
     a = m.rx(rec_rs1(rec));
     b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
     return true;
@@ -3094,7 +3195,7 @@ template <class MEM> struct Lane {
     bool have = false;
     if (recs && h.priv == PRV_M && !(h.flags & (HF_CODE_DIRTY | HF_PMP_MLOCK)) && hot_fetch(recs, rec)) {
       if ((rec.w0 & 0xff) == OP_STOPCHK) { const Rec r2 = decode(rec.raw, isa); rec.w0 = r2.w0; rec.imm = r2.imm; }   // another hart's stop address
-      h.pc = cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2);
+      h.pc = (cur_pc + ((rec.w0 & F_SIZE4) ? 4 : 2)) & amask();
       a = m.rx(rec_rs1(rec));
       b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
       have = true;

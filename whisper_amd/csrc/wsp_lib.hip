@@ -71,12 +71,16 @@ extern __shared__ __align__(16) u64 wsp_lds[];
 __device__ __forceinline__ u8* wsp_vreg_lds(u32 off) { return (u8*)wsp_lds + off; }
 struct DevMem {
   u64* xs; u64* fs; u64* cold_; u64* tlb_; u8* arena; u32 S, lpw_shift;
+  u64* vcsr_;          // vstart, vcsr, vl, vtype of this hart: in LDS while the step kernel runs (null when the ISA has no V)
   u32 voff;            // byte offset in LDS of this hart's vector register file ([32][vlenb], element 0 first)
   __device__ __forceinline__ u64 rx(u32 r) const { return xs[r ? r : 32]; }
   __device__ __forceinline__ void wx(u32 r, u64 v) { xs[r] = v; }
   __device__ __forceinline__ u64 rf(u32 r) const { return fs[r]; }
   __device__ __forceinline__ void wf(u32 r, u64 v) { fs[r] = v; }
-  __device__ __forceinline__ u64& cold(u32 i) { return cold_[(size_t)i * S]; }
+#ifndef WSP_VCSR_LDS
+#define WSP_VCSR_LDS 1
+#endif
+  __device__ __forceinline__ u64& cold(u32 i) { return (WSP_VCSR_LDS && i >= CI_VSTART && i <= CI_VTYPE) ? vcsr_[i - CI_VSTART] : cold_[(size_t)i * S]; }
   __device__ __forceinline__ u64& tlb(u32 i) { return tlb_[i]; }
   // element of 1 << esz bytes at byte offset o (a multiple of the size) of this hart's vector register file
   __device__ __forceinline__ u64 vld(u32 o, u32 esz) const
@@ -114,13 +118,14 @@ struct DevMem {
 __device__ __forceinline__ u32 ln_of(const DevState& d)
 { const u32 lane = threadIdx.x; return (lane < d.lpw && blockIdx.x * d.lpw + lane < d.n_harts) ? lane : 0; }
 
-__device__ __forceinline__ void wsp_lane_setup(Lane<DevMem>& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
+template <class LaneT> __device__ __forceinline__ void wsp_lane_setup(LaneT& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
 {
   L.m.xs = wsp_lds + ln * WSP_XSLOTS;
   L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot;
   L.m.tlb_ = d.tlb + (size_t)(wave * d.lpw + ln) * 2 * d.tlb_n; L.tlb_n = d.tlb_n;
   L.m.voff = d.lpw * (2 * WSP_XSLOTS * 8) + ln * 32 * d.vlenb; L.vlenb = d.vlenb;
+  L.m.vcsr_ = wsp_lds + d.lpw * (2 * WSP_XSLOTS + 4 * d.vlenb) + ln * 4;
   if (d.ring) { L.ring_ = d.ring + (size_t)(wave * d.lpw + ln) * d.ring_cap; L.ring_pos_ = d.ring_pos + wave * d.lpw + ln; L.ring_cap = d.ring_cap; }
   L.m.arena = d.arena + (size_t)wave * d.lpw * d.mem_size + (size_t)ln * 8;
   L.m.S = d.S; L.m.lpw_shift = d.lpw_shift;
@@ -222,7 +227,7 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
 {
   Lane<DevMem> L;
   L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.m.cold_ = nullptr; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
@@ -245,28 +250,99 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
 // same minimal hart (registers only: no HBM state is loaded or stored, the vector registers are in LDS) and runs the vector unit
 // (Lane::vec_call) in lock step; the unit's element loops marked "lanes" are split, lane k of the sub-group taking the elements
 // k, k + vgrp, ... (the lanes-per-element mapping of the reference's loops, vector.cpp:808-855, vector-float.cpp:667-691,
-// vector-ls.cpp:156-247).  The unit runs dry (HF_DRY): whatever would trap, stop the hart or change mstatus changes nothing and
+// vector-ls.cpp:156-247).  The unit runs dry (Lane<DevMem, true>): whatever would trap, stop the hart or change mstatus changes nothing and
 // comes back as handled = 0; the general path then executes that instruction in full.  mstatus is synthetic: M mode, VS Dirty, FS
 // Dirty or Off (Off sends an FP vector instruction of a hart whose FS is not Dirty yet to the general path).
-template <bool TRACE>
-__device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
+__device__ __forceinline__ u32 wsp_uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 wsp_uni64(u64 v) { return (u64)wsp_uni32((u32)v) | ((u64)wsp_uni32((u32)(v >> 32)) << 32); }
+// Returns in `handled` the number of instructions completed: the call goes on with the instructions that follow while they are
+// vector instructions too (at most max_n, the hart's remaining budget), so that a strip-mined loop body costs one call.
+// Lanes are grouped by instruction word: each distinct word present is executed once, for the lanes that hold it, with the word
+// in scalar registers - the unit's decode and dispatch then run on the scalar unit (the sub-groups of a wave of replicas hold the
+// same word, and even a mixed wave pays no more than the divergent form would).
+struct VWarmArgs { const Rec* recs; u64 text_lo, text_hi, tohost; };
+__device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags, u32 max_n)
 {
   const DevState& d = *dp;
-  const u32 wave = blockIdx.x, ln = threadIdx.x & (d.lpw - 1), slot = wave * 64 + ln;
-  Lane<DevMem> L; const Rec* recs;
-  wsp_lane_setup(L, d, wave, ln, slot, recs);
+  // what is the same for every lane of the wave goes through readfirstlane: scalar registers, not one vector register per lane
+  const u32 lpw = wsp_uni32(d.lpw), lpw_shift = wsp_uni32(d.lpw_shift), S = wsp_uni32(d.S), vlenb = wsp_uni32(d.vlenb);
+  const u32 wave = blockIdx.x, ln = threadIdx.x & (lpw - 1), slot = wave * 64 + ln;
+  Lane<DevMem, true> L;
+  L.m.xs = wsp_lds + ln * WSP_XSLOTS;
+  L.m.fs = wsp_lds + (lpw + ln) * WSP_XSLOTS;
+  L.m.cold_ = (u64*)(size_t)wsp_uni64((u64)(size_t)d.cold) + slot;
+  L.m.tlb_ = nullptr; L.tlb_n = 0;
+  L.m.voff = lpw * (2 * WSP_XSLOTS * 8) + ln * 32 * vlenb; L.vlenb = vlenb;
+  L.m.vcsr_ = wsp_lds + lpw * (2 * WSP_XSLOTS + 4 * vlenb) + ln * 4;
   L.ring_ = nullptr; L.ring_pos_ = nullptr; L.ring_cap = 0;      // (no ring on this path: HF_RING keeps a hart off it)
-  L.vsub = threadIdx.x >> d.lpw_shift; L.vgrp = 64u >> d.lpw_shift;
-  L.h.pc = pc + 4; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_VS_SH) | ((flags & HF_FS_DIRTY) ? (3ULL << MST_FS_SH) : 0) | MST_SD;
+  L.mem_base = wsp_uni64(d.mem_base); L.mem_size = wsp_uni64(d.mem_size); L.isa = wsp_uni32(d.isa);
+  L.m.arena = (u8*)(size_t)wsp_uni64((u64)(size_t)d.arena) + (size_t)wave * lpw * L.mem_size + (size_t)ln * 8;
+  L.m.S = S; L.m.lpw_shift = lpw_shift;
+  L.hart_id = wsp_uni32(d.hart_id_base) + wave * lpw + ln;
+  L.tohost = va.tohost; L.stop_pc = ~0ULL; L.text_lo = va.text_lo; L.text_hi = va.text_hi;
+  L.vsub = threadIdx.x >> lpw_shift; L.vgrp = 64u >> lpw_shift;
+  L.h.mstatus = MSTATUS_RESET | (3ULL << MST_VS_SH) | ((flags & HF_FS_DIRTY) ? (3ULL << MST_FS_SH) : 0) | MST_SD;
   L.h.cycle = 0; L.h.instret = 0; L.h.exec = 0; L.h.retired = 0; L.h.thash = thash; L.h.lr_addr = 0; L.h.exec_last_ill = 0; L.h.stop_value = 0;
   L.h.fcsr = fcsr; L.h.priv = PRV_M; L.h.status = ST_RUNNING; L.h.consec_ill = 0; L.h.htif_dev = 0;
-  L.h.flags = flags | HF_DRY | (TRACE ? 0u : (u32)HF_NOTRACE);
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
-  Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
-  const u32 op = w0 & 0xff;
-  const u64 a = L.m.rx(rec_rs1(rec)), b = (w0 & F_IMM) ? (u64)(i64)imm : L.m.rx(rec_rs2(rec));
-  const Lane<DevMem>::VecRet o = Lane<DevMem>::vec_call(L, rec, a, b, pc, (op == OP_VEC ? 0u : op == OP_VLD ? 1u : 2u) | 4u);
-  WarmRet r; r.thash = o.h.thash; r.fcsr = o.h.fcsr; r.handled = (o.s.chg & CH_BAIL) ? 0u : 1u;
+  L.h.flags = flags;                                             // HF_NOTRACE (set per launch) makes commit() return at once
+  u32 n_done = 0;
+  bool alive = true;
+  const u32 text_len = (u32)(va.text_hi - va.text_lo);
+  // (WSP_VW_GROUP: execute each distinct instruction word once with the word in scalar registers.  Measured slower than letting
+  // the lanes diverge - 0.39 vs 0.49 GIPS on the vector-kernel workload - and off by default; the burst is worth +43 %.)
+#ifndef WSP_VW_GROUP
+#define WSP_VW_GROUP 0
+#endif
+#ifndef WSP_VW_BURST
+#define WSP_VW_BURST 1
+#endif
+  if (!WSP_VW_BURST) max_n = 1;
+  for (;;) {
+    bool done = false;
+#define WSP_VW_ONE(W0, IMM, RAW) do {                                                                                             \
+      L.h.pc = pc + 4;                                                                                                            \
+      L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; \
+      Rec rec; rec.w0 = (W0); rec.imm = (IMM); rec.pad = 0; rec.raw = (RAW);                                                      \
+      const u32 op = rec.w0 & 0xff;                                                                                               \
+      const u64 a = L.m.rx(rec_rs1(rec)), b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : L.m.rx(rec_rs2(rec));                         \
+      if (op == OP_VEC) L.exec_vector_body(rec, a, b, pc); else L.exec_vector_ldst_body(rec, a, b, pc, op == OP_VST);             \
+      done = !(L.s.chg & CH_BAIL);                                                                                                \
+      if (done) L.template commit<true>(pc, rec.raw, 4, PRV_M, 0);                                                                \
+    } while (0)
+#if WSP_VW_GROUP
+    // ---- one instruction per live lane: every distinct word present, once, with the word in scalar registers
+    bool todo = alive;
+    unsigned long long pend = __ballot(alive);
+    while (pend) {
+      const int leader = __ffsll((long long)pend) - 1;
+      const u32 uraw = (u32)__builtin_amdgcn_readlane((int)raw, leader);
+      const bool mine = todo && raw == uraw;
+      if (mine) {
+        const u32 uw0 = (u32)__builtin_amdgcn_readlane((int)w0, leader); const i32 uimm = (i32)__builtin_amdgcn_readlane((int)imm, leader);
+        WSP_VW_ONE(uw0, uimm, uraw);
+        todo = false;
+      }
+      pend &= ~__ballot(mine);
+    }
+#else
+    if (alive) WSP_VW_ONE(w0, imm, raw);
+#endif
+#undef WSP_VW_ONE
+    // ---- go on while the next instruction is a vector instruction too
+    if (alive && done) {
+      ++n_done; pc += 4;
+      const u64 idx = pc - va.text_lo;
+      alive = n_done < max_n && idx < (u64)text_len;
+      if (alive) {
+        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(va.recs) + (idx << 3));
+        w0 = q.x; imm = (i32)q.y; raw = q.w;
+        const u32 op = w0 & 0xff;
+        alive = op >= OP_VEC && op <= OP_VST;
+      }
+    } else alive = false;
+    if (!__any(alive)) break;
+  }
+  WarmRet r; r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = n_done;
   return r;
 }
 
@@ -308,7 +384,9 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   const u32 lane = threadIdx.x, wave = blockIdx.x;
   const u32 hart = wave * d.lpw + lane;
   const bool active = lane < d.lpw && hart < d.n_harts;
-  const u32 ln = active ? lane : 0;
+  // a lane without a hart looks at hart 0's slot; in a V batch at the slot of the hart whose sub-group it belongs to (wsp_vwarm)
+  const u32 own = lane & (d.lpw - 1);
+  const u32 ln = active ? lane : (d.vreg && wave * d.lpw + own < d.n_harts) ? own : 0;
   const u32 slot = wave * 64 + ln;
   const u32 S = d.S;
 
@@ -343,9 +421,13 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   u64* const vlds = wsp_lds + d.lpw * (2 * WSP_XSLOTS);
   u64* const vhbm = (u64*)(d.vreg + (size_t)wave * d.lpw * 32 * d.vlenb);
   for (u32 i = lane; i < vwords; i += 64) vlds[i] = vhbm[i];
+  if (WSP_VCSR_LDS && d.vreg && active) for (u32 k = 0; k < 4; ++k) L.m.vcsr_[k] = d.cold[(size_t)(CI_VSTART + k) * S + slot];
   __syncthreads();
 
   const bool zca = (d.isa & ISA_C) != 0;                 // without C, taken control transfers can trap: general path
+  // RV32 batch (ISA_RV32): addresses wrap at 32 bits, register values are kept sign-extended, commit records carry 32-bit values
+  const bool rv32 = (d.isa & ISA_RV32) != 0;
+  const u64 am = rv32 ? 0xffffffffULL : ~0ULL;
   // Every hart of the wave runs the same program image: the converged loop below applies (one pc for the running group).
   const u32 pg0 = (u32)__builtin_amdgcn_readfirstlane((int)d.prog[wave * 64]);
   const bool same_prog = pg0 != ~0u && __all(!active || d.prog[slot] == pg0);
@@ -428,12 +510,12 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             u64 tr_k = 1ULL << 60, tr_v = 0;
             const bool rd_nz = (w0 & 0x1f00u) != 0;
             const u64 rd_key = rd_nz ? ((u64)((w0 >> 8) & 31) ^ (1ULL << 60)) : (1ULL << 60);
-#define WSP_CW(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? v_ : 0; } } while (0)
+#define WSP_CW(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? (v_ & am) : 0; } } while (0)
 #define WSP_BAD(cond) do { bad = (cond); } while (0)
             if (op == OP_ADD) WSP_CW(a + bi);
             else if (op >= OP_LB && op <= OP_LWU) {
               const u32 k = op - OP_LB, sz = 1u << (k & 3);
-              const u64 va = a + simm, off = va - mbase;
+              const u64 va = (a + simm) & am, off = va - mbase;
               const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);
               const u8* p = L.m.p(ok ? off : 0);
               u64 v;
@@ -442,7 +524,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
               else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;
               *(ok ? rdp : sinkx) = v;
               WSP_BAD(!ok);
-              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? v : 0; }
+              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? (v & am) : 0; }
             } else if (op >= OP_BEQ && op <= OP_BGEU) {
               const u32 m = op - OP_BEQ;
               const bool c = m < 2 ? a == b2 : m < 4 ? (i64)a < (i64)b2 : a < b2;
@@ -457,7 +539,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             else if (op == OP_SRL) WSP_CW(a >> (bi & 63));
             else if (op >= OP_SB && op <= OP_SD) {
               const u32 k = op - OP_SB, sz = 1u << k;
-              const u64 va = a + simm, off = va - mbase;
+              const u64 va = (a + simm) & am, off = va - mbase;
               const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost) & (va != tohost + 4) &
                               !((va + sz > tlo) & (va < thi));
               u8* p = ok ? L.m.p(off) : gsink;
@@ -470,7 +552,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             else if (FP && op >= OP_FLW && op <= OP_FSD) {
               const bool st = op >= OP_FSW, dw = (op & 1u) == (OP_FLD & 1u);
               const u32 sz = dw ? 8u : 4u;
-              const u64 va = a + simm, off = va - mbase;
+              const u64 va = (a + simm) & am, off = va - mbase;
               bool ok = fsd & ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);
               if (st) {
                 ok = ok & (va != tohost + 4) & !((va + sz > tlo) & (va < thi));
@@ -488,13 +570,13 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
               }
               WSP_BAD(!ok);
             } else if (op == OP_JAL || op == OP_JALR) {
-              const u64 t = op == OP_JAL ? (u64)(upc + (u32)imm) : (((a + simm) & ~1ULL) - tlo);
+              const u64 t = op == OP_JAL ? (u64)(upc + (u32)imm) : (((a + simm) & am & ~1ULL) - tlo);
               const bool ok = zca & (t < (u64)tlen);
-              const u64 link = tlo + upc + size;
+              const u64 link0 = tlo + upc + size, link = rv32 ? (u64)(i64)(i32)link0 : link0;
               *(ok ? rdp : sinkx) = link;
               npc = (u32)t & ~1u;
               WSP_BAD(!ok);
-              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? link : 0; }
+              if (TRACE) { tr_k = rd_key; tr_v = rd_nz ? link0 : 0; }
             } else switch (op) {
               case OP_SUB: WSP_CW(a - bi); break;
               case OP_SLT: WSP_CW((u64)((i64)a < (i64)bi)); break;
@@ -506,7 +588,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
               case OP_SLLW: WSP_CW((u64)(i64)(i32)((u32)a << (bi & 31))); break;
               case OP_SRLW: WSP_CW((u64)(i64)(i32)((u32)a >> (bi & 31))); break;
               case OP_SRAW: WSP_CW((u64)(i64)((i32)a >> (bi & 31))); break;
-              case OP_AUIPC: WSP_CW(tlo + upc + simm); break;
+              case OP_AUIPC: { const u64 v0 = tlo + upc + simm; WSP_CW(rv32 ? (u64)(i64)(i32)v0 : v0); break; }
               case OP_NOP: break;
               default: bad = true; break;                 // not in the inline subset
             }
@@ -569,12 +651,12 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 
           // One op for the lanes in EXEC.  Every case is straight-line (selects, no divergent branch and no short-circuit
           // evaluation); the most frequent ops sit at the top of the compare chain.
-#define WSP_WX(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? v_ : 0; } } while (0)
+#define WSP_WX(val) do { const u64 v_ = (val); *rdp = v_; if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? (v_ & am) : 0; } } while (0)
 #define WSP_HOT_OP(uop, aa, bb, cc)                                                                                        \
           if (uop == OP_ADD) WSP_WX(aa + cc);                                                                              \
           else if (uop >= OP_LB && uop <= OP_LWU) {                                                                        \
             const u32 k = uop - OP_LB, sz = 1u << (k & 3);                                                                 \
-            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            const u64 va = (aa + simm) & am, off = va - mbase;                                                                    \
             const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);                                 \
             const u8* p = L.m.p(ok ? off : 0);            /* rejected lanes read their own dword 0 and discard it */     \
             u64 v;                                                                                                         \
@@ -583,7 +665,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             else if (k == 1) v = (u64)(i64)*(const int16_t*)p; else v = *(const u16*)p;                                    \
             *(ok ? rdp : sinkx) = v;                                                                                       \
             ncv |= ok ? 0u : 1u;                                                                                           \
-            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? v : 0; }                                                   \
+            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? (v & am) : 0; }                                            \
           } else if (uop >= OP_BEQ && uop <= OP_BGEU) {                                                                    \
             const u32 m = uop - OP_BEQ;                                                                                    \
             const bool c = m < 2 ? aa == bb : m < 4 ? (i64)aa < (i64)bb : aa < bb;                                         \
@@ -598,7 +680,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
           else if (uop == OP_SRL) WSP_WX(aa >> (cc & 63));                                                                 \
           else if (uop >= OP_SB && uop <= OP_SD) {                                                                         \
             const u32 k = uop - OP_SB, sz = 1u << k;                                                                       \
-            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            const u64 va = (aa + simm) & am, off = va - mbase;                                                                    \
             const bool ok = ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost) & (va != tohost + 4) &           \
                             !((va + sz > tlo) & (va < thi));                                                               \
             u8* p = ok ? L.m.p(off) : gsink;              /* rejected lanes store into their private sink */              \
@@ -612,7 +694,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             /* flw fld fsw fsd with FS already Dirty (float.cpp:281-321, 1019-1057): f registers in LDS, no CSR change */  \
             const bool st = uop >= OP_FSW, dw = (uop & 1u) == (OP_FLD & 1u);                                               \
             const u32 sz = dw ? 8u : 4u;                                                                                   \
-            const u64 va = aa + simm, off = va - mbase;                                                                    \
+            const u64 va = (aa + simm) & am, off = va - mbase;                                                                    \
             bool ok = fsd & ((va & (sz - 1)) == 0) & (off <= msize - sz) & (va != tohost);                                 \
             if (st) {                                                                                                      \
               ok = ok & (va != tohost + 4) & !((va + sz > tlo) & (va < thi));                                              \
@@ -630,13 +712,13 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             }                                                                                                              \
             ncv |= ok ? 0u : 1u;                                                                                           \
           } else if (uop == OP_JAL || uop == OP_JALR) {                                                                      \
-            const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((aa + simm) & ~1ULL) - tlo);                           \
+            const u64 t = uop == OP_JAL ? (u64)(pco + (u32)imm) : (((aa + simm) & am & ~1ULL) - tlo);                      \
             const bool ok = zca & (t < (u64)text_len);                                                                     \
-            const u64 link = tlo + pco + size;                                                                             \
+            const u64 link0 = tlo + pco + size, link = rv32 ? (u64)(i64)(i32)link0 : link0;                                \
             *(ok ? rdp : sinkx) = link;                                                                                    \
             npc = ok ? ((u32)t & ~1u) : npc;                                                                               \
             ncv |= ok ? 0u : 1u;                                                                                           \
-            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? link : 0; }                                                \
+            if (TRACE) { tr_k = rd_key; tr_v = (w0 & 0x1f00u) ? link0 : 0; }                                               \
           } else switch (uop) {                                                                                            \
             case OP_SUB: WSP_WX(aa - cc); break;                                                                           \
             case OP_SLT: WSP_WX((u64)((i64)aa < (i64)cc)); break;                                                          \
@@ -648,7 +730,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
             case OP_SLLW: WSP_WX((u64)(i64)(i32)((u32)aa << (cc & 31))); break;                                            \
             case OP_SRLW: WSP_WX((u64)(i64)(i32)((u32)aa >> (cc & 31))); break;                                            \
             case OP_SRAW: WSP_WX((u64)(i64)((i32)aa >> (cc & 31))); break;                                                 \
-            case OP_AUIPC: WSP_WX(tlo + pco + simm); break;                                                                \
+            case OP_AUIPC: { const u64 v0 = tlo + pco + simm; WSP_WX(rv32 ? (u64)(i64)(i32)v0 : v0); break; }            \
             case OP_NOP: break;                                                                                            \
             default: ncv = 1u; break;                     /* not in the inline subset */                                  \
           }
@@ -722,18 +804,22 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         const int owner = (int)(lane & (d.lpw - 1));
         const bool helper = lane >= d.lpw && ((cm >> owner) & 1);
         u64 vpc = L.h.pc, vth = L.h.thash; u32 vfcsr = L.h.fcsr, vfl = L.h.flags, vw0 = rec.w0, vraw = rec.raw; i32 vimm = rec.imm;
+        const u64 left = stop_at - L.h.exec;
+        u32 vmax = left > 64 ? 64u : (u32)left;
 #define WSP_FROM_OWNER64(x) do { const u32 lo_ = (u32)__shfl((int)(u32)x, owner, 64), hi_ = (u32)__shfl((int)(u32)(x >> 32), owner, 64); if (helper) x = (u64)lo_ | ((u64)hi_ << 32); } while (0)
 #define WSP_FROM_OWNER32(x) do { const u32 v_ = (u32)__shfl((int)x, owner, 64); if (helper) x = v_; } while (0)
-        WSP_FROM_OWNER64(vpc); WSP_FROM_OWNER64(vth); WSP_FROM_OWNER32(vfcsr); WSP_FROM_OWNER32(vfl); WSP_FROM_OWNER32(vw0); WSP_FROM_OWNER32(vraw);
+        WSP_FROM_OWNER64(vpc); WSP_FROM_OWNER64(vth); WSP_FROM_OWNER32(vfcsr); WSP_FROM_OWNER32(vfl); WSP_FROM_OWNER32(vw0); WSP_FROM_OWNER32(vraw); WSP_FROM_OWNER32(vmax);
         { u32 t_ = (u32)vimm; WSP_FROM_OWNER32(t_); vimm = (i32)t_; }
 #undef WSP_FROM_OWNER64
 #undef WSP_FROM_OWNER32
         if (cand || helper) {
-          // one call site for the hart's lane and its helpers: they execute the call together
+          // one call site for the hart's lane and its helpers: they execute the call together.  (A helper lane was set up with
+          // its hart's slot: program image, text bounds and tohost are the owner's.)
+          VWarmArgs va; va.recs = recs; va.text_lo = L.text_lo; va.text_hi = L.text_hi; va.tohost = L.tohost;
           const unsigned long long pv0 = WSP_PROF_T();
-          const WarmRet w = (TRACE && tr) ? wsp_vwarm<true>(dp, vw0, vimm, vraw, vpc, vth, vfcsr, vfl) : wsp_vwarm<false>(dp, vw0, vimm, vraw, vpc, vth, vfcsr, vfl);
+          const WarmRet w = wsp_vwarm(dp, va, vw0, vimm, vraw, vpc, vth, vfcsr, vfl, vmax);
           WSP_PROF_ADD(10, WSP_PROF_T() - pv0); WSP_PROF_ADD(9, 1); WSP_PROF_ADD(11, __popcll(__ballot(cand && w.handled)));
-          if (cand && w.handled) { L.h.pc += 4; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; need_cold = false; }
+          if (cand && w.handled) { L.h.pc += 4 * w.handled; L.h.exec += w.handled; L.h.thash = w.thash; L.h.fcsr = w.fcsr; need_cold = false; }
         }
       }
     }
@@ -752,6 +838,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 
   __syncthreads();
   for (u32 i = lane; i < vwords; i += 64) vhbm[i] = vlds[i];
+  if (WSP_VCSR_LDS && d.vreg && active) for (u32 k = 0; k < 4; ++k) d.cold[(size_t)(CI_VSTART + k) * S + slot] = L.m.vcsr_[k];
   if (active) {
     for (u32 r = 1; r < 32; ++r) d.x[(size_t)r * S + slot] = L.m.rx(r);
     if (FP) for (u32 r = 0; r < 32; ++r) d.f[(size_t)r * S + slot] = L.m.rf(r);
@@ -822,7 +909,7 @@ __global__ void wsp_poke_each_kernel(DevState d, u32 lo, u32 hi, u32 res, u64 id
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (lo + i >= hi) return;
   u32 hart = lo + i;
-  if (res == WSP_RES_X) d.x[(size_t)idx * d.S + slot_of(d, hart)] = vals[i];
+  if (res == WSP_RES_X) d.x[(size_t)idx * d.S + slot_of(d, hart)] = (d.isa & ISA_RV32) ? (u64)(i64)(i32)vals[i] : vals[i];
   else *(u64*)(d.arena + arena_off(d, hart, idx)) = vals[i];
 }
 
@@ -947,8 +1034,9 @@ static int parse_isa(const char* isa, u32* out, std::string* why)
   std::string s = isa ? isa : "";
   for (auto& c : s) c = (char)tolower(c);
   if (s.rfind("rv64", 0) == 0) s = s.substr(4);
-  else if (s.rfind("rv32", 0) == 0) { if (why) *why = "rv32 is not supported yet"; return WSP_EUNSUPPORTED; }
-  u32 f = 0; size_t us = s.find('_');
+  u32 f = 0;
+  if (s.rfind("rv32", 0) == 0) { s = s.substr(4); f |= ISA_RV32; }      // (wsp_batch_create decides the width: descriptor, config, then this prefix)
+  size_t us = s.find('_');
   std::string base = s.substr(0, us);
   for (char c : base) {
     switch (c) {
@@ -1101,7 +1189,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   if (!isa_str) return fail(WSP_EINVAL, "no ISA string (descriptor isa or config tag \"isa\")");
   u32 xlen = desc->xlen ? desc->xlen : cfg.xlen;
   if (!xlen) { std::string t = isa_str; xlen = (t.rfind("rv32", 0) == 0 || t.rfind("RV32", 0) == 0) ? 32 : 64; }   // HartConfig::getXlen (HartConfig.cpp:3431-3459)
-  if (xlen != 64) return fail(WSP_EUNSUPPORTED, "only xlen=64 is supported");
+  if (xlen != 64 && xlen != 32) return fail(WSP_EUNSUPPORTED, "xlen must be 32 or 64");
   const u64 mem_size = desc->mem_size ? desc->mem_size : cfg.mem_size;
   if (desc->n_harts == 0) return fail(WSP_EINVAL, "n_harts must be > 0");
   if (mem_size == 0 || (mem_size & 4095)) return fail(WSP_EINVAL, "mem_size must be a non-zero multiple of 4096");
@@ -1110,6 +1198,11 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   int rc = parse_isa(isa_str, &isa, &why);
   if (rc != WSP_OK) return fail(rc, why);
   isa |= cfg.features;
+  isa = xlen == 32 ? (isa | ISA_RV32) : (isa & ~(u32)ISA_RV32);
+  if (xlen == 32) {     // System<uint32_t>: modelled for M / U mode integer, A, F, D, C code
+    if (isa & (ISA_S | ISA_V)) return fail(WSP_EUNSUPPORTED, "xlen=32 is modelled without S mode (Sv32) and without V");
+    if (desc->mem_base + mem_size > (1ULL << 32)) return fail(WSP_EINVAL, "an RV32 arena must lie below 4 GiB");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device: whisper_amd has no CPU execution path");
   int dev = desc->device;
@@ -1132,7 +1225,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     // the vector register files of a wave's harts are staged in LDS (wsp_vreg_lds): the wave's block must fit the 64 KiB a
     // workgroup gets without asking for more; a larger request is lowered (16 at VLEN 512, 32 at VLEN 256 / 128)
     const u32 vb = desc->vlen_bytes ? desc->vlen_bytes : cfg.vlen_bytes ? cfg.vlen_bytes : 64u;
-    while (lpw > 1 && (size_t)lpw * (2 * WSP_XSLOTS * 8 + 32 * vb) > 65536) lpw >>= 1;
+    while (lpw > 1 && (size_t)lpw * (2 * WSP_XSLOTS * 8 + 32 * vb + 32) > 65536) lpw >>= 1;
   }
   wsp_batch* b = new wsp_batch();
   b->device = dev;
@@ -1162,7 +1255,8 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
   std::vector<u64> v64(S);
   std::fill(v64.begin(), v64.end(), cfg.has_reset_pc ? (cfg.reset_pc & ~1ULL) : d.mem_base);   // defineResetPc (config tag reset_vec), else the arena base
   hipMemcpy(d.hot64 + (size_t)H64_PC * S, v64.data(), S * 8, hipMemcpyHostToDevice);
-  std::fill(v64.begin(), v64.end(), MSTATUS_RESET);   hipMemcpy(d.hot64 + (size_t)H64_MSTATUS * S, v64.data(), S * 8, hipMemcpyHostToDevice);
+  std::fill(v64.begin(), v64.end(), xlen == 32 ? (3ULL << MST_MPP_SH) : MSTATUS_RESET);   // RV32: no SXL / UXL fields (mstatus = 0x1800)
+  hipMemcpy(d.hot64 + (size_t)H64_MSTATUS * S, v64.data(), S * 8, hipMemcpyHostToDevice);
   std::fill(v64.begin(), v64.end(), 1ULL << 63);      hipMemcpy(d.cold + (size_t)CI_VTYPE * S, v64.data(), S * 8, hipMemcpyHostToDevice);   // vtype resets to vill (CsRegs.cpp:5363)
   std::fill(v64.begin(), v64.end(), ~0ULL);           hipMemcpy(d.tohost, v64.data(), S * 8, hipMemcpyHostToDevice);
   hipMemcpy(d.max_exec, v64.data(), S * 8, hipMemcpyHostToDevice);
@@ -1337,6 +1431,11 @@ struct Elf64_Ehdr_ { u8 ident[16]; u16 type, machine; u32 version; u64 entry, ph
 struct Elf64_Phdr_ { u32 type, flags; u64 offset, vaddr, paddr, filesz, memsz, align; };
 struct Elf64_Shdr_ { u32 name, type; u64 flags, addr, offset, size; u32 link, info; u64 addralign, entsize; };
 struct Elf64_Sym_ { u32 name; u8 info, other; u16 shndx; u64 value, size; };
+// ELF32 (an RV32 program, README.md:167-185): the same records with 32-bit fields, widened on the way in
+struct Elf32_Ehdr_ { u8 ident[16]; u16 type, machine; u32 version; u32 entry, phoff, shoff; u32 flags; u16 ehsize, phentsize, phnum, shentsize, shnum, shstrndx; };
+struct Elf32_Phdr_ { u32 type, offset, vaddr, paddr, filesz, memsz, flags, align; };
+struct Elf32_Shdr_ { u32 name, type, flags, addr, offset, size, link, info, addralign, entsize; };
+struct Elf32_Sym_ { u32 name, value, size; u8 info, other; u16 shndx; };
 
 // What one ELF file asks of a hart (Memory::loadElfFile, Memory.cpp:450-489, 687; System::loadElfFiles, System.cpp:288-354).
 struct ElfSeg { u64 paddr, file_off, size; };
@@ -1350,19 +1449,35 @@ struct ParsedElf {
 static int parse_elf(const DevState& d, const void* elf, size_t n, ParsedElf& out)
 {
   const u8* e = (const u8*)elf;
-  if (!e || n < sizeof(Elf64_Ehdr_) || memcmp(e, "\177ELF", 4) != 0) return fail(WSP_EFORMAT, "not an ELF file");
-  if (e[4] != 2) return fail(WSP_EFORMAT, "ELF class is not 64-bit");        // Session.cpp:1373-1424 xlen from ELF class
+  if (!e || n < sizeof(Elf32_Ehdr_) || memcmp(e, "\177ELF", 4) != 0 || (e[4] == 2 && n < sizeof(Elf64_Ehdr_))) return fail(WSP_EFORMAT, "not an ELF file");
+  const bool c32 = e[4] == 1;
+  if (e[4] != 1 && e[4] != 2) return fail(WSP_EFORMAT, "ELF class is neither 32- nor 64-bit");
+  if (c32 != ((d.isa & ISA_RV32) != 0)) return fail(WSP_EFORMAT, c32 ? "ELF32 file for an xlen=64 batch" : "ELF64 file for an xlen=32 batch");   // Session.cpp:1373-1424: the ELF class decides the width
   if (e[5] != 1) return fail(WSP_EFORMAT, "ELF is not little-endian");
-  Elf64_Ehdr_ eh; memcpy(&eh, e, sizeof eh);
+  Elf64_Ehdr_ eh;
+  if (c32) {
+    Elf32_Ehdr_ h32; memcpy(&h32, e, sizeof h32);
+    memcpy(eh.ident, h32.ident, 16); eh.type = h32.type; eh.machine = h32.machine; eh.version = h32.version; eh.entry = h32.entry; eh.phoff = h32.phoff; eh.shoff = h32.shoff;
+    eh.flags = h32.flags; eh.ehsize = h32.ehsize; eh.phentsize = h32.phentsize; eh.phnum = h32.phnum; eh.shentsize = h32.shentsize; eh.shnum = h32.shnum; eh.shstrndx = h32.shstrndx;
+  } else memcpy(&eh, e, sizeof eh);
+  const size_t ph_sz = c32 ? sizeof(Elf32_Phdr_) : sizeof(Elf64_Phdr_), sh_sz = c32 ? sizeof(Elf32_Shdr_) : sizeof(Elf64_Shdr_), sym_sz = c32 ? sizeof(Elf32_Sym_) : sizeof(Elf64_Sym_);
+  auto read_ph = [&](u32 i) { Elf64_Phdr_ ph; const u8* q = e + eh.phoff + (u64)i * eh.phentsize;
+    if (c32) { Elf32_Phdr_ p; memcpy(&p, q, sizeof p); ph.type = p.type; ph.flags = p.flags; ph.offset = p.offset; ph.vaddr = p.vaddr; ph.paddr = p.paddr; ph.filesz = p.filesz; ph.memsz = p.memsz; ph.align = p.align; }
+    else memcpy(&ph, q, sizeof ph);
+    return ph; };
+  auto read_sh = [&](u32 i) { Elf64_Shdr_ sh; const u8* q = e + eh.shoff + (u64)i * eh.shentsize;
+    if (c32) { Elf32_Shdr_ p; memcpy(&p, q, sizeof p); sh.name = p.name; sh.type = p.type; sh.flags = p.flags; sh.addr = p.addr; sh.offset = p.offset; sh.size = p.size; sh.link = p.link; sh.info = p.info; sh.addralign = p.addralign; sh.entsize = p.entsize; }
+    else memcpy(&sh, q, sizeof sh);
+    return sh; };
   // every range check in the form "off > n || len > n - off": no sum can wrap
   auto in_file = [n](u64 off, u64 len) { return off <= n && len <= n - off; };
-  if (eh.phnum && eh.phentsize != sizeof(Elf64_Phdr_)) return fail(WSP_EFORMAT, "unexpected program header entry size");
-  if (eh.shnum && eh.shentsize != sizeof(Elf64_Shdr_)) return fail(WSP_EFORMAT, "unexpected section header entry size");
-  if (!in_file(eh.phoff, (u64)eh.phnum * sizeof(Elf64_Phdr_))) return fail(WSP_EFORMAT, "program headers out of file");
+  if (eh.phnum && eh.phentsize != ph_sz) return fail(WSP_EFORMAT, "unexpected program header entry size");
+  if (eh.shnum && eh.shentsize != sh_sz) return fail(WSP_EFORMAT, "unexpected section header entry size");
+  if (!in_file(eh.phoff, (u64)eh.phnum * ph_sz)) return fail(WSP_EFORMAT, "program headers out of file");
   u64 xlo = ~0ULL, xhi = 0;
   std::vector<Elf64_Phdr_> xs;
   for (u32 i = 0; i < eh.phnum; ++i) {
-    Elf64_Phdr_ ph; memcpy(&ph, e + eh.phoff + (u64)i * eh.phentsize, sizeof ph);
+    const Elf64_Phdr_ ph = read_ph(i);
     if (ph.type != 1 || ph.filesz == 0) continue;                            // PT_LOAD, p_filesz bytes only (Memory.cpp:450-489)
     if (!in_file(ph.offset, ph.filesz)) return fail(WSP_EFORMAT, "segment out of file");
     if (ph.paddr < d.mem_base || ph.paddr - d.mem_base > d.mem_size - ph.filesz || ph.filesz > d.mem_size)
@@ -1371,9 +1486,9 @@ static int parse_elf(const DevState& d, const void* elf, size_t n, ParsedElf& ou
     if (ph.flags & 1) { xlo = std::min(xlo, ph.paddr); xhi = std::max(xhi, ph.paddr + ph.filesz); xs.push_back(ph); }
   }
   // symbols + .tdata
-  if (eh.shoff && in_file(eh.shoff, (u64)eh.shnum * sizeof(Elf64_Shdr_))) {
+  if (eh.shoff && in_file(eh.shoff, (u64)eh.shnum * sh_sz)) {
     std::vector<Elf64_Shdr_> sh(eh.shnum);
-    for (u32 i = 0; i < eh.shnum; ++i) memcpy(&sh[i], e + eh.shoff + (u64)i * eh.shentsize, sizeof(Elf64_Shdr_));
+    for (u32 i = 0; i < eh.shnum; ++i) sh[i] = read_sh(i);
     // a name is taken only when its terminating NUL lies inside its string table (and the table inside the file)
     auto name_at = [&](const Elf64_Shdr_& tab, u64 off) -> const char* {
       if (!in_file(tab.offset, tab.size) || off >= tab.size) return nullptr;
@@ -1386,9 +1501,11 @@ static int parse_elf(const DevState& d, const void* elf, size_t n, ParsedElf& ou
       if (sn && strcmp(sn, ".tdata") == 0) out.tdata = sh[i].addr;
       if (sh[i].type != 2 || sh[i].link >= eh.shnum || !in_file(sh[i].offset, sh[i].size)) continue;   // SHT_SYMTAB
       const Elf64_Shdr_& st = sh[sh[i].link];
-      size_t cnt = sh[i].size / sizeof(Elf64_Sym_);
+      size_t cnt = sh[i].size / sym_sz;
       for (size_t k = 0; k < cnt; ++k) {
-        Elf64_Sym_ sy; memcpy(&sy, e + sh[i].offset + k * sizeof(Elf64_Sym_), sizeof sy);
+        Elf64_Sym_ sy;
+        if (c32) { Elf32_Sym_ p; memcpy(&p, e + sh[i].offset + k * sym_sz, sizeof p); sy.name = p.name; sy.info = p.info; sy.other = p.other; sy.shndx = p.shndx; sy.value = p.value; sy.size = p.size; }
+        else memcpy(&sy, e + sh[i].offset + k * sym_sz, sizeof sy);
         const char* nm = name_at(st, sy.name);
         if (nm && *nm) out.syms[nm] = sy.value;
       }
@@ -1673,6 +1790,11 @@ extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
       return WSP_OK; }
     default: return fail(WSP_EINVAL, "unknown resource");
   }
+  if (d.isa & ISA_RV32) {   // the 32-bit view of a value kept in its RV64 shape (x registers sign-extended, CSR file as CsRegs<uint32_t> shows it)
+    if (res == WSP_RES_CSR && (idx == C_MSTATUS || idx == C_SSTATUS || idx == C_MCAUSE || idx == C_SCAUSE)) v = (v & 0x7fffffffULL) | ((v >> 63) << 31);
+    else if (res == WSP_RES_CSR && idx == C_MISA) v = 0x4034112dULL;
+    else if (res != WSP_RES_F) v &= 0xffffffffULL;
+  }
   memcpy(val, &v, std::min<size_t>(size, 8));
   return WSP_OK;
 }
@@ -1684,13 +1806,19 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
   HIPOK(hipSetDevice(b->device));
   DevState& d = b->d; u32 s = slot_of(d, hart); size_t S = d.S;
   u64 v = 0; memcpy(&v, val, std::min<size_t>(size, 8));
+  const bool rv32 = (d.isa & ISA_RV32) != 0;
+  if (rv32 && res != WSP_RES_F && res != WSP_RES_MEM && res != WSP_RES_V) {
+    v &= 0xffffffffULL;
+    if (res == WSP_RES_X) v = (u64)(i64)(i32)v;                                                        // registers are held sign-extended
+    if (res == WSP_RES_CSR && (idx == C_MCAUSE || idx == C_SCAUSE)) v = (v & 0x7fffffffULL) | ((v >> 31) << 63);
+  }
   switch (res) {
     case WSP_RES_PC: v &= ~1ULL; HIPOK(hipMemcpy(d.hot64 + H64_PC * S + s, &v, 8, hipMemcpyHostToDevice)); break;
     case WSP_RES_X: if (idx > 31) return fail(WSP_ERANGE, "x register"); if (idx) HIPOK(hipMemcpy(d.x + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
     case WSP_RES_F: if (idx > 31) return fail(WSP_ERANGE, "f register"); HIPOK(hipMemcpy(d.f + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
     case WSP_RES_CSR: {
       u32 ix; u32 n = (u32)idx; int loc = csr_loc(n, &ix);
-      if (n == C_MSTATUS) v = (MSTATUS_RESET & ~MSTATUS_WMASK) | (v & (MSTATUS_WMASK | MST_SD));
+      if (n == C_MSTATUS) v = ((rv32 ? (3ULL << MST_MPP_SH) : MSTATUS_RESET) & ~MSTATUS_WMASK) | (v & MSTATUS_WMASK) | ((v & (rv32 ? (1ULL << 31) : MST_SD)) ? MST_SD : 0);
       if (loc == 0) HIPOK(hipMemcpy(d.hot64 + ix * S + s, &v, 8, hipMemcpyHostToDevice));
       else if (loc == 1) { u32 f = (u32)v & 0xff; HIPOK(hipMemcpy(d.hot32 + ix * S + s, &f, 4, hipMemcpyHostToDevice)); }
       else if (loc == 2) {
@@ -1750,7 +1878,7 @@ template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 s
 {
   DevState& d = b->d;
   size_t lds = (size_t)d.lpw * WSP_XSLOTS * 8 * (FP ? 2 : 1);
-  if (d.vreg) lds = (size_t)d.lpw * (2 * WSP_XSLOTS * 8 + 32 * d.vlenb);     // x block, f block, vector register files
+  if (d.vreg) lds = (size_t)d.lpw * (2 * WSP_XSLOTS * 8 + 32 * d.vlenb + 32);     // x block, f block, vector register files, vector CSRs
   hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps, notrace);

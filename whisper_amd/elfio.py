@@ -72,6 +72,43 @@ def write_elf(segments, entry, symbols=None, sections=None) -> bytes:
     return bytes(eh + ph + blob + b"".join(sec_hdrs))
 
 
+def write_elf32(segments, entry, symbols=None) -> bytes:
+    """ELF32 little-endian (an RV32 program, as riscv32 gcc writes for README.md:167-185): segments + one symbol table."""
+    symbols = symbols or {}
+    ehsize, phentsize, shentsize = 52, 32, 40
+    phnum = len(segments)
+    off = ehsize + phnum * phentsize
+    blob = bytearray()
+    seg_offsets = []
+    for paddr, data, flags in segments:
+        blob += bytes((-off - len(blob)) % 16)
+        seg_offsets.append(off + len(blob))
+        blob += data
+    shstr = bytearray(b"\0.symtab\0.strtab\0.shstrtab\0")
+    strtab = bytearray(b"\0")
+    symtab = bytearray(16)
+    for name, addr in symbols.items():
+        o = len(strtab)
+        strtab += name.encode() + b"\0"
+        symtab += struct.pack("<IIIBBH", o, addr & 0xFFFFFFFF, 0, 0x10, 0, 0xFFF1)
+    blob += bytes((-(off + len(blob))) % 8)
+    symtab_off = off + len(blob); blob += symtab
+    strtab_off = off + len(blob); blob += strtab
+    shstr_off = off + len(blob); blob += shstr
+    blob += bytes((-(off + len(blob))) % 8)
+    shoff = off + len(blob)
+    sec = [bytes(shentsize),
+           struct.pack("<IIIIIIIIII", 1, 2, 0, 0, symtab_off, len(symtab), 2, 1, 4, 16),
+           struct.pack("<IIIIIIIIII", 9, 3, 0, 0, strtab_off, len(strtab), 0, 0, 1, 0),
+           struct.pack("<IIIIIIIIII", 17, 3, 0, 0, shstr_off, len(shstr), 0, 0, 1, 0)]
+    eh = b"\x7fELF" + bytes([1, 1, 1, 0]) + bytes(8)
+    eh += struct.pack("<HHIIIIIHHHHHH", 2, EM_RISCV, 1, entry & 0xFFFFFFFF, ehsize, shoff, 0x1, ehsize, phentsize, phnum, shentsize, len(sec), len(sec) - 1)
+    ph = b""
+    for (paddr, data, flags), so in zip(segments, seg_offsets):
+        ph += struct.pack("<IIIIIIII", 1, so, paddr, paddr, len(data), len(data), flags, 16)
+    return bytes(eh + ph + blob + b"".join(sec))
+
+
 def read_elf(elf: bytes):
     """Returns (entry, [(paddr, bytes, flags)], {symbol: addr}). Test helper mirroring the C++ loader."""
     assert elf[:4] == b"\x7fELF" and elf[4] == 2 and elf[5] == 1

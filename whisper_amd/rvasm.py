@@ -30,8 +30,9 @@ def _chk_simm(v: int, bits: int, what: str) -> int:
 
 
 class Asm:
-    def __init__(self, base: int = 0x80000000):
+    def __init__(self, base: int = 0x80000000, xlen: int = 64):
         self.base = base
+        self.xlen = xlen        # 32: li builds 32-bit constants with lui / addi (no addiw, no 64-bit shifts)
         self.items: list = []   # (kind, size, payload)
         self.pc = base
         self.symbols: dict[str, int] = {}
@@ -158,6 +159,8 @@ class Asm:
         """Load a 64-bit constant (sign-agnostic) with lui/addi(w)/slli sequences."""
         value &= MASK64
         sv = _sx(value, 64)
+        if self.xlen == 32:
+            sv = _sx(value & 0xFFFFFFFF, 32)
         if -2048 <= sv < 2048:
             self.addi(rd, 0, sv)
             return
@@ -166,7 +169,7 @@ class Asm:
             hi = ((sv - lo) >> 12) & 0xFFFFF
             self.lui(rd, hi)
             if lo:
-                self.addiw(rd, rd, lo)
+                (self.addi if self.xlen == 32 else self.addiw)(rd, rd, lo)
             return
         # general: build upper part recursively then shift in 12-bit chunks
         lo = _sx(sv & 0xFFF, 12)

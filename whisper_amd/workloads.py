@@ -13,7 +13,7 @@ from __future__ import annotations
 import random
 from dataclasses import dataclass, field
 
-from .elfio import PF_R, PF_W, PF_X, write_elf
+from .elfio import write_elf32, PF_R, PF_W, PF_X, write_elf
 from .rvasm import CSR, Asm
 
 MASK64 = (1 << 64) - 1
@@ -48,7 +48,7 @@ def _finish(a: Asm, name, isa, data: Asm | None = None, mem_size=1 << 16, max_in
     if extra_syms:
         syms.update(extra_syms)
     entry = syms.get("_start", a.base)
-    elf = write_elf(segs, entry, syms)
+    elf = (write_elf32 if isa.lower().startswith("rv32") else write_elf)(segs, entry, syms)
     return Program(name, isa, elf, entry, segs, syms, BASE, mem_size, max_inst, meta or {})
 
 
@@ -1451,3 +1451,185 @@ def rvv_kernel(n: int = 1024, iters: int = 2, vlenb: int = 64) -> Program:
     while data_base + 0x100 + 32 * n > BASE + size:
         size <<= 1
     return _finish(a, f"rvvk-{n}-{vlenb}", "rv64imafdcv_zicsr", d, mem_size=size, max_inst=1 << 26, meta=dict(n=n, iters=iters, vlenb=vlenb))
+
+
+# ------------------------------------------------------------------------------------------ RV32 (BASELINE config 0)
+def readme_rv32_program() -> Program:
+    """BASELINE config 0: the README.md:167-185 test program (x = 1; y = 2; z = x + y; tohost = 1) as riscv32 gcc -nostdlib
+    would emit it for rv32imc: an ELF32 file of c.* forms, a call into main (c.jal, the RV32-only code point) and a store of 1
+    to tohost."""
+    data_base = BASE + 0x1000
+    a = Asm(BASE, xlen=32)
+    a.label("_start")
+    a.li(2, BASE + 0x3000)                  # sp
+    a.half(0x2000 | (((8 >> 1) & 7) << 3) | (((8 >> 4) & 1) << 11) | (((8 >> 5) & 1) << 2) | 1)   # c.jal +8 (main): quadrant 1, funct3 001 on RV32
+    a.pc  # noqa: B018
+    a.label("after_call")
+    a.j("exit")
+    a.align(4)
+    a.label("main")
+    a.c_li(10, 1)
+    a.c_li(11, 2)
+    a.c_add(10, 11)
+    a.c_jr(1)
+    a.align(4)
+    a.label("exit")
+    a.li(5, data_base)
+    a.c_li(6, 1)
+    a.sw(6, 0, 5)
+    a.jal(0, a.pc)
+    d = Asm(data_base, xlen=32)
+    d.label("tohost")
+    d.dword(0)
+    d.label("fromhost")
+    d.dword(0)
+    return _finish(a, "readme-rv32", "rv32imc_zicsr", d, mem_size=1 << 14, max_inst=1000)
+
+
+def rv32_program(seed: int, n: int = 300, fp: bool = False) -> Program:
+    """Random RV32 code (M mode, bare): the integer ops whose results differ between the two widths (add / sub / shifts / mul*
+    / div* / slt* on values with bit 31 set), loads / stores with wrapping addresses, branches, jal / jalr / auipc links,
+    A (lr / sc / amo*.w), the compressed forms including the RV32-only code points (c.jal, c.flw / c.fsw and friends when F is
+    on), CSR traffic over the 32-bit views (mstatus / mstatush, mcycle / mcycleh, minstret / minstreth, menvcfg / menvcfgh,
+    odd pmpcfg registers, mcause after traps), RV64-only encodings that must trap (addiw, ld, sd, slli by 32, amoadd.d,
+    fcvt.l.s).  A handler skips the trapping instruction."""
+    rng = random.Random(0x32 * 1000003 + seed)
+    data_base = BASE + 0x2000
+    isa = "rv32imafdc_zicsr_zicntr" if fp else "rv32imac_zicsr_zicntr"
+    a = Asm(BASE, xlen=32)
+    d = Asm(data_base, xlen=32)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("data")
+    d.data(bytes(rng.getrandbits(8) for _ in range(1024)))
+    S = d.symbols
+    H1, H2 = 30, 31
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    a.csrr(H1, CSR["mepc"]); a.lhu(H2, 0, H1); a.andi(H2, H2, 3); a.addi(H2, H2, -3)
+    a.bnez(H2, "h2"); a.addi(H1, H1, 2)
+    a.label("h2"); a.addi(H1, H1, 2); a.csrw(CSR["mepc"], H1); a.mret()
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    if fp:
+        a.li(5, 0x2000); a.csrs(CSR["mstatus"], 5)
+        a.li(5, S["data"])
+        for i in range(8):
+            a.fld(i, 8 * i, 5)
+    vals = [0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x80000001, 0x55555555, 0xAAAAAAAA, 31, 32, 0xFFFF8000]
+    for r in range(1, 30):
+        a.li(r, rng.choice(vals + [rng.getrandbits(32), rng.getrandbits(12), S["data"] + 4 * rng.randrange(200)]))
+    ptrs = [8, 9, 18, 19]
+    for r in ptrs:
+        a.li(r, S["data"] + 128 + 4 * rng.randrange(64))
+    regs = list(range(0, 30))
+    rr = ["add", "sub", "sll", "slt", "sltu", "xor", "srl", "sra", "or_", "and_", "mul", "mulh", "mulhsu", "mulhu", "div", "divu", "rem", "remu"]
+    ri = ["addi", "slti", "sltiu", "xori", "ori", "andi"]
+    csrs_rw = [0x340, 0x300, 0x304, 0x305, 0x341, 0x342, 0x343, 0x30A, 0x31A, 0x310, 0xB00, 0xB80, 0xB02, 0xB82, 0x3A0, 0x3A1, 0x3B0, 0x3B1, 0x306, 0x320]
+    csrs_ro = [0x301, 0xF14, 0xC00, 0xC80, 0xC01, 0xC81, 0xC02, 0xC82, 0xF11, 0x344]
+    labels = 0
+    for i in range(n):
+        k = rng.random()
+        rd, r1, r2 = rng.choice(regs), rng.choice(regs), rng.choice(regs)
+        if rd in ptrs:
+            rd = 5
+        if k < 0.30:
+            getattr(a, rng.choice(rr))(rd, r1, r2)
+        elif k < 0.42:
+            getattr(a, rng.choice(ri))(rd, r1, rng.randrange(-2048, 2048))
+        elif k < 0.50:
+            getattr(a, rng.choice(["slli", "srli", "srai"]))(rd, r1, rng.randrange(32))
+        elif k < 0.62:
+            p = rng.choice(ptrs)
+            name, sz = rng.choice([("lb", 1), ("lh", 2), ("lw", 4), ("lbu", 1), ("lhu", 2), ("sb", 1), ("sh", 2), ("sw", 4)])
+            off = rng.randrange(-64, 64)
+            if rng.random() < 0.7:
+                off -= off % sz
+            if name[0] == "l":
+                getattr(a, name)(rd, off, p)
+            else:
+                getattr(a, name)(r2, off, p)
+        elif k < 0.66:                                       # addresses that wrap at 32 bits / lie outside the arena
+            a.li(5, rng.choice([0xFFFFFFFC, 0, S["data"] - 0x80000000 + 0x80000000, BASE + (1 << 14) - 2]))
+            (a.lw if rng.random() < 0.5 else a.sw)(6, rng.choice([0, 4, 8, -4]), 5)
+        elif k < 0.74:
+            lab = f"L{labels}"; labels += 1
+            getattr(a, rng.choice(_BR))(r1, r2, lab)
+            for _ in range(rng.randrange(1, 4)):
+                getattr(a, rng.choice(rr))(rng.choice([5, 6, 7]), rng.choice(regs), rng.choice(regs))
+            a.label(lab)
+        elif k < 0.78:
+            lab = f"L{labels}"; labels += 1
+            if rng.random() < 0.5:
+                a.jal(rng.choice([0, 1, 5]), lab)
+            else:
+                a.la(6, lab); a.jalr(rng.choice([0, 1, 7]), 6, 0)
+            a.addi(7, 7, 1)
+            a.label(lab)
+            a.auipc(rng.choice([5, 6, 7]), rng.randrange(1 << 20))
+        elif k < 0.86:
+            q = rng.random()
+            if q < 0.2:
+                a.c_li(rng.choice([5, 6, 7, 10, 11]), rng.randrange(-32, 32))
+            elif q < 0.35:
+                a.c_addi(rng.choice([5, 6, 7, 10, 11]), rng.randrange(1, 32))
+            elif q < 0.45:
+                a.c_slli(rng.choice([5, 6, 7]), rng.randrange(1, 32))
+            elif q < 0.55:
+                getattr(a, rng.choice(["c_srli", "c_srai"]))(rng.choice([10, 11, 12]), rng.randrange(1, 32))
+            elif q < 0.65:
+                getattr(a, rng.choice(["c_sub", "c_xor", "c_or", "c_and"]))(rng.choice([10, 11, 12]), rng.choice([13, 14, 15]))
+            elif q < 0.75:
+                a.c_lw(rng.choice([10, 11, 12]), 8, 4 * rng.randrange(16)) if rng.random() < 0.5 else a.c_sw(rng.choice([10, 11, 12]), 9, 4 * rng.randrange(16))
+            elif q < 0.82:
+                a.c_add(rng.choice([5, 6, 7]), rng.choice([10, 11, 12])) if rng.random() < 0.5 else a.c_mv(rng.choice([5, 6, 7]), rng.choice([10, 11, 12]))
+            elif q < 0.90:                                   # c.jal: quadrant 1, funct3 001 (c.addiw on RV64)
+                a.half(0x2000 | (((4 >> 1) & 7) << 3) | 1)  # c.jal +4
+                a.c_addi(7, 1)
+                a.c_addi(7, 2)
+            else:                                            # the RV32 code points of c.ld / c.sd / c.ldsp / c.sdsp, shamt[5], c.subw / c.addw
+                a.half(rng.choice([0x6000 | (1 << 10) | (1 << 7), 0xE000 | (1 << 10) | (1 << 7) | (2 << 2), 0x6002 | (5 << 7) | (1 << 4),
+                                   0xE002 | (6 << 2) | (1 << 9), 0x1002 | (5 << 7) | (3 << 2), 0x9C01 | (2 << 7) | (3 << 2), 0x9C21 | (2 << 7) | (3 << 2),
+                                   0x9001 | (2 << 7) | (3 << 2)]))
+        elif k < 0.93:
+            q = rng.random()
+            if q < 0.45:
+                n_ = rng.choice(csrs_rw)
+                op = rng.choice([a.csrrw, a.csrrs, a.csrrc])
+                src = rng.choice(regs)
+                if n_ == 0x300:
+                    a.li(5, rng.choice([0x1800, 0x1888, 0x0088, 0x80001800, 0x6000 if fp else 0x1800, 0x1808])); src = 5
+                    op = a.csrrw
+                if n_ == 0x305:
+                    src = 0; op = a.csrrs                    # mtvec stays the handler
+                if n_ in (0x3A0, 0x3A1):
+                    a.li(5, rng.choice([0, 0x0F, 0x1F00, 0x00180F00, 0x1F1F1F1F & ~0x80808080])); src = 5
+                op(rng.choice(regs[:29]), n_, src)
+            elif q < 0.8:
+                a.csrrs(rng.choice(regs[:29]), rng.choice(csrs_ro + csrs_rw), 0)
+            else:
+                a.csrrw(rng.choice(regs[:29]), rng.choice(csrs_ro), rng.choice(regs))          # read-only: illegal
+        elif k < 0.97:
+            q = rng.random()
+            p = rng.choice(ptrs)
+            if q < 0.5:
+                getattr(a, rng.choice(["amoadd_w", "amoswap_w", "amoxor_w", "amoand_w", "amoor_w", "amomin_w", "amomax_w", "amominu_w", "amomaxu_w"]))(rd, r2, p)
+            elif q < 0.8:
+                a.lr_w(rd, p); a.sc_w(rng.choice([5, 6, 7]), r2, p)
+            else:
+                a.word(rng.choice([0x0000302F | (p << 15) | (6 << 20) | (5 << 7), 0x1000302F | (p << 15) | (5 << 7)]))   # amoadd.d / lr.d: RV64 only
+        else:
+            a.word(rng.choice([0x0010029B, 0x0002B283, 0x0052B023, 0x02029293, 0x4202D293, 0x005302BB, 0x0252C2BB, 0x00000073, 0x00100073,
+                               0xC0201053 | (1 << 20) * 2, 0xE2000053, 0xF2000053, 0x0062E283, rng.getrandbits(32) | 3]))
+    _exit_tohost32(a, S["tohost"])
+    assert a.here() < data_base
+    return _finish(a, f"rv32-{seed}", isa, d, mem_size=1 << 14, max_inst=40000, meta=dict(seed=seed))
+
+
+def _exit_tohost32(a: Asm, tohost_addr, value=1, tmp1=5, tmp2=6):
+    a.li(tmp1, tohost_addr)
+    a.li(tmp2, value)
+    a.sw(tmp2, 0, tmp1)
+    a.jal(0, a.pc)
