@@ -35,6 +35,8 @@ enum { WSP_ST_RUNNING = 0,
        WSP_ST_STOP_ADDR = 5         /* pc reached the stop address before executing it (Hart.cpp:6025, 6230) */ };
 
 /* Resources for peek/poke (Hart::peekIntReg/pokeIntReg ... Hart.hpp:219-325, Hart.cpp:1345-1560). */
+/* WSP_RES_PC takes an index: 0 pc; 1 executed-instruction count (the log's tag, the snapshot's "po"); 2 retired-instruction count
+ * ("pr"); 3 privilege mode ("pm": 0 U, 1 S, 3 M; Hart::privilegeMode / setPrivilegeMode, snapshot.cpp:40, 270). */
 enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4, WSP_RES_V = 5 /* whole vector register, vlen_bytes bytes */ };
 
 /* wsp_batch_run flags */
@@ -124,6 +126,12 @@ int  wsp_batch_poke_each(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint3
  * WSP_ST_STOP_ADDR (the instruction at stop_pc is not executed). */
 int  wsp_batch_set_stop(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi, uint64_t tohost, uint64_t max_inst, uint64_t max_ret, uint64_t stop_pc);
 
+/* Harts of [hart_lo, hart_hi) that ended with WSP_ST_STOP_LIMIT or WSP_ST_STOP_ADDR become runnable again (set new limits / a new
+ * stop address first): Hart::run / untilAddress / singleStep called again on a hart that had reached its limit, as the interactive
+ * "step" / "until" commands and a park-and-service loop do (Hart.cpp:6003, 6963; Interactive.cpp stepCommand / untilCommand).
+ * Harts that wrote tohost, hit consecutive illegal instructions or left the modelled subset stay stopped. */
+int  wsp_batch_resume(wsp_batch* b, uint32_t hart_lo, uint32_t hart_hi);
+
 /* System::batchRun / Hart::run (System.cpp:1654, Hart.cpp:6963): step every running hart until it
  * stops or has executed max_steps more instructions. Returns the number of harts still running
  * (>= 0) or a negative error. */
@@ -146,13 +154,26 @@ int  wsp_batch_last_hash_stats(wsp_batch* b, double* kernel_seconds, uint64_t* b
 /* Commit ring (the binary side of the reference's --logfile, printTrace.cpp:380-495; Hart::printInstTrace).  With
  * words_per_hart > 0 every run started with WSP_RUN_TRACE_HASH also appends each hart's commit records to a ring of that
  * many 64-bit words (recording stops when it is full; the digest goes on; every step takes the general path while a ring
- * is on).  Record: pc, meta = inst | priv << 32 | trap << 40 | size << 48 | npairs << 56, kinds, then npairs x (id, value):
- * pair k has kind = (kinds >> 4k) & 15: 1 x-reg, 2 f-reg, 3 v-reg (value = digest of the register), 4 memory (id = the
- * whole 64-bit address), 5 CSR, in the order the reference's log prints them.  0 switches it off.  Calling it again clears
- * the ring.  Not part of snapshot / restore. */
+ * is on).  Record: pc, meta = inst | priv << 32 | trap << 40 | size << 48 | ldst << 55 | npairs << 56, kinds, then npairs x (id,
+ * value): pair k has kind = (kinds >> 4k) & 15: 1 x-reg, 2 f-reg, 3 v-reg (value = digest of the register), 4 memory (id = the
+ * whole 64-bit address), 5 CSR, in the order the reference's log prints them; then, outside the digest, what only the text log
+ * needs: if ldst, the virtual and the physical address of the scalar load / store / atomic (2 words), and for every v-reg pair
+ * the vlen_bytes / 8 words of the register.  0 switches it off.  Calling it again clears the ring.  Not part of snapshot /
+ * restore. */
 int wsp_batch_trace_ring(wsp_batch* b, uint32_t words_per_hart);
 /* Copies the words recorded for one hart (at most cap); returns their count, or a negative error. */
 int64_t wsp_batch_trace_read(wsp_batch* b, uint32_t hart, uint64_t* words, size_t cap);
+/* The recorded commits of one hart as the reference's --logfile text (Hart::printDecodedInstTrace, printTrace.cpp:302-517, line
+ * layouts printTrace.cpp:56-209 for RV32 / RV64; disassembly column as Disassembler.cpp prints it): one line per changed resource
+ * in the order r f v m c, continuation lines joined by "  +" (" +" before a vector register line), "[va]" / "[va:pa]" after
+ * scalar loads, stores and atomics, "(exception)" / "(interrupted)" marks, vector registers with their bytes.  first_tag is the
+ * instruction number of the first recorded commit (1 for a ring switched on before the first run).  Writes at most cap - 1
+ * characters and a NUL; returns the length of the whole text, or a negative error.  Not printed: the element address lists of
+ * vector loads / stores and page-table-walk lines (--traceptw). */
+int64_t wsp_batch_trace_text(wsp_batch* b, uint32_t hart, uint64_t first_tag, char* text, size_t cap);
+/* Disassembler::disassembleInst (Disassembler.cpp:519): the log's disassembly column for one instruction word as fetched (a 16-bit
+ * instruction in the low half); xlen 32 or 64.  Needs no device.  Returns the text length. */
+int     wsp_disassemble(uint32_t inst, uint32_t xlen, char* text, size_t cap);
 
 /* System::produceTestSignatureFile (System.cpp:1586-1633): 32-bit words from begin_signature to
  * end_signature of `hart`; writes up to cap words, returns the word count or a negative error. */

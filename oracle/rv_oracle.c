@@ -189,6 +189,7 @@ struct rvo_hart {
   int ch_ireg; int ch_freg;
   int ch_vreg; int ch_vgroup;       /* first register (operand 0) and register count of the vector group written */
   int ch_mem; u64 ch_mem_addr, ch_mem_val;
+  int ld_has; u64 ld_va, ld_pa;     /* ldStSize_ != 0, ldStAddr_, ldStPhysAddr1_ */
   unsigned ch_csr[8]; int ch_ncsr;
   u64 trace_hash;
 };
@@ -539,7 +540,7 @@ static void csr_store(rvo_hart* h, unsigned num, u64 v, int record)
 /* ------------------------------------------------------------------ trace capture */
 static void begin_inst(rvo_hart* h)
 {
-  h->has_exc = 0; h->ch_ireg = -1; h->ch_freg = -1; h->ch_mem = 0; h->ch_ncsr = 0; h->ch_vreg = -1; h->ch_vgroup = 0;
+  h->has_exc = 0; h->ch_ireg = -1; h->ch_freg = -1; h->ch_mem = 0; h->ch_ncsr = 0; h->ch_vreg = -1; h->ch_vgroup = 0; h->ld_has = 0;
 }
 
 static inline void wx(rvo_hart* h, unsigned rd, u64 v)
@@ -583,6 +584,7 @@ static void finish_commit(rvo_hart* h, u32 inst, unsigned size, unsigned priv, i
   }
   if (k == 0) { c.ch[0].kind = RVO_CH_R; c.ch[0].key = 0; c.ch[0].val = 0; k = 1; }  /* printTrace.cpp:491-493 */
   c.nchanges = (uint8_t)k;
+  c.has_ld = (uint32_t)h->ld_has; c.ld_va = h->ld_va; c.ld_pa = h->ld_pa;
   u64 hh = h->trace_hash;
   hh = rvo_fold(hh, c.pc);
   hh = rvo_fold(hh, (u64)c.inst | ((u64)c.priv << 32) | ((u64)c.trap << 40) | ((u64)c.size << 48));
@@ -922,9 +924,11 @@ static int do_load(rvo_hart* h, u64 va, unsigned size, u64* out)
 {
   u64 tval, pa1, pa2;
   if (h->rv32) va &= 0xffffffffULL;
+  h->ld_has = 1; h->ld_va = va; h->ld_pa = va;
   if (ldst_translate_unsupported(h)) return 0;
   unsigned c = ldst_addr(h, va, size, 1, &pa1, &pa2, &tval);
   if (c) { ldst_exception(h, c, tval); return 0; }
+  h->ld_pa = pa1;
   if (h->cfg.tohost_valid && pa1 == h->cfg.tohost) { *out = 0; return 1; }   /* Hart.cpp:2509-2513 */
   *out = mem_read2(h, pa1, pa2, size);
   return 1;
@@ -950,9 +954,11 @@ static int do_store(rvo_hart* h, u64 va, unsigned size, u64 val)
 {
   u64 tval, pa1, pa2;
   if (h->rv32) va &= 0xffffffffULL;
+  h->ld_has = 1; h->ld_va = va; h->ld_pa = va;
   if (ldst_translate_unsupported(h)) return 0;
   unsigned c = ldst_addr(h, va, size, 2, &pa1, &pa2, &tval);
   if (c) { ldst_exception(h, c, tval); return 0; }
+  h->ld_pa = pa1;
   u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
   h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;                    /* the log's m line carries the virtual address (printTrace.cpp:457) */
   if (h->cfg.tohost_valid && (pa1 == h->cfg.tohost || pa1 == h->cfg.tohost + 4)) { store_tohost(h, pa1, sv, size); return 1; }
@@ -1131,8 +1137,7 @@ static u32 expand16(u32 c, int rv32)
         return enc_i(0x13, 0, rdp, 2, (i32)imm); }
       case 1: return enc_i(0x07, 3, rdp, rs1p, (i32)uimm_d);          /* c.fld */
       case 2: return enc_i(0x03, 2, rdp, rs1p, (i32)uimm_w);          /* c.lw */
-      case 3: if (rv32) return enc_s(0x23, 2, rs1p, rdp, 0);          /* RV32: the reference hands back its c.sw entry with the offset operand left
-                                                                         at zero for this code point (Decoder.cpp:1491-1502) */
+      case 3: if (rv32) return enc_i(0x07, 2, rdp, rs1p, (i32)uimm_w);   /* c.flw (Decoder.cpp:1490-1503) */
               return enc_i(0x03, 3, rdp, rs1p, (i32)uimm_d);          /* c.ld */
       case 5: return enc_s(0x27, 3, rs1p, rdp, (i32)uimm_d);          /* c.fsd */
       case 6: return enc_s(0x23, 2, rs1p, rdp, (i32)uimm_w);          /* c.sw */
@@ -1210,6 +1215,9 @@ static u32 expand16(u32 c, int rv32)
   return 0;
 }
 
+/* test hook: the 32-bit encoding a 16-bit word stands for (0 = illegal) */
+uint32_t rvo_expand16(uint32_t c, int rv32) { return expand16(c & 0xffff, rv32); }
+
 /* ------------------------------------------------------------------ execute one 32-bit encoding */
 typedef unsigned __int128 u128;
 typedef __int128 i128;
@@ -1218,6 +1226,95 @@ static void exec_fp(rvo_hart* h, u32 inst, u32 raw);
 static void exec_amo(rvo_hart* h, u32 inst, u32 raw);
 #include "rv_oracle_vec.inc"
 
+
+/* Zba / Zbb / Zbs / Zbc / Zicond (bitmanip.cpp:10-1110, Hart.cpp:14728-14760; encodings Decoder.cpp:2490-2557, 2596-2627,
+ * 2771-2864 and the OP-32 block).  Returns 1 with the result in *out when `inst` is one of them and its extension is on; 0
+ * otherwise (the caller goes on to the base ISA and ends in an illegal-instruction trap).  a, b: x[rs1], x[rs2] as held (an RV32
+ * hart's are sign-extended; the caller's wx() brings the result back into that shape). */
+static int exec_bitmanip(const rvo_hart* h, u32 inst, u64 a, u64 b, u64* out)
+{
+  const u32 op = inst & 0x7f, f3 = (inst >> 12) & 7, f7 = inst >> 25, imm12 = inst >> 20;
+  const int rv32 = h->rv32, zba = ext(h, RVO_ISA_ZBA), zbb = ext(h, RVO_ISA_ZBB), zbs = ext(h, RVO_ISA_ZBS), zbc = ext(h, RVO_ISA_ZBC);
+  const unsigned xlen = rv32 ? 32 : 64, smask = xlen - 1;
+  const u64 ua = rv32 ? (u64)(u32)a : a;                       /* the register as the URV the reference reads */
+  const u32 aw = (u32)a, bw = (u32)b;
+  u64 r;
+  if (op == 0x33) {
+    const unsigned ix = (unsigned)(b & smask);
+    switch (f7) {
+      case 0x04: if (!(rv32 && zbb && f3 == 4 && ((inst >> 20) & 31) == 0)) return 0; r = a & 0xffff; break;         /* zext.h = pack rd, rs1, x0 on RV32 (bitmanip.cpp:435-451) */
+      case 0x05:
+        if (f3 >= 4) { if (!zbb) return 0;
+          r = f3 == 4 ? ((i64)a < (i64)b ? a : b) : f3 == 6 ? ((i64)a > (i64)b ? a : b) : f3 == 5 ? (a < b ? a : b) : (a > b ? a : b); break; }
+        if (!zbc || f3 == 0) return 0;
+        { const u64 ub = rv32 ? (u64)(u32)b : b; unsigned i; r = 0;
+          if (f3 == 1) { for (i = 0; i < xlen; ++i) if ((ub >> i) & 1) r ^= ua << i; }
+          else if (f3 == 3) { for (i = 1; i < xlen; ++i) if ((ub >> i) & 1) r ^= ua >> (xlen - i); }
+          else { for (i = 0; i < xlen; ++i) if ((ub >> i) & 1) r ^= ua >> (xlen - i - 1); } }
+        break;
+      case 0x07: if (!ext(h, RVO_ISA_ZICOND) || (f3 != 5 && f3 != 7)) return 0; r = ((b == 0) == (f3 == 5)) ? 0 : a; break;
+      case 0x10: if (!zba || (f3 != 2 && f3 != 4 && f3 != 6)) return 0; r = (a << (f3 >> 1)) + b; break;
+      case 0x14: if (!zbs || f3 != 1) return 0; r = a | (1ULL << ix); break;
+      case 0x20: if (!zbb || f3 < 4 || f3 == 5) return 0; r = f3 == 4 ? a ^ ~b : f3 == 6 ? a | ~b : a & ~b; break;
+      case 0x24: if (!zbs || (f3 != 1 && f3 != 5)) return 0; r = f3 == 1 ? a & ~(1ULL << ix) : (ua >> ix) & 1; break;
+      case 0x30: if (!zbb || (f3 != 1 && f3 != 5)) return 0;
+        if (rv32) { const u32 w = f3 == 1 ? (aw << ix) | (aw >> ((32 - ix) & 31)) : (aw >> ix) | (aw << ((32 - ix) & 31)); r = w; }
+        else r = f3 == 1 ? (a << ix) | (a >> ((64 - ix) & 63)) : (a >> ix) | (a << ((64 - ix) & 63));
+        break;
+      case 0x34: if (!zbs || f3 != 1) return 0; r = a ^ (1ULL << ix); break;
+      default: return 0;
+    }
+  } else if (op == 0x13) {
+    const unsigned top5 = imm12 >> 7, amt = imm12 & 0x7f;
+    if (f3 == 1) {
+      if (top5 == 0x0c) {
+        if (!zbb) return 0;
+        switch (amt) {
+          case 0: r = rv32 ? (aw ? (u64)__builtin_clz(aw) : 32) : (a ? (u64)__builtin_clzll(a) : 64); break;
+          case 1: r = rv32 ? (aw ? (u64)__builtin_ctz(aw) : 32) : (a ? (u64)__builtin_ctzll(a) : 64); break;
+          case 2: r = (u64)__builtin_popcountll(ua); break;
+          case 4: r = (u64)(i64)(int8_t)a; break;
+          case 5: r = (u64)(i64)(int16_t)a; break;
+          default: return 0;
+        }
+      } else if (top5 == 5 || top5 == 9 || top5 == 0x0d) {
+        if (!zbs || amt > smask) return 0;                                  /* checkShiftImmediate (Hart.cpp:11736-11746) */
+        r = top5 == 5 ? a | (1ULL << amt) : top5 == 9 ? a & ~(1ULL << amt) : a ^ (1ULL << amt);
+      } else return 0;
+    } else if (f3 == 5) {
+      if (top5 == 5) { unsigned i; if (!zbb || amt != 7) return 0; r = 0; for (i = 0; i < 64; i += 8) if ((a >> i) & 0xff) r |= 0xffULL << i; }
+      else if (top5 == 9) { if (!zbs || amt > smask) return 0; r = (ua >> amt) & 1; }
+      else if (top5 == 0x0c) {
+        if (!zbb || amt > smask) return 0;
+        if (rv32) r = (u32)((aw >> amt) | (aw << ((32 - amt) & 31))); else r = (a >> amt) | (a << ((64 - amt) & 63));
+      }
+      else if (!rv32 && imm12 == 0x6b8) { if (!zbb) return 0; r = __builtin_bswap64(a); }
+      else if (rv32 && imm12 == 0x698) { if (!zbb) return 0; r = __builtin_bswap32(aw); }
+      else return 0;
+    } else return 0;
+  } else if (op == 0x1b) {                                                  /* RV64 only: the caller has rejected OP-IMM-32 on RV32 */
+    const unsigned top5 = imm12 >> 7, amt = imm12 & 0x7f;
+    if (f3 == 1 && (imm12 >> 6) == 2) { if (!zba) return 0; r = (u64)aw << (amt & 63); }
+    else if (f3 == 1 && top5 == 0x0c && amt <= 2) {
+      if (!zbb) return 0;
+      r = amt == 0 ? (aw ? (u64)__builtin_clz(aw) : 32) : amt == 1 ? (aw ? (u64)__builtin_ctz(aw) : 32) : (u64)__builtin_popcount(aw);
+    }
+    else if (f3 == 5 && f7 == 0x30) { const unsigned s = (inst >> 20) & 31; if (!zbb) return 0; r = (u64)(i64)(i32)((aw >> s) | (aw << ((32 - s) & 31))); }
+    else return 0;
+  } else if (op == 0x3b) {
+    const unsigned s = bw & 31;
+    if (f7 == 0x04 && f3 == 0) { if (!zba) return 0; r = (u64)aw + b; }
+    else if (f7 == 0x04 && f3 == 4) { if (!zbb || ((inst >> 20) & 31) != 0) return 0; r = a & 0xffff; }                /* zext.h = packw rd, rs1, x0 (bitmanip.cpp:498-524) */
+    else if (f7 == 0x10 && (f3 == 2 || f3 == 4 || f3 == 6)) { if (!zba) return 0; r = ((u64)aw << (f3 >> 1)) + b; }
+    else if (f7 == 0x30 && (f3 == 1 || f3 == 5)) {
+      if (!zbb) return 0;
+      r = (u64)(i64)(i32)(f3 == 1 ? (aw << s) | (aw >> ((32 - s) & 31)) : (aw >> s) | (aw << ((32 - s) & 31)));
+    }
+    else return 0;
+  } else return 0;
+  *out = r;
+  return 1;
+}
 
 /* `inst` is the (possibly expanded) 32-bit encoding; `raw` the bits as fetched (mtval on illegal). */
 static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
@@ -1231,8 +1328,12 @@ static void execute(rvo_hart* h, u32 inst, u32 raw, unsigned size)
   const u64 pcm = rv32 ? 0xffffffffULL : ~0ULL;          /* RV32: pc and addresses wrap at 32 bits */
   if (rv32) {                                            /* encodings that exist on RV64 only */
     if (op == 0x1b || op == 0x3b || (op == 0x03 && (f3 == 3 || f3 == 6)) || (op == 0x23 && f3 == 3)) goto ill;
-    if (op == 0x13 && (f3 == 1 || f3 == 5) && (inst & (1u << 25))) goto ill;         /* shamt[5] (Hart.cpp:11736-11746) */
   }
+  if ((h->cfg.isa & (RVO_ISA_ZBA | RVO_ISA_ZBB | RVO_ISA_ZBS | RVO_ISA_ZBC | RVO_ISA_ZICOND)) && (op == 0x13 || op == 0x1b || op == 0x33 || op == 0x3b)) {
+    u64 r;
+    if (exec_bitmanip(h, inst, a, b, &r)) { wx(h, rd, r); return; }
+  }
+  if (rv32 && op == 0x13 && (f3 == 1 || f3 == 5) && (inst & (1u << 25))) goto ill;   /* shamt[5] (Hart.cpp:11736-11746) */
   switch (op) {
     case 0x37: wx(h, rd, (u64)(i64)(i32)(inst & 0xfffff000u)); return;
     case 0x17: wx(h, rd, h->curr_pc + (u64)(i64)(i32)(inst & 0xfffff000u)); return;
@@ -1419,6 +1520,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
   u64 va = h->rv32 ? (u64)(u32)h->x[rs1] : h->x[rs1], tval;
   if (f5 == 2) {                                            /* lr: amo.cpp:142-266 */
     if (rs2 != 0) { illegal(h, raw); return; }
+    h->ld_has = 1; h->ld_va = va; h->ld_pa = va;
     if (ldst_translate_unsupported(h)) return;
     u64 pa1, pa2;
     /* determineLoadException first (a translation fault wins), then the alignment / reservability check; either way
@@ -1427,6 +1529,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
     if (c == 4) c = 5;                                      /* misalAtomicCauseAccessFault_ (amo.cpp:180-181) */
     if (c == 0 && (va & (size - 1))) c = 5;
     if (c) { ldst_exception(h, c, va); return; }
+    h->ld_pa = pa1;
     u64 v = ld_le(h->mem + (pa1 - h->cfg.mem_base), size);
     if (size == 4) v = (u64)(i64)(i32)v;
     wx(h, rd, v);
@@ -1434,6 +1537,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
     return;
   }
   if (f5 == 3) {                                            /* sc: amo.cpp:273-420 */
+    h->ld_has = 1; h->ld_va = va; h->ld_pa = va;
     if (ldst_translate_unsupported(h)) return;
     int exc = 0;
     u64 pa1 = va, pa2;
@@ -1442,6 +1546,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
     int had = h->lr_valid && h->lr_addr <= pa1 && pa1 + size <= h->lr_addr + h->lr_size;
     h->lr_valid = 0;                                                  /* cancelLr(SC) amo.cpp:403-405 */
     if (exc) return;
+    h->ld_pa = pa1;
     if (!had) { wx(h, rd, 1); return; }
     u64 sv = size == 8 ? h->x[rs2] : (h->x[rs2] & 0xffffffffULL);
     h->ch_mem = 1; h->ch_mem_addr = va; h->ch_mem_val = sv;
@@ -1451,6 +1556,7 @@ static void exec_amo(rvo_hart* h, u32 inst, u32 raw)
   }
   switch (f5) { case 0: case 1: case 4: case 8: case 12: case 16: case 20: case 24: case 28: break; default: illegal(h, raw); return; }
   /* amo: execAmo32Op / execAmo64Op (amo.cpp:427-460): amoLoad then store<>() */
+  h->ld_has = 1; h->ld_va = va; h->ld_pa = va;
   if (ldst_translate_unsupported(h)) return;
   u64 apa1 = va, apa2;
   if (va & (size - 1)) { ldst_exception(h, 7, va); return; }           /* validateAmoAddr: misaligned first (amo.cpp:35-38) */
@@ -1673,6 +1779,8 @@ static u32 read_inst_for_log(rvo_hart* h, u64 va)
   return iw;
 }
 
+/* Hart::run / untilAddress / singleStep called again after a limit or the stop address ended the last call (Hart.cpp:6003, 6963) */
+void rvo_resume(rvo_hart* h) { if (h->status == RVO_STOP_LIMIT || h->status == RVO_STOP_ADDR) h->status = RVO_RUNNING; }
 void rvo_set_stop(rvo_hart* h, u64 max_ret, int stop_pc_valid, u64 stop_pc) { h->max_ret = max_ret; h->stop_pc_valid = stop_pc_valid; h->stop_pc = stop_pc; }
 
 int rvo_run(rvo_hart* h, u64 max_exec, rvo_commit* log, size_t cap, size_t* n)

@@ -26,6 +26,8 @@ enum {
   RVO_ISA_M = 1 << 0, RVO_ISA_A = 1 << 1, RVO_ISA_F = 1 << 2, RVO_ISA_D = 1 << 3,
   RVO_ISA_C = 1 << 4, RVO_ISA_S = 1 << 5, RVO_ISA_U = 1 << 6, RVO_ISA_V = 1 << 7,
   RVO_ISA_ZICNTR = 1 << 8,
+  /* (bit 9 is the library's RV32 mark; the oracle takes the width from rvo_config.xlen) */
+  RVO_ISA_ZBA = 1 << 10, RVO_ISA_ZBB = 1 << 11, RVO_ISA_ZBS = 1 << 12, RVO_ISA_ZICOND = 1 << 13, RVO_ISA_ZBC = 1 << 14,
   /* configuration switches (HartConfig::applyConfig tags, HartConfig.cpp:2085-2958); all clear = the reference's defaults */
   RVO_CFG_NO_MISAL = 1 << 16,          /* enable_misaligned_data = false */
   RVO_CFG_CLR_MTVAL_ILL = 1 << 17,     /* clear_mtval_on_illegal_instruction */
@@ -65,6 +67,10 @@ typedef struct {
   uint8_t  trap;       /* 1 exception, 2 interrupt */
   uint8_t  nchanges;
   rvo_change ch[RVO_MAX_CHANGES];
+  /* scalar load / store / atomic: the addresses the log prints as "[va]" / "[va:pa]" (ldStAddr_, ldStPhysAddr1_; Hart.cpp:2306-2333,
+   * 2678-2710, amo.cpp:68-97, 146-183, 277-321).  Not part of the trace digest. */
+  uint64_t ld_va, ld_pa;
+  uint32_t has_ld, pad2;
 } rvo_commit;
 
 typedef struct {
@@ -110,6 +116,7 @@ void      rvo_set_vreg(rvo_hart* h, unsigned i, const void* src);
 int       rvo_run(rvo_hart* h, uint64_t max_exec, rvo_commit* log, size_t log_cap, size_t* log_n);
 
 /* retCountLim_ and the stop address of Hart::untilAddress (Hart.cpp:6011, 6025-6026): max_ret = UINT64_MAX for none */
+void      rvo_resume(rvo_hart* h);   /* a hart stopped by a count limit or its stop address runs again */
 void      rvo_set_stop(rvo_hart* h, uint64_t max_ret, int stop_pc_valid, uint64_t stop_pc);
 
 int       rvo_status(const rvo_hart* h);
@@ -140,6 +147,9 @@ int       rvo_vec_probe(rvo_hart* h, unsigned what, uint64_t a, uint64_t b, uint
 uint64_t  rvo_vf_probe(unsigned kind, unsigned esz, uint64_t a, uint64_t b, uint64_t c, unsigned rm, unsigned* flags);
 uint64_t  rvo_fold(uint64_t h, uint64_t w);
 uint64_t  rvo_mix(uint64_t x);
+
+/* test hook: Decoder::expandCompressedInst restated (0 = illegal) */
+uint32_t rvo_expand16(uint32_t c, int rv32);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "librvoracle.so")
 SF_LIB = os.path.join(HERE, "_ref", "libsoftfloat_ref.so")
 WH_LIB = os.path.join(HERE, "_ref", "libwhisper_ref.so")
 
-ISA_BITS = dict(m=1, a=2, f=4, d=8, c=16, s=32, u=64, v=128, zicntr=256)
+ISA_BITS = dict(m=1, a=2, f=4, d=8, c=16, s=32, u=64, v=128, zicntr=256, zba=1 << 10, zbb=1 << 11, zbs=1 << 12, zicond=1 << 13, zbc=1 << 14)
 
 RUNNING, STOP_TOHOST, STOP_ILLEGAL, STOP_LIMIT, STOP_UNSUPPORTED, STOP_ADDR = range(6)
 CH_R, CH_F, CH_V, CH_M, CH_C = 1, 2, 3, 4, 5
@@ -44,7 +44,8 @@ class Change(C.Structure):
 
 class Commit(C.Structure):
     _fields_ = [("tag", C.c_uint64), ("pc", C.c_uint64), ("inst", C.c_uint32), ("size", C.c_uint8),
-                ("priv", C.c_uint8), ("trap", C.c_uint8), ("nchanges", C.c_uint8), ("ch", Change * MAX_CHANGES)]
+                ("priv", C.c_uint8), ("trap", C.c_uint8), ("nchanges", C.c_uint8), ("ch", Change * MAX_CHANGES),
+                ("ld_va", C.c_uint64), ("ld_pa", C.c_uint64), ("has_ld", C.c_uint32), ("pad2", C.c_uint32)]
 
     def changes(self):
         return [(self.ch[i].kind, self.ch[i].key, self.ch[i].val) for i in range(self.nchanges)]
@@ -206,6 +207,11 @@ class Hart:
 
     tlb_hash = property(lambda s: s.L.rvo_tlb_hash(s.h))
 
+    def resume(self):
+        self.L.rvo_resume.argtypes = [C.c_void_p]
+        self.L.rvo_resume.restype = None
+        self.L.rvo_resume(self.h)
+
     def run(self, max_exec=1 << 62, log_cap=0):
         """Returns (status, [Commit...])."""
         if log_cap:
@@ -263,25 +269,44 @@ def ref_decode(inst: int, rv64=True):
 PRIV_STR = {0: "U", 1: "S", 3: "M"}
 
 
-def format_commit(c, hart_ix=0, disasm=None) -> str:
-    """One logical commit record in the reference's --log text format for RV64
-    (printTrace.cpp:139-209, 302-517): continuation lines joined by '  +\\n'."""
+def format_commit(c, hart_ix=0, disasm=None, xlen=64, has_d=True, vbytes=None) -> str:
+    """One logical commit record in the reference's --log text format (printTrace.cpp:56-209 line layouts for the two widths,
+    302-517 record assembly): continuation lines joined by '  +\n' (' +\n' before a vector register line).  disasm: the
+    disassembly column; vbytes: {reg: bytes} for the vector register lines (the record itself carries a digest only)."""
     op = f"{c.inst:08x}" if c.size == 4 else f"{c.inst & 0xffff:04x}"
     txt = disasm if disasm is not None else ""
-    # printTrace.cpp:338-346 appends the data address of scalar loads/stores; the commit record carries it for
-    # stores (the m change) only, so load lines lack the suffix (text-log parity is SURVEY 8f row 2, not this round)
-    for kind, key, _ in c.changes():
-        if kind == CH_M:
-            txt += f" [0x{key:x}]"
+    if c.has_ld:                                             # printTrace.cpp:338-346
+        txt += f" [0x{c.ld_va:x}]" if c.ld_va == c.ld_pa else f" [0x{c.ld_va:x}:0x{c.ld_pa:x}]"
     if c.trap == 1:
         txt += " (exception)"
     elif c.trap == 2:
         txt += " (interrupted)"
-    lines = []
+    out = ""
+    pending = False
     for kind, key, val in c.changes():
-        res = {CH_R: "r", CH_F: "f", CH_M: "m", CH_C: "c", CH_V: "v"}[kind]
-        lines.append(f"#{c.tag} {hart_ix} {PRIV_STR[c.priv]:>2s} {c.pc:016x} {op:>8s} {res} {key:016x} {val:016x} {txt}")
-    return "  +\n".join(lines)
+        if pending:
+            out += " +\n" if kind == CH_V else "  +\n"
+        head = f"#{c.tag} {hart_ix} {PRIV_STR[c.priv]:>2s} " + (f"{c.pc:08x}" if xlen == 32 else f"{c.pc:016x}") + f" {op:>8s} "
+        if kind == CH_V:
+            data = vbytes[key] if vbytes else b""
+            out += head + f"v {key:02x} " + "".join(f"{x:02x}" for x in reversed(data)) + " " + txt
+        elif kind == CH_F:
+            if xlen == 32:
+                out += head + (f"f {key:02x} {val:016x}  " if has_d else f"f {key:02x}         {val & 0xffffffff:08x}  ") + txt
+            else:
+                out += head + (f"f {key:016x} {val:016x} " if has_d else f"f {key:016x}         {val & 0xffffffff:08x} ") + txt
+        else:
+            ch = {CH_R: "r", CH_M: "m", CH_C: "c"}[kind]
+            if xlen == 64:
+                out += head + f"{ch} {key:016x} {val:016x} " + txt
+            elif ch == "r":
+                out += head + f"r {key:02x}         {val:08x}  " + txt
+            elif ch == "c" and (key >> 16) == 0:
+                out += head + f"c {key:04x}       {val:08x}  " + txt
+            else:
+                out += head + f"{ch} {key:08x}   {val:08x}  " + txt
+        pending = True
+    return out
 
 
 def pmp_perm(hart: "Hart", priv: int, addr: int) -> int:

@@ -114,6 +114,7 @@ u64 hs_cold_raw(Sim* s, u32 ix) { return ix < CI_COUNT ? s->L.m.cold_[ix] : 0; }
 void hs_poke_csr(Sim* s, u32 num, u64 v) { s->L.csr_store(num, v); s->L.s.chg = 0; }
 int hs_run(Sim* s, u64 max_exec, int trace)
 {
+  if (s->L.h.status == ST_STOP_LIMIT || s->L.h.status == ST_STOP_ADDR) s->L.h.status = ST_RUNNING;   // (wsp_batch_resume)
   if (trace) run_t<true>(s, max_exec); else run_t<false>(s, max_exec);
   return (int)s->L.h.status;
 }

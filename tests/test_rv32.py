@@ -86,6 +86,40 @@ def test_rv32_decoder_matches_reference_decoder():
     assert {"c.jal", "c.fsw", "c.flwsp", "c.fswsp", "mulh", "amoadd.w", "fadd.d"} <= seen
 
 
+@needs_ref
+@pytest.mark.parametrize("rv64", [True, False])
+def test_compressed_expansion_matches_reference(rv64):
+    """Every 16-bit word, both widths: the 32-bit instruction the oracle executes for it == the reference's own
+    Decoder::expandCompressedInst (registers and immediates included), wherever the oracle accepts the word; and the device decoder
+    produces the same record for the 16-bit word as for that expansion."""
+    L = rvoracle.lib()
+    L.rvo_expand16.restype = C.c_uint32
+    L.rvo_expand16.argtypes = [C.c_uint32, C.c_int]
+    words = [w for w in range(1, 65536) if (w & 3) != 3]
+    flags = rvoracle.isa_flags("rv64imafdc_zicsr") | (0 if rv64 else 512)
+    d16 = _host_decode(flags, words)
+    exp = [L.rvo_expand16(w, 0 if rv64 else 1) for w in words]
+    d32 = _host_decode(flags, [e if e else 0 for e in exp])
+    n = 0
+    for i, w in enumerate(words):
+        mine_ill = (d16[i].w0 & 0xff) == 0
+        if exp[i] == 0:
+            assert mine_ill, f"{w:#x}: oracle illegal, device decodes"
+            continue
+        ref = R.ref_expand16(1 if rv64 else 0, w)
+        if not rv64 and (w & 0xE003) == 0xE000:
+            # c.fsw: expandCompressedInst hands encodeFsw its registers the other way round than encodeSw gets them
+            # (Decoder.cpp:1930-1936); execution goes through decode16, whose operands are checked here instead
+            _, name, ops = rvoracle.ref_decode(w, rv64=False)
+            assert name == "c.fsw" and (ops[0], ops[1], ops[2]) == ((exp[i] >> 20) & 31, (exp[i] >> 15) & 31, ((exp[i] >> 25) << 5) | ((exp[i] >> 7) & 31))
+            ref = exp[i]
+        assert exp[i] == ref, f"{w:#06x}: oracle expands to {exp[i]:#010x}, reference to {ref:#010x} ({rvoracle.ref_disassemble(w, rv64=rv64)})"
+        if not mine_ill:                                      # same operation, registers and immediate as the expansion (size flag aside)
+            assert (d16[i].w0 & ~(1 << 28), d16[i].imm) == (d32[i].w0 & ~(1 << 28), d32[i].imm), f"{w:#06x} vs {exp[i]:#010x}"
+            n += 1
+    assert n > 40000
+
+
 CSR32 = [0x300, 0x301, 0x304, 0x305, 0x306, 0x30A, 0x310, 0x31A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x344, 0x001, 0x002, 0x003,
          0xB00, 0xB02, 0xB80, 0xB82, 0xC00, 0xC01, 0xC02, 0xC80, 0xC81, 0xC82, 0xF11, 0xF12, 0xF13, 0xF14] + list(range(0x3A0, 0x3F0))
 CSR32_W = [0x300, 0x304, 0x305, 0x306, 0x30A, 0x310, 0x31A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x001, 0x002, 0x003]

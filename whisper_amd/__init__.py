@@ -58,7 +58,7 @@ class Decoded(C.Structure):
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_softfloat.h"), os.path.join(HERE, "csrc", "wsp_config.h"),
-            os.path.join(ROOT, "include", "whisper_amd.h")]
+            os.path.join(HERE, "csrc", "wsp_disasm.h"), os.path.join(HERE, "csrc", "wsp_disasm_tables.inc"), os.path.join(ROOT, "include", "whisper_amd.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
@@ -104,6 +104,10 @@ def lib():
         L.wsp_batch_trace_ring.argtypes = [vp, u32]
         L.wsp_batch_trace_read.restype = C.c_int64
         L.wsp_batch_trace_read.argtypes = [vp, u32, C.POINTER(u64), C.c_size_t]
+        L.wsp_batch_trace_text.restype = C.c_int64
+        L.wsp_batch_trace_text.argtypes = [vp, u32, u64, C.c_char_p, C.c_size_t]
+        L.wsp_disassemble.argtypes = [u32, u32, C.c_char_p, C.c_size_t]
+        L.wsp_batch_resume.argtypes = [vp, u32, u32]
         L.wsp_batch_snapshot.argtypes = [vp]
         L.wsp_batch_restore.argtypes = [vp]
         L.wsp_decode_words.argtypes = [C.c_char_p, C.POINTER(u32), C.c_size_t, C.POINTER(Decoded)]
@@ -208,6 +212,11 @@ class Batch:
         _check(self.L.wsp_batch_set_stop(self.h, lo, hi, NO_LIMIT if tohost is None else tohost, max_inst, max_ret,
                                          NO_LIMIT if stop_pc is None else stop_pc))
 
+    def resume(self, lo=None, hi=None):
+        """wsp_batch_resume: harts stopped by a count limit or their stop address run again."""
+        lo, hi = self._rng(lo, hi)
+        _check(self.L.wsp_batch_resume(self.h, lo, hi))
+
     def run(self, max_steps=NO_LIMIT, trace_hash=False):
         return _check(self.L.wsp_batch_run(self.h, max_steps, RUN_TRACE_HASH if trace_hash else 0))
 
@@ -237,19 +246,28 @@ class Batch:
 
     def trace(self, hart):
         """Commit records of one hart: [(pc, inst, size, priv, trap, [(kind, id, value), ...]), ...]; a record cut off by the
-        end of the ring is dropped."""
+        end of the ring is dropped.  (The ring also holds each record's load / store address pair and vector register bytes:
+        trace_text prints them.)"""
         buf = (C.c_uint64 * self._ring_cap)()
         n = _check(self.L.wsp_batch_trace_read(self.h, hart, buf, self._ring_cap))
         out, i = [], 0
         while i + 3 <= n:
             pc, meta, kinds = buf[i], buf[i + 1], buf[i + 2]
             npairs = meta >> 56
-            if i + 3 + 2 * npairs > n:
+            pairs = [((kinds >> (4 * k)) & 15, buf[i + 3 + 2 * k], buf[i + 4 + 2 * k]) for k in range(npairs) if i + 4 + 2 * k < n]
+            length = 3 + 2 * npairs + (2 if (meta >> 55) & 1 else 0) + sum(1 for p in pairs if p[0] == 3) * (self.vlen_bytes // 8)
+            if i + length > n:
                 break
-            pairs = [((kinds >> (4 * k)) & 15, buf[i + 3 + 2 * k], buf[i + 4 + 2 * k]) for k in range(npairs)]
-            out.append((pc, meta & 0xFFFFFFFF, (meta >> 48) & 0xFF, (meta >> 32) & 0xFF, (meta >> 40) & 0xFF, pairs))
-            i += 3 + 2 * npairs
+            out.append((pc, meta & 0xFFFFFFFF, (meta >> 48) & 0x7F, (meta >> 32) & 0xFF, (meta >> 40) & 0xFF, pairs))
+            i += length
         return out
+
+    def trace_text(self, hart, first_tag=1):
+        """wsp_batch_trace_text: the recorded commits of one hart in the reference's --logfile text."""
+        n = _check(self.L.wsp_batch_trace_text(self.h, hart, first_tag, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        _check(self.L.wsp_batch_trace_text(self.h, hart, first_tag, buf, n + 1))
+        return buf.value.decode()
 
     def snapshot(self):
         _check(self.L.wsp_batch_snapshot(self.h))
@@ -280,6 +298,13 @@ def decode_words(isa, words, host=False):
     fn = L.wsp_decode_words_host if host else L.wsp_decode_words
     _check(fn(isa.encode(), arr, n, out))
     return out
+
+
+def disassemble(inst, xlen=64):
+    """wsp_disassemble: the log's disassembly column for one instruction word."""
+    buf = C.create_string_buffer(256)
+    _check(lib().wsp_disassemble(inst, xlen, buf, 256))
+    return buf.value.decode()
 
 
 def sf_eval(op, rm, a, b, c):

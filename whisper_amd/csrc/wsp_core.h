@@ -37,7 +37,10 @@ enum { ISA_M = 1, ISA_A = 2, ISA_F = 4, ISA_D = 8, ISA_C = 16, ISA_S = 32, ISA_U
        // results in that representation (add -> addw, sll -> sllw, mul -> mulw, div -> divw, ...; slt / sltu / and / or / xor are
        // the same on sign-extended values), addresses wrap at 32 bits, and the CSR file is kept in its RV64 shape behind 32-bit
        // views (csr_peek / csr_store).  Modelled for M / U mode with I M A F D C Zicsr Zicntr: no S mode (Sv32) and no V.
-       ISA_RV32 = 512 };
+       ISA_RV32 = 512,
+       // bit manipulation and conditional zero (bitmanip.cpp, Hart.cpp:14728-14760): --isa ..._zba_zbb_zbs_zbc_zicond
+       ISA_ZBA = 1 << 10, ISA_ZBB = 1 << 11, ISA_ZBS = 1 << 12, ISA_ZICOND = 1 << 13, ISA_ZBC = 1 << 14,
+       ISA_ZB_ANY = ISA_ZBA | ISA_ZBB | ISA_ZBS | ISA_ZICOND | ISA_ZBC };
 // Configuration switches (HartConfig::applyConfig tags, HartConfig.cpp:2085-2958) travel in the same word as the ISA bits: they are
 // fixed for the lifetime of a batch exactly as the ISA is.  All zero = the reference's defaults.
 enum : u32 {
@@ -72,6 +75,7 @@ enum Op : u32 {
   OP_FSGNJ /* imm: 0 j 1 jn 2 jx */, OP_FMINMAX /* imm: 0 min 1 max */, OP_FCMP /* imm: 0 le 1 lt 2 eq */,
   OP_FCVT_F2I /* rs2: 0 w 1 wu 2 l 3 lu */, OP_FCVT_I2F, OP_FCVT_FF /* to F_DBL ? d.s : s.d */,
   OP_FMV_F2X, OP_FCLASS, OP_FMV_X2F,
+  OP_ZB,                                // Zba / Zbb / Zbs / Zbc / Zicond: function (ZB_*) in the rs3 field, a parameter in imm for register forms
   OP_VEC, OP_VLD, OP_VST,               // RVV: OP-V (0x57), vector load, vector store; fields are taken from Rec.raw
   OP_SLOWFETCH,                         // predecoded slot cannot be trusted: fetch + decode from RAM
   OP_STOPCHK,                           // some hart's stop address (wsp_batch_set_stop): never in the inline subset, so the general
@@ -122,6 +126,75 @@ WSP_HD Rec lower_rv32(Rec r)
   }
   r.w0 = (r.w0 & ~0xffu) | n;
   return r;
+}
+
+// OP_ZB functions.  Register forms keep a parameter in Rec.imm (ZB_SHADD: shift | 8 for the .uw forms; ZB_CLZ / CTZ / CPOP / REV8:
+// 1 = the 32-bit form); immediate forms (F_IMM) carry the shift amount / bit index there like the base shifts.
+enum { ZB_SHADD, ZB_SLLIUW, ZB_ANDN, ZB_ORN, ZB_XNOR, ZB_CLZ, ZB_CTZ, ZB_CPOP, ZB_MIN, ZB_MINU, ZB_MAX, ZB_MAXU, ZB_SEXTB, ZB_SEXTH,
+       ZB_ZEXTH, ZB_ROL, ZB_ROR, ZB_ROLW, ZB_RORW, ZB_ORCB, ZB_REV8, ZB_BCLR, ZB_BEXT, ZB_BINV, ZB_BSET, ZB_CZEQZ, ZB_CZNEZ,
+       ZB_CLMUL, ZB_CLMULH, ZB_CLMULR };
+
+// The encodings of those extensions (Decoder.cpp:2490-2557 OP-IMM, 2596-2627 OP-IMM-32, 2771-2864 OP, and the OP-32 block), gated
+// on the extension the reference checks at execute time (bitmanip.cpp: isRvzba / isRvzbb / isRvzbs / isRvzbc, isRvzicond).  An RV32
+// hart gets the 32-bit forms of the operations whose result depends on the register width.
+WSP_HD Rec decode_zb(u32 inst, u32 isa)
+{
+  const u32 op = inst & 0x7f, rd = (inst >> 7) & 31, f3 = (inst >> 12) & 7, rs1 = (inst >> 15) & 31, rs2 = (inst >> 20) & 31, f7 = inst >> 25;
+  const u32 imm12 = inst >> 20, top5 = imm12 >> 7, amt = imm12 & 0x7f;
+  const bool rv32 = (isa & ISA_RV32) != 0, zba = (isa & ISA_ZBA) != 0, zbb = (isa & ISA_ZBB) != 0, zbs = (isa & ISA_ZBS) != 0, zbc = (isa & ISA_ZBC) != 0;
+  const u32 amax = rv32 ? 31 : 63;                                          // checkShiftImmediate (Hart.cpp:11736-11746)
+  auto rr = [&](u32 fn, i32 par = 0) { return mk(OP_ZB, rd, rs1, rs2, par, 0, fn); };
+  auto un = [&](u32 fn, i32 par = 0) { return mk(OP_ZB, rd, rs1, 0, par, 0, fn); };
+  auto ri = [&](u32 fn, u32 imm) { return mk(OP_ZB, rd, rs1, 0, (i32)imm, F_IMM, fn); };
+  const Rec none = mk(OP_ILLEGAL, 0, 0, 0, 0);
+  switch (op) {
+    case 0x33:
+      switch (f7) {
+        case 0x04: if (rv32 && zbb && f3 == 4 && rs2 == 0) return un(ZB_ZEXTH); break;                 // zext.h = pack rd, rs1, x0 (bitmanip.cpp:435-451)
+        case 0x05:
+          if (f3 >= 4) { if (zbb) return rr(f3 == 4 ? ZB_MIN : f3 == 5 ? ZB_MINU : f3 == 6 ? ZB_MAX : ZB_MAXU); }
+          else if (f3 != 0 && zbc) return rr(f3 == 1 ? ZB_CLMUL : f3 == 2 ? ZB_CLMULR : ZB_CLMULH);
+          break;
+        case 0x07: if ((isa & ISA_ZICOND) && (f3 == 5 || f3 == 7)) return rr(f3 == 5 ? ZB_CZEQZ : ZB_CZNEZ); break;
+        case 0x10: if (zba && (f3 == 2 || f3 == 4 || f3 == 6)) return rr(ZB_SHADD, (i32)(f3 >> 1)); break;
+        case 0x14: if (zbs && f3 == 1) return rr(ZB_BSET); break;
+        case 0x20: if (zbb && (f3 == 4 || f3 == 6 || f3 == 7)) return rr(f3 == 4 ? ZB_XNOR : f3 == 6 ? ZB_ORN : ZB_ANDN); break;
+        case 0x24: if (zbs && (f3 == 1 || f3 == 5)) return rr(f3 == 1 ? ZB_BCLR : ZB_BEXT); break;
+        case 0x30: if (zbb && (f3 == 1 || f3 == 5)) return rr(f3 == 1 ? (rv32 ? ZB_ROLW : ZB_ROL) : (rv32 ? ZB_RORW : ZB_ROR)); break;
+        case 0x34: if (zbs && f3 == 1) return rr(ZB_BINV); break;
+        default: break;
+      }
+      break;
+    case 0x13:
+      if (f3 == 1) {
+        if (top5 == 0x0c) {
+          if (!zbb) break;
+          if (amt <= 2) return un(ZB_CLZ + amt, rv32 ? 1 : 0);
+          if (amt == 4 || amt == 5) return un(amt == 4 ? ZB_SEXTB : ZB_SEXTH);
+        } else if (top5 == 5 || top5 == 9 || top5 == 0x0d) {
+          if (zbs && amt <= amax) return ri(top5 == 5 ? ZB_BSET : top5 == 9 ? ZB_BCLR : ZB_BINV, amt);
+        }
+      } else if (f3 == 5) {
+        if (top5 == 5) { if (zbb && amt == 7) return un(ZB_ORCB); }
+        else if (top5 == 9) { if (zbs && amt <= amax) return ri(ZB_BEXT, amt); }
+        else if (top5 == 0x0c) { if (zbb && amt <= amax) return ri(rv32 ? ZB_RORW : ZB_ROR, amt); }
+        else if (imm12 == (rv32 ? 0x698u : 0x6b8u)) { if (zbb) return un(ZB_REV8, rv32 ? 1 : 0); }
+      }
+      break;
+    case 0x1b:                                                               // (RV64 only: decode32 has turned OP-IMM-32 / OP-32 away on RV32)
+      if (f3 == 1 && (imm12 >> 6) == 2) { if (zba) return ri(ZB_SLLIUW, amt & 63); }
+      else if (f3 == 1 && top5 == 0x0c && amt <= 2) { if (zbb) return un(ZB_CLZ + amt, 1); }
+      else if (f3 == 5 && f7 == 0x30) { if (zbb) return ri(ZB_RORW, rs2); }
+      break;
+    case 0x3b:
+      if (f7 == 0x04 && f3 == 0) { if (zba) return rr(ZB_SHADD, 8); }
+      else if (f7 == 0x04 && f3 == 4) { if (zbb && rs2 == 0) return un(ZB_ZEXTH); }                    // zext.h = packw rd, rs1, x0 (bitmanip.cpp:498-524)
+      else if (f7 == 0x10 && (f3 == 2 || f3 == 4 || f3 == 6)) { if (zba) return rr(ZB_SHADD, (i32)((f3 >> 1) | 8)); }
+      else if (f7 == 0x30 && (f3 == 1 || f3 == 5)) { if (zbb) return rr(f3 == 1 ? ZB_ROLW : ZB_RORW); }
+      break;
+    default: break;
+  }
+  return none;
 }
 
 // 32-bit encodings (Decoder.cpp:2232). Extension gating that the reference performs at execute
@@ -248,6 +321,7 @@ WSP_HD Rec decode32(u32 inst, u32 isa)
       break; }
     default: break;
   }
+  if ((isa & ISA_ZB_ANY) && rec_op(r) == OP_ILLEGAL && (op == 0x13 || op == 0x1b || op == 0x33 || op == 0x3b)) r = decode_zb(inst, isa);
   if (rv32) r = lower_rv32(r);
   r.w0 |= F_SIZE4;
   r.raw = inst;
@@ -277,8 +351,8 @@ WSP_HD Rec decode16(u32 c, u32 isa)
         break; }
       case 1: if (fd) r = mk(OP_FLD, rdp, rs1p, 0, (i32)ud); break;
       case 2: r = mk(OP_LW, rdp, rs1p, 0, (i32)uw); break;
-      case 3: if (rv32) r = mk(OP_SW, 0, rs1p, rdp, 0);                    // RV32: the reference hands back its c.sw entry with the offset operand
-              else r = mk(OP_LD, rdp, rs1p, 0, (i32)ud);                   // left at zero for this code point (Decoder.cpp:1491-1502)
+      case 3: if (rv32) { if (ff) r = mk(OP_FLW, rdp, rs1p, 0, (i32)uw); }  // c.flw (Decoder.cpp:1490-1503)
+              else r = mk(OP_LD, rdp, rs1p, 0, (i32)ud);
               break;
       case 5: if (fd) r = mk(OP_FSD, 0, rs1p, rdp, (i32)ud); break;
       case 6: r = mk(OP_SW, 0, rs1p, rdp, (i32)uw); break;
@@ -410,12 +484,14 @@ enum : u32 {
   CH_IREG = 1, CH_FREG = 2, CH_MEM = 4, CH_GEN = 8, CH_SSTATUS = 16, CH_SEPC = 32, CH_SCAUSE = 64, CH_STVAL = 128,
   CH_MSTATUS = 256, CH_MEPC = 512, CH_MCAUSE = 1024, CH_MTVAL = 2048, CH_EXC = 4096,
   CH_VREG = 8192, CH_VL = 16384, CH_VTYPE = 32768,
-  CH_BAIL = 65536                  // Lane<MEM, DRY = true>: the instruction was not completed (and changed nothing)
+  CH_BAIL = 65536,                 // Lane<MEM, DRY = true>: the instruction was not completed (and changed nothing)
+  CH_LDST = 131072                 // commit ring only: a scalar load / store / atomic ran; Step::lva / lpa hold its addresses
 };
 struct Step {
   u32 chg, ireg, freg, gen_csr;
   u32 vreg, vgroup;              // vector group written: first register (operand 0), register count (0: none)
   u64 ival, fval, maddr, mval;
+  u64 lva, lpa;                  // ldStAddr_ / ldStPhysAddr1_ of the log's "[va:pa]" suffix (printTrace.cpp:338-346); kept only while a ring records
 };
 
 // ---------------------------------------------------------------------------------- lane context
@@ -914,13 +990,19 @@ template <class MEM, bool DRY = false> struct Lane {
   }
 
   // Hart::load + readForLoad (Hart.cpp:2302, 2477)
+  // Hart::load / store / amoLoad / lr / sc note the access for the log before anything can fault (Hart.cpp:2306-2309, 2678-2681,
+  // amo.cpp:68-72, 146-150, 277-280), and the physical address once it is known (Hart.cpp:2333, 2710)
+  WSP_HD void note_ldst(u64 va) { if (ring_) { s.lva = va; s.lpa = va; s.chg |= CH_LDST; } }
+  WSP_HD void note_ldst_pa(u64 pa) { if (ring_) s.lpa = pa; }
   WSP_HD bool do_load(u64 va, u32 size, u64 cur_pc, u64& out)
   {
     u64 tval, pa1, pa2;
     va &= amask();
+    note_ldst(va);
     if (paging_unsupported()) return false;
     const u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
     if (c) { take_exception(c, cur_pc, tval, false); return false; }
+    note_ldst_pa(pa1);
     if (pa1 == tohost) { out = 0; return true; }                           // Hart.cpp:2509-2513
     out = mem_read2(pa1, pa2, size);
     return true;
@@ -930,9 +1012,11 @@ template <class MEM, bool DRY = false> struct Lane {
   {
     u64 tval, pa1, pa2;
     va &= amask();
+    note_ldst(va);
     if (paging_unsupported()) return false;
     const u32 c = ldst_addr(va, size, 2, pa1, pa2, tval);
     if (c) { take_exception(c, cur_pc, tval, false); return false; }
+    note_ldst_pa(pa1);
     u64 sv = size == 8 ? val : (val & ((1ULL << (8 * size)) - 1));
     s.chg |= CH_MEM; s.maddr = va; s.mval = sv;                            // the log's m line carries the virtual address (printTrace.cpp:457)
     if (pa1 + size > text_lo && pa1 < text_hi) h.flags |= HF_CODE_DIRTY;    // invalidateDecodeCache (Hart.cpp:7375, 2751-2753)
@@ -1273,12 +1357,14 @@ template <class MEM, bool DRY = false> struct Lane {
   {
     u32 op = rec_op(r), rd = rec_rd(r), size = (r.w0 & F_DBL) ? 8 : 4;
     u64 tval, pa1 = va, pa2;
+    note_ldst(va);
     if (paging_unsupported()) return;
     if (op == OP_LR) {                                                                     // amo.cpp:142-266
       // determineLoadException first (a translation fault wins), then alignment; the trap value is the LR's own address
       u32 c = ldst_addr(va, size, 1, pa1, pa2, tval);
       if (c == 4 || (c == 0 && (va & (size - 1)))) c = 5;                                  // misalAtomicCauseAccessFault_ (amo.cpp:180-181, 188-201)
       if (c) { take_exception(c, cur_pc, va, false); return; }
+      note_ldst_pa(pa1);
       u64 v = mem_read(pa1 - mem_base, size);
       if (size == 4) v = (u64)(i64)(i32)v;
       wx(rd, v);
@@ -1292,6 +1378,7 @@ template <class MEM, bool DRY = false> struct Lane {
       bool had = (h.flags & HF_LR_VALID) && h.lr_addr <= pa1 && pa1 + size <= h.lr_addr + 8;
       h.flags &= ~HF_LR_VALID;                                                             // cancelLr(SC): amo.cpp:403-405
       if (c) { take_exception(c, cur_pc, va, false); return; }
+      note_ldst_pa(pa1);
       if (!had) { wx(rd, 1); return; }
       u64 sv = size == 8 ? b : (b & 0xffffffffULL);
       s.chg |= CH_MEM; s.maddr = va; s.mval = sv;
@@ -1303,6 +1390,7 @@ template <class MEM, bool DRY = false> struct Lane {
     {                                                                                      // validateAmoAddr (amo.cpp:28-56): misaligned first
       u32 c = (va & (size - 1)) ? 7u : ldst_addr(va, size, 2, pa1, pa2, tval);
       if (c) { take_exception(c, cur_pc, va, false); return; }
+      note_ldst_pa(pa1);
     }
     u64 ld = mem_read(pa1 - mem_base, size), res;
     if (size == 4) ld = (u64)(i64)(i32)ld;
@@ -2991,6 +3079,54 @@ template <class MEM, bool DRY = false> struct Lane {
   WSP_HD void exec_vector_ldst(const Rec& r, u64 a, u64 b, u64 cur_pc, bool store) { exec_vector_ldst_body(r, a, b, cur_pc, store); }
 #endif
 
+  // ---- Zba / Zbb / Zbs / Zbc / Zicond (bitmanip.cpp:10-1110, Hart.cpp:14728-14760).  a = x[rs1]; b = x[rs2] or the immediate;
+  // par = the decoder's parameter (see ZB_*).  An RV32 hart's operands arrive sign-extended and wx() brings the result back into
+  // that shape, so only the operations that look at the upper half have a 32-bit form.
+  WSP_HD u64 exec_zb(u32 fn, i32 par, u64 a, u64 b) const
+  {
+    const bool w32 = rv32();
+    const u32 aw = (u32)a, sm = w32 ? 31u : 63u, ix = (u32)b & sm, s5 = (u32)b & 31;
+    switch (fn) {
+      case ZB_SHADD: return (((par & 8) ? (u64)aw : a) << (par & 3)) + b;
+      case ZB_SLLIUW: return (u64)aw << (b & 63);
+      case ZB_ANDN: return a & ~b;
+      case ZB_ORN: return a | ~b;
+      case ZB_XNOR: return a ^ ~b;
+      case ZB_CLZ: if (par) { u32 n = 0; while (n < 32 && !((aw << n) & 0x80000000u)) ++n; return n; }
+                   else { u32 n = 0; while (n < 64 && !((a << n) >> 63)) ++n; return n; }
+      case ZB_CTZ: if (par) { u32 n = 0; while (n < 32 && !((aw >> n) & 1)) ++n; return n; }
+                   else { u32 n = 0; while (n < 64 && !((a >> n) & 1)) ++n; return n; }
+      case ZB_CPOP: { u64 v = par ? (u64)aw : a; v = v - ((v >> 1) & 0x5555555555555555ULL); v = (v & 0x3333333333333333ULL) + ((v >> 2) & 0x3333333333333333ULL);
+                      v = (v + (v >> 4)) & 0x0f0f0f0f0f0f0f0fULL; return (v * 0x0101010101010101ULL) >> 56; }
+      case ZB_MIN: return (i64)a < (i64)b ? a : b;
+      case ZB_MINU: return a < b ? a : b;
+      case ZB_MAX: return (i64)a > (i64)b ? a : b;
+      case ZB_MAXU: return a > b ? a : b;
+      case ZB_SEXTB: return (u64)(i64)(int8_t)a;
+      case ZB_SEXTH: return (u64)(i64)(int16_t)a;
+      case ZB_ZEXTH: return a & 0xffff;
+      case ZB_ROL: return (a << ix) | (a >> ((64 - ix) & 63));
+      case ZB_ROR: return (a >> ix) | (a << ((64 - ix) & 63));
+      case ZB_ROLW: return (u64)(i64)(i32)((aw << s5) | (aw >> ((32 - s5) & 31)));
+      case ZB_RORW: return (u64)(i64)(i32)((aw >> s5) | (aw << ((32 - s5) & 31)));
+      case ZB_ORCB: { u64 r = 0; for (u32 i = 0; i < 64; i += 8) if ((a >> i) & 0xff) r |= 0xffULL << i; return r; }
+      case ZB_REV8: { u64 r = 0; const u32 n = par ? 4 : 8; for (u32 i = 0; i < n; ++i) r |= ((a >> (8 * i)) & 0xff) << (8 * (n - 1 - i)); return r; }
+      case ZB_BCLR: return a & ~(1ULL << ix);
+      case ZB_BEXT: return ((w32 ? (u64)aw : a) >> ix) & 1;
+      case ZB_BINV: return a ^ (1ULL << ix);
+      case ZB_BSET: return a | (1ULL << ix);
+      case ZB_CZEQZ: return b == 0 ? 0 : a;
+      case ZB_CZNEZ: return b != 0 ? 0 : a;
+      default: {                                                             // carry-less multiply: low half, high half, reversed
+        const u32 n = w32 ? 32 : 64; const u64 ua = w32 ? (u64)aw : a, ub = w32 ? (u64)(u32)b : b; u64 r = 0;
+        for (u32 i = 0; i < n; ++i) {
+          if (!((ub >> i) & 1)) continue;
+          if (fn == ZB_CLMUL) r ^= ua << i; else if (fn == ZB_CLMULH) { if (i) r ^= ua >> (n - i); } else r ^= ua >> (n - i - 1);
+        }
+        return r; }
+    }
+  }
+
   // ---- one decoded instruction. `op` is passed separately so the GPU kernel can hand in a
   // wave-uniform copy (scalar branch over the switch); a = x[rs1], b = second operand.
   WSP_HD void exec(u32 op, const Rec& r, u64 a, u64 b, u64 cur_pc)
@@ -3034,6 +3170,7 @@ template <class MEM, bool DRY = false> struct Lane {
       case OP_DIVUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? ~0u : x / y)); break; }
       case OP_REMW: { i32 x = (i32)a, y = (i32)b; wx(rd, (u64)(i64)(y == 0 ? x : (x == INT32_MIN && y == -1) ? 0 : x % y)); break; }
       case OP_REMUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? x : x % y)); break; }
+      case OP_ZB: wx(rd, exec_zb(rec_rs3(r), (r.w0 & F_IMM) ? 0 : r.imm, a, b)); break;
       case OP_AUIPC: wx(rd, cur_pc + (u64)(i64)r.imm); break;
       case OP_JAL: {
         u64 t = (cur_pc + (u64)(i64)r.imm) & amask();
@@ -3218,6 +3355,7 @@ template <class MEM, bool DRY = false> struct Lane {
     u64 t = h.thash;
     u64* const rg = ring_; u32 pos = rg ? *ring_pos_ : 0; const u32 cap = ring_cap, meta_at = pos + 1, kinds_at = pos + 2; u32 np = 0; u64 kinds = 0;
 #define WSP_RING(w) do { if (rg && pos < cap) rg[pos++] = (w); } while (0)
+#define WSP_RING2(w) do { if (pos < cap) rg[pos++] = (w); } while (0)
 #define WSP_PAIR(kind, id, v) do { const u64 id_ = (id), v_ = (v); t = fold(t, id_ ^ ((u64)(kind) << 60)); t = fold(t, v_); \
                                    WSP_RING(id_); WSP_RING(v_); if (np < 16) kinds |= (u64)(kind) << (4 * np); ++np; } while (0)
     const u64 meta = (u64)raw | ((u64)priv0 << 32) | ((u64)trap << 40) | ((u64)size << 48);
@@ -3249,8 +3387,17 @@ template <class MEM, bool DRY = false> struct Lane {
     if (c & CH_VTYPE) WSP_PAIR(5, C_VTYPE, m.cold(CI_VTYPE));
     if (np == 0) WSP_PAIR(1, 0, 0);                                                               // printTrace.cpp:491-493: an "r x0 0" line
 #undef WSP_PAIR
+    if (rg) {
+      // ring only (not part of the digest): the load / store address pair, then the bytes of every vector register reported
+      // above (vlenb / 8 words each, in pair order) - what the text log prints beside the record
+      const bool ldst = (c & CH_LDST) != 0;
+      if (ldst) { WSP_RING2(s.lva); WSP_RING2(s.lpa); }
+      for (u32 g = 0; g < s.vgroup; ++g) for (u32 w = 0; w < vlenb / 8; ++w) WSP_RING2(m.vld(((s.vreg + g) & 31) * vlenb + 8 * w, 3));
+      if (kinds_at < pos) { rg[meta_at] |= ((u64)np << 56) | ((u64)ldst << 55); rg[kinds_at] = kinds; }
+      *ring_pos_ = pos;
+    }
 #undef WSP_RING
-    if (rg) { if (kinds_at < pos) { rg[meta_at] |= (u64)np << 56; rg[kinds_at] = kinds; } *ring_pos_ = pos; }
+#undef WSP_RING2
     h.thash = t;
   }
 };

@@ -27,6 +27,7 @@ __device__ unsigned long long wsp_prof[16];
 #endif
 #include "wsp_core.h"
 #include "wsp_config.h"
+#include "wsp_disasm.h"
 #include "../../include/whisper_amd.h"
 
 using namespace wsp;
@@ -204,7 +205,7 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
   u32 k = 0;
   const unsigned long long pt1 = WSP_PROF_T();
   do {
-    L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+    L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
     L.template cold_step<true>(recs);
     stop_at = wsp_stop_at(hr.slice_end, max_exec, max_ret, L.h.exec, L.h.retired);
   } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < stop_at &&
@@ -231,7 +232,7 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
-  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
   Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
   const u32 op = w0 & 0xff;
   WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0;
@@ -301,7 +302,7 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
     bool done = false;
 #define WSP_VW_ONE(W0, IMM, RAW) do {                                                                                             \
       L.h.pc = pc + 4;                                                                                                            \
-      L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; \
+      L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0; \
       Rec rec; rec.w0 = (W0); rec.imm = (IMM); rec.pad = 0; rec.raw = (RAW);                                                      \
       const u32 op = rec.w0 & 0xff;                                                                                               \
       const u64 a = L.m.rx(rec_rs1(rec)), b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : L.m.rx(rec_rs2(rec));                         \
@@ -1053,6 +1054,8 @@ static int parse_isa(const char* isa, u32* out, std::string* why)
     if (e == "zicsr" || e == "zifencei" || e.empty()) {}
     else if (e == "zicntr") f |= ISA_ZICNTR;
     else if (e == "zca") f |= ISA_C;
+    else if (e == "zba") f |= ISA_ZBA; else if (e == "zbb") f |= ISA_ZBB; else if (e == "zbs") f |= ISA_ZBS;
+    else if (e == "zbc") f |= ISA_ZBC; else if (e == "zicond") f |= ISA_ZICOND;
     else { if (why) *why = "ISA extension '" + e + "' is not supported"; return WSP_EUNSUPPORTED; }
     us = nx;
   }
@@ -1707,6 +1710,24 @@ extern "C" int wsp_batch_symbol(wsp_batch* b, uint32_t hart, const char* name, u
   return WSP_OK;
 }
 
+// Harts of [lo, hi) that ended on an instruction / retired count limit or on their stop address become runnable again.
+__global__ void wsp_resume_kernel(DevState d, u32 lo, u32 hi)
+{
+  const u32 h = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= hi) return;
+  u32* st = d.hot32 + (size_t)H32_STATUS * d.S + slot_of(d, h);
+  if (*st == ST_STOP_LIMIT || *st == ST_STOP_ADDR) *st = ST_RUNNING;
+}
+
+extern "C" int wsp_batch_resume(wsp_batch* b, uint32_t lo, uint32_t hi)
+{
+  int rc = check_range(b, lo, hi); if (rc) return rc;
+  HIPOK(hipSetDevice(b->device));
+  hipLaunchKernelGGL(wsp_resume_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, b->stream, b->d, lo, hi);
+  HIPOK(hipGetLastError()); HIPOK(hipStreamSynchronize(b->stream));
+  return WSP_OK;
+}
+
 extern "C" int wsp_batch_set_stop(wsp_batch* b, uint32_t lo, uint32_t hi, uint64_t tohost, uint64_t max_inst, uint64_t max_ret, uint64_t stop_pc)
 {
   int rc = check_range(b, lo, hi); if (rc) return rc;
@@ -1762,7 +1783,13 @@ extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
   DevState& d = b->d; u32 s = slot_of(d, hart); size_t S = d.S;
   u64 v = 0;
   switch (res) {
-    case WSP_RES_PC: HIPOK(hipMemcpy(&v, d.hot64 + H64_PC * S + s, 8, hipMemcpyDeviceToHost)); break;
+    case WSP_RES_PC: {   // idx 0: pc; 1: executed-instruction count (the log's tag, snapshot "po"); 2: retired-instruction count ("pr"); 3: privilege mode ("pm")
+      if (idx > 3) return fail(WSP_ERANGE, "pc resource index");
+      if (idx == 3) { u32 pm; HIPOK(hipMemcpy(&pm, d.hot32 + H32_PRIV * S + s, 4, hipMemcpyDeviceToHost)); v = pm; memcpy(val, &v, std::min<size_t>(size, 8)); return WSP_OK; }
+      const u32 row = idx == 0 ? H64_PC : idx == 1 ? H64_EXEC : H64_RETIRED;
+      HIPOK(hipMemcpy(&v, d.hot64 + row * S + s, 8, hipMemcpyDeviceToHost));
+      if (idx) { memcpy(val, &v, std::min<size_t>(size, 8)); return WSP_OK; }
+      break; }
     case WSP_RES_X: if (idx > 31) return fail(WSP_ERANGE, "x register"); HIPOK(hipMemcpy(&v, d.x + idx * S + s, 8, hipMemcpyDeviceToHost)); break;
     case WSP_RES_F: if (idx > 31) return fail(WSP_ERANGE, "f register"); HIPOK(hipMemcpy(&v, d.f + idx * S + s, 8, hipMemcpyDeviceToHost)); break;
     case WSP_RES_CSR: {
@@ -1813,7 +1840,15 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
     if (res == WSP_RES_CSR && (idx == C_MCAUSE || idx == C_SCAUSE)) v = (v & 0x7fffffffULL) | ((v >> 31) << 63);
   }
   switch (res) {
-    case WSP_RES_PC: v &= ~1ULL; HIPOK(hipMemcpy(d.hot64 + H64_PC * S + s, &v, 8, hipMemcpyHostToDevice)); break;
+    case WSP_RES_PC: {   // idx as in wsp_batch_peek (the counters are restored by snapshot import)
+      if (idx > 3) return fail(WSP_ERANGE, "pc resource index");
+      if (idx == 0) v &= ~1ULL; else memcpy(&v, val, std::min<size_t>(size, 8));
+      if (idx == 3) {
+        if (v != PRV_M && !(v == PRV_U && (d.isa & ISA_U)) && !(v == PRV_S && (d.isa & ISA_S))) return fail(WSP_EINVAL, "privilege mode not in the ISA");
+        const u32 pm = (u32)v; HIPOK(hipMemcpy(d.hot32 + H32_PRIV * S + s, &pm, 4, hipMemcpyHostToDevice)); break;
+      }
+      const u32 row = idx == 0 ? H64_PC : idx == 1 ? H64_EXEC : H64_RETIRED;
+      HIPOK(hipMemcpy(d.hot64 + row * S + s, &v, 8, hipMemcpyHostToDevice)); break; }
     case WSP_RES_X: if (idx > 31) return fail(WSP_ERANGE, "x register"); if (idx) HIPOK(hipMemcpy(d.x + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
     case WSP_RES_F: if (idx > 31) return fail(WSP_ERANGE, "f register"); HIPOK(hipMemcpy(d.f + idx * S + s, &v, 8, hipMemcpyHostToDevice)); break;
     case WSP_RES_CSR: {
@@ -2020,6 +2055,90 @@ extern "C" int64_t wsp_batch_trace_read(wsp_batch* b, uint32_t hart, uint64_t* w
   if (n > cap) return fail(WSP_ERANGE, "trace buffer too small");
   if (n) HIPOK(hipMemcpy(words, d.ring + (size_t)hart * d.ring_cap, (size_t)n * 8, hipMemcpyDeviceToHost));
   return (int64_t)n;
+}
+
+// ---- the commit log as text (printTrace.cpp:302-517).  One record of the ring: pc, meta (instruction | priv << 32 | trap << 40 |
+// size << 48 | has-ld/st-address << 55 | pairs << 56), kinds (4 bits per pair), the pairs, the ld/st address pair if flagged, then
+// vlenb / 8 words for every vector register pair.  Lines in the reference's layouts for the two widths (printTrace.cpp:56-209).
+static void format_record(std::string& out, const u64* w, u64 tag, u32 vlenb, bool rv32, bool has_d, u32 np, bool ldst)
+{
+  const u64 pc = w[0], meta = w[1], kinds = w[2];
+  const u32 inst = (u32)meta, priv = (u32)(meta >> 32) & 0xff, trap = (u32)(meta >> 40) & 0xff, size = (u32)(meta >> 48) & 0x7f;
+  const u64* pairs = w + 3;
+  const u64* extra = pairs + 2 * np;
+  std::string text = wspdis::disassemble(size == 4 ? inst : (inst & 0xffff), !rv32);
+  char buf[256];
+  if (ldst) {
+    if (extra[0] == extra[1]) snprintf(buf, sizeof buf, " [0x%llx]", (unsigned long long)extra[0]);
+    else snprintf(buf, sizeof buf, " [0x%llx:0x%llx]", (unsigned long long)extra[0], (unsigned long long)extra[1]);
+    text += buf; extra += 2;
+  }
+  if (trap == 2) text += " (interrupted)"; else if (trap == 1) text += " (exception)";
+  char op[16];
+  if (size == 4) snprintf(op, sizeof op, "%08x", inst); else snprintf(op, sizeof op, "%04x", inst & 0xffff);
+  const char* pm = priv == 3 ? "M" : priv == 1 ? "S" : "U";
+  char head[96];
+  if (rv32) snprintf(head, sizeof head, "#%llu %d %2s %08x %8s ", (unsigned long long)tag, 0, pm, (u32)pc, op);
+  else snprintf(head, sizeof head, "#%llu %d %2s %016llx %8s ", (unsigned long long)tag, 0, pm, (unsigned long long)pc, op);
+  bool pending = false;
+  for (u32 k = 0; k < np; ++k) {
+    const u32 kind = (u32)(kinds >> (4 * k)) & 15;
+    const u64 key = pairs[2 * k], val = pairs[2 * k + 1];
+    if (pending) out += kind == 3 ? " +\n" : "  +\n";
+    out += head;
+    if (kind == 3) {                                                     // formatVecInstTrace: the register's bytes, most significant first
+      snprintf(buf, sizeof buf, "v %02x ", (u32)key); out += buf;
+      for (u32 i = 0; i < vlenb; ++i) { const u32 bi = vlenb - 1 - i; snprintf(buf, sizeof buf, "%02x", (u32)(extra[bi >> 3] >> (8 * (bi & 7))) & 0xff); out += buf; }
+      out += ' '; out += text;
+      extra += vlenb / 8;
+    } else if (kind == 2) {                                              // formatFpInstTrace
+      if (rv32) { if (has_d) snprintf(buf, sizeof buf, "f %02x %016llx  ", (u32)key, (unsigned long long)val); else snprintf(buf, sizeof buf, "f %02x         %08x  ", (u32)key, (u32)val); }
+      else { if (has_d) snprintf(buf, sizeof buf, "f %016llx %016llx ", (unsigned long long)key, (unsigned long long)val); else snprintf(buf, sizeof buf, "f %016llx         %08x ", (unsigned long long)key, (u32)val); }
+      out += buf; out += text;
+    } else {
+      const char c = kind == 1 ? 'r' : kind == 4 ? 'm' : 'c';
+      if (!rv32) snprintf(buf, sizeof buf, "%c %016llx %016llx ", c, (unsigned long long)key, (unsigned long long)val);
+      else if (c == 'r') snprintf(buf, sizeof buf, "r %02x         %08x  ", (u32)key, (u32)val);
+      else if (c == 'c' && (key >> 16) == 0) snprintf(buf, sizeof buf, "c %04x       %08x  ", (u32)key, (u32)val);
+      else snprintf(buf, sizeof buf, "%c %08x   %08x  ", c, (u32)key, (u32)val);
+      out += buf; out += text;
+    }
+    pending = true;
+  }
+  out += '\n';
+}
+
+extern "C" int64_t wsp_batch_trace_text(wsp_batch* b, uint32_t hart, uint64_t first_tag, char* text, size_t cap)
+{
+  if (!b) return fail(WSP_EINVAL, "null batch");
+  const DevState& d = b->d;
+  if (!d.ring) return fail(WSP_EINVAL, "trace ring is off");
+  std::vector<u64> w(d.ring_cap);
+  const int64_t n = wsp_batch_trace_read(b, hart, w.data(), w.size());
+  if (n < 0) return n;
+  const bool rv32 = (d.isa & ISA_RV32) != 0, has_d = (d.isa & ISA_D) != 0;
+  std::string out;
+  size_t i = 0; u64 tag = first_tag;
+  while (i + 3 <= (size_t)n) {
+    const u64 meta = w[i + 1], kinds = w[i + 2];
+    const u32 np = (u32)(meta >> 56); const bool ldst = (meta >> 55) & 1;
+    u32 nv = 0;
+    for (u32 k = 0; k < np && k < 16; ++k) nv += ((kinds >> (4 * k)) & 15) == 3;
+    const size_t len = 3 + 2 * (size_t)np + (ldst ? 2 : 0) + (size_t)nv * (d.vlenb / 8);
+    if (np == 0 || np > 16 || i + len > (size_t)n) break;                  // a record cut off by the end of the ring is dropped
+    format_record(out, w.data() + i, tag++, d.vlenb, rv32, has_d, np, ldst);
+    i += len;
+  }
+  if (text && cap) { const size_t m = std::min(cap - 1, out.size()); memcpy(text, out.data(), m); text[m] = 0; }
+  return (int64_t)out.size();
+}
+
+extern "C" int wsp_disassemble(uint32_t inst, uint32_t xlen, char* text, size_t cap)
+{
+  if (!text || !cap) return fail(WSP_EINVAL, "null buffer");
+  const std::string s = wspdis::disassemble(inst, xlen != 32);
+  snprintf(text, cap, "%s", s.c_str());
+  return (int)s.size();
 }
 
 extern "C" int64_t wsp_batch_signature(wsp_batch* b, uint32_t hart, uint32_t* words, size_t cap)

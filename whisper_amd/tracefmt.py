@@ -3,9 +3,9 @@
 
     #<tag> <hart>  <priv> <pc:016x> <inst:08x> <kind> <key:016x> <value:016x> <disassembly>[  +]
 
-one line per changed resource, all but the last of a record ending in "  +".  The library carries no disassembler: pass
-`disasm` (a callable inst -> str) to fill the last column, otherwise it is left empty.  Vector-register lines carry the
-digest of the register the ring holds, not its bytes (read those with Batch.peek(hart, RES_V, reg))."""
+one line per changed resource, all but the last of a record ending in "  +".  Kept for callers that post-process the records
+in Python; the product formatter is the library's own wsp_batch_trace_text (Batch.trace_text), which prints the complete
+reference text: disassembly column (wsp_disassemble), load / store address suffixes, vector register bytes, both widths."""
 
 KIND_CHAR = {1: "r", 2: "f", 3: "v", 4: "m", 5: "c"}
 PRIV_CHAR = {0: "U", 1: "S", 3: "M"}

@@ -1633,3 +1633,97 @@ def _exit_tohost32(a: Asm, tohost_addr, value=1, tmp1=5, tmp2=6):
     a.li(tmp2, value)
     a.sw(tmp2, 0, tmp1)
     a.jal(0, a.pc)
+
+
+# ------------------------------------------------------------------------------------------ Zba / Zbb / Zbs / Zbc / Zicond
+# name -> (major opcode, funct3, funct7 or 12-bit immediate pattern, form): "r" three registers, "u" unary (imm12 fixed),
+# "s" shift-immediate (imm12 = pattern | shamt), "w5" 5-bit shift in the rs2 field
+ZB_ENC = {
+    "sh1add": (0x33, 2, 0x10, "r"), "sh2add": (0x33, 4, 0x10, "r"), "sh3add": (0x33, 6, 0x10, "r"),
+    "add.uw": (0x3B, 0, 0x04, "r"), "sh1add.uw": (0x3B, 2, 0x10, "r"), "sh2add.uw": (0x3B, 4, 0x10, "r"), "sh3add.uw": (0x3B, 6, 0x10, "r"),
+    "slli.uw": (0x1B, 1, 0x080, "s"),
+    "andn": (0x33, 7, 0x20, "r"), "orn": (0x33, 6, 0x20, "r"), "xnor": (0x33, 4, 0x20, "r"),
+    "clz": (0x13, 1, 0x600, "u"), "ctz": (0x13, 1, 0x601, "u"), "cpop": (0x13, 1, 0x602, "u"),
+    "clzw": (0x1B, 1, 0x600, "u"), "ctzw": (0x1B, 1, 0x601, "u"), "cpopw": (0x1B, 1, 0x602, "u"),
+    "max": (0x33, 6, 0x05, "r"), "maxu": (0x33, 7, 0x05, "r"), "min": (0x33, 4, 0x05, "r"), "minu": (0x33, 5, 0x05, "r"),
+    "sext.b": (0x13, 1, 0x604, "u"), "sext.h": (0x13, 1, 0x605, "u"), "zext.h": (0x3B, 4, 0x080, "u"), "zext.h32": (0x33, 4, 0x080, "u"),
+    "rol": (0x33, 1, 0x30, "r"), "ror": (0x33, 5, 0x30, "r"), "rori": (0x13, 5, 0x600, "s"),
+    "rolw": (0x3B, 1, 0x30, "r"), "rorw": (0x3B, 5, 0x30, "r"), "roriw": (0x1B, 5, 0x600, "w5"),
+    "orc.b": (0x13, 5, 0x287, "u"), "rev8": (0x13, 5, 0x6B8, "u"), "rev8_32": (0x13, 5, 0x698, "u"),
+    "bclr": (0x33, 1, 0x24, "r"), "bclri": (0x13, 1, 0x480, "s"), "bext": (0x33, 5, 0x24, "r"), "bexti": (0x13, 5, 0x480, "s"),
+    "binv": (0x33, 1, 0x34, "r"), "binvi": (0x13, 1, 0x680, "s"), "bset": (0x33, 1, 0x14, "r"), "bseti": (0x13, 1, 0x280, "s"),
+    "czero.eqz": (0x33, 5, 0x07, "r"), "czero.nez": (0x33, 7, 0x07, "r"),
+    "clmul": (0x33, 1, 0x05, "r"), "clmulh": (0x33, 3, 0x05, "r"), "clmulr": (0x33, 2, 0x05, "r"),
+}
+
+
+def zb_word(name, rd, rs1, rs2_or_shamt=0):
+    op, f3, pat, form = ZB_ENC[name]
+    if form == "r":
+        return Asm.enc_r(op, f3, pat, rd, rs1, rs2_or_shamt)
+    imm = pat if form == "u" else pat | rs2_or_shamt
+    return (imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op
+
+
+def bitmanip_program(seed: int, n: int = 400, xlen: int = 64, ext: str = "zba_zbb_zbs_zbc_zicond") -> Program:
+    """Random Zba / Zbb / Zbs / Zbc / Zicond code (bitmanip.cpp, Hart.cpp:14728-14760) on corner-heavy operands, both widths: every
+    mnemonic, shift amounts beyond the register width (must trap), the RV64-only forms on RV32 and the other width's rev8 / zext.h
+    code points, neighbouring encodings of Zbkb / Zbkx that stay illegal, and - with `ext` naming fewer extensions - the
+    instructions of the ones that are off.  A handler skips whatever traps; results are folded into memory as they are made."""
+    rng = random.Random(0xB17 * 1000003 + seed * 7 + xlen)
+    data_base = BASE + 0x3000
+    rv32 = xlen == 32
+    isa = ("rv32imac" if rv32 else "rv64imac") + "_zicsr_" + ext
+    a = Asm(BASE, xlen=xlen)
+    d = Asm(data_base, xlen=xlen)
+    d.label("tohost"); d.dword(0)
+    d.label("fromhost"); d.dword(0)
+    d.label("data")
+    d.zeros(2048)
+    S = d.symbols
+    H1, H2, PTR = 30, 31, 29
+    a.label("_start")
+    a.j("init")
+    a.align(4)
+    a.label("handler")
+    a.csrr(H1, CSR["mepc"]); a.addi(H1, H1, 4); a.csrw(CSR["mepc"], H1); a.mret()
+    a.label("init")
+    a.la(5, "handler"); a.csrw(CSR["mtvec"], 5)
+    m = (1 << xlen) - 1
+    corner = [0, 1, 2, m, m >> 1, 1 << (xlen - 1), 0x80, 0xFF, 0x8000, 0xFFFF, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x100000000 & m,
+              0x0001000100010001 & m, 0x8040201008040201 & m, 0x00FF00FF00FF00FF & m, xlen - 1, xlen, xlen + 1, 31, 32, 33, 63, 64, 65]
+    regs = list(range(0, 29))
+    for r in range(1, 29):
+        a.li(r, rng.choice(corner) if rng.random() < 0.6 else rng.getrandbits(xlen))
+    a.li(PTR, S["data"])
+    names = sorted(ZB_ENC)
+    slot = 0
+    for i in range(n):
+        rd, r1, r2 = rng.choice(regs), rng.choice(regs), rng.choice(regs)
+        k = rng.random()
+        if k < 0.78:
+            name = rng.choice(names)
+            form = ZB_ENC[name][3]
+            x = r2 if form == "r" else rng.randrange(32) if form == "w5" else rng.choice([rng.randrange(xlen), rng.randrange(64), rng.randrange(128)])
+            w = zb_word(name, rd, r1, x)
+            if form == "u" and rng.random() < 0.05:
+                w |= rng.randrange(1, 32) << 20 if name.startswith("zext") else 0           # pack / packw with rs2 != 0: Zbkb, illegal
+            a.word(w)
+        elif k < 0.84:                                       # neighbours: Zbkb (brev8, zip, unzip, packh), Zbkx (xperm), unknown funct7
+            a.word(rng.choice([0x68705013 | (rd << 7) | (r1 << 15), 0x08F01013 | (rd << 7) | (r1 << 15), 0x08F05013 | (rd << 7) | (r1 << 15),
+                               Asm.enc_r(0x33, 7, 0x04, rd, r1, r2), Asm.enc_r(0x33, 2, 0x14, rd, r1, r2), Asm.enc_r(0x33, 4, 0x14, rd, r1, r2),
+                               Asm.enc_r(0x33, rng.randrange(8), rng.choice([0x02, 0x06, 0x08, 0x11, 0x21, 0x25, 0x31, 0x35, 0x3F]), rd, r1, r2),
+                               (rng.choice([0x603, 0x606, 0x607, 0x284, 0x288, 0x6B9, 0x699, 0x4C0 if rv32 else 0x4FF]) << 20) | (r1 << 15) | (rng.choice([1, 5]) << 12) | (rd << 7) | 0x13]))
+        elif k < 0.92:
+            getattr(a, rng.choice(["add", "sub", "xor", "sll", "srl", "sra"]))(rd, r1, r2)
+        else:
+            src = rng.choice(regs)
+            (a.sw if rv32 else a.sd)(src, (slot % 256) * 8, PTR); slot += 1
+    for r in range(1, 29):
+        (a.sw if rv32 else a.sd)(r, 0, PTR); a.addi(PTR, PTR, 8)
+    if rv32:
+        _exit_tohost32(a, S["tohost"])
+    else:
+        _exit_tohost(a, S["tohost"])
+    assert a.here() < data_base
+    return _finish(a, f"zb{xlen}-{seed}", isa, d, mem_size=1 << 15, max_inst=40000, meta=dict(seed=seed))
