@@ -312,15 +312,15 @@ static int csr_class(const rvo_hart* h, unsigned num)
     if (num == 0x310 || num == 0x31A || num == 0xB80 || num == 0xB82) return 1;          /* mstatush menvcfgh mcycleh minstreth */
     if (num >= 0xC80 && num <= 0xC82) return ext(h, RVO_ISA_ZICNTR) ? 1 : 0;             /* cycleh timeh instreth */
     if (num >= 0x3A0 && num <= 0x3EF) return 1;
-    if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || num == 0x7C7 || (num >= 0xB83 && num <= 0xB9F)) return -1;   /* mhpmevent<n>h mseccfgh mhpmcounter<n>h */
+    if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || (num >= 0xB83 && num <= 0xB9F)) return 1;      /* mhpmevent<n>h mseccfgh mhpmcounter<n>h: hardwired zero */
   }
   /* Implemented in the reference's default configuration but not modelled here. */
   if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   /* pmpcfg (even only on rv64), pmpaddr0..63 */
-  if (num >= 0xB03 && num <= 0xB1F) return -1;      /* mhpmcounter3..31 */
-  if (num >= 0x323 && num <= 0x33F) return -1;      /* mhpmevent3..31 */
-  if (num == 0x747) return -1;                      /* mseccfg */
-  if (num == 0x7B0 || num == 0x7B1 || num == 0x7B2 || num == 0x7B3) return -1; /* dcsr dpc dscratch */
-  return 0;
+  /* mhpmcounter3..31, mhpmevent3..31, mseccfg: present with all-zero write masks while no performance counters and no Smepmp
+   * are configured (CsRegs.cpp:4810, 4848-4866): read zero, a write changes nothing (and is logged like any other) */
+  if ((num >= 0xB03 && num <= 0xB1F) || (num >= 0x323 && num <= 0x33F) || num == 0x747) return 1;
+  if (num == 0x7C7) return -1;                      /* c_matp: a custom register of the reference, not modelled */
+  return 0;                                         /* dcsr / dpc / dscratch: debug mode only (CsRegs.cpp:1252): illegal here */
 }
 
 static u64 csr_peek64(const rvo_hart* h, unsigned num)

@@ -24,10 +24,13 @@ if R is not None:
 # every CSR the oracle/device model but the PMP file (own test below); satp!=bare/vector are "unsupported" stops
 MODELLED = [0x300, 0x301, 0x302, 0x303, 0x304, 0x305, 0x306, 0x30A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x344,
             0x100, 0x104, 0x105, 0x106, 0x10A, 0x140, 0x141, 0x142, 0x143, 0x144, 0x180,
-            0x001, 0x002, 0x003, 0xB00, 0xB02, 0xF11, 0xF12, 0xF13, 0xF14, 0xC00, 0xC01, 0xC02]
+            0x001, 0x002, 0x003, 0xB00, 0xB02, 0xF11, 0xF12, 0xF13, 0xF14, 0xC00, 0xC01, 0xC02,
+            # hardwired zero in the default configuration: mhpmevent3..31, mhpmcounter3..31, mseccfg; debug-mode only: dcsr, dpc
+            0x323, 0x330, 0x33F, 0xB03, 0xB10, 0xB1F, 0x747]
 # written through csrrw in the read-back test (counters are compensated at Hart level, Hart.cpp:13251-13360; satp: below)
 WRITABLE = [0x300, 0x302, 0x303, 0x304, 0x305, 0x306, 0x30A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x344,
-            0x100, 0x104, 0x105, 0x106, 0x10A, 0x140, 0x141, 0x142, 0x143, 0x144, 0x001, 0x002, 0x003]
+            0x100, 0x104, 0x105, 0x106, 0x10A, 0x140, 0x141, 0x142, 0x143, 0x144, 0x001, 0x002, 0x003,
+            0x323, 0x33F, 0xB03, 0xB1F, 0x747]
 CONFIGS = {"rv64imafdc_zicsr": (0, 0, 1, 1, 0), "rv64imafdcsu_zicsr": (1, 1, 1, 1, 0), "rv64imacu_zicsr": (0, 1, 0, 1, 0),
            "rv64imafdsu_zicsr_zicntr": (1, 1, 1, 0, 1)}
 M64 = (1 << 64) - 1

@@ -121,8 +121,10 @@ def test_compressed_expansion_matches_reference(rv64):
 
 
 CSR32 = [0x300, 0x301, 0x304, 0x305, 0x306, 0x30A, 0x310, 0x31A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x344, 0x001, 0x002, 0x003,
-         0xB00, 0xB02, 0xB80, 0xB82, 0xC00, 0xC01, 0xC02, 0xC80, 0xC81, 0xC82, 0xF11, 0xF12, 0xF13, 0xF14] + list(range(0x3A0, 0x3F0))
-CSR32_W = [0x300, 0x304, 0x305, 0x306, 0x30A, 0x310, 0x31A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x001, 0x002, 0x003]
+         0xB00, 0xB02, 0xB80, 0xB82, 0xC00, 0xC01, 0xC02, 0xC80, 0xC81, 0xC82, 0xF11, 0xF12, 0xF13, 0xF14] + list(range(0x3A0, 0x3F0)) + \
+        [0x323, 0x33F, 0x723, 0x73F, 0xB03, 0xB1F, 0xB83, 0xB9F, 0x747, 0x757]     # (hardwired zero)
+CSR32_W = [0x300, 0x304, 0x305, 0x306, 0x30A, 0x310, 0x31A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x001, 0x002, 0x003, 0x323, 0x723, 0xB03, 0xB83,
+           0x747, 0x757]
 
 
 @needs_ref

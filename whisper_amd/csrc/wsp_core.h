@@ -1053,13 +1053,14 @@ template <class MEM, bool DRY = false> struct Lane {
       if (num == 0x310 || num == 0x31A || num == 0xB80 || num == 0xB82) return 1;                                  // mstatush menvcfgh mcycleh minstreth
       if (num >= 0xC80 && num <= 0xC82) return ext(ISA_ZICNTR) ? 1 : 0;                                            // cycleh timeh instreth
       if (num >= 0x3A0 && num <= 0x3EF) return 1;
-      if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || num == 0x7C7 || (num >= 0xB83 && num <= 0xB9F)) return -1;   // mhpmevent<n>h mseccfgh mhpmcounter<n>h
+      if ((num >= 0x723 && num <= 0x73F) || num == 0x757 || (num >= 0xB83 && num <= 0xB9F)) return 1;             // mhpmevent<n>h mseccfgh mhpmcounter<n>h: zero (below)
     }
     if (num >= 0x3A0 && num <= 0x3EF) return (num < 0x3B0 && (num & 1)) ? 0 : 1;   // pmpcfg (even only on rv64), pmpaddr0..63
-    if (num >= 0xB03 && num <= 0xB1F) return -1;
-    if (num >= 0x323 && num <= 0x33F) return -1;
-    if (num == 0x747 || (num >= 0x7B0 && num <= 0x7B3)) return -1;
-    return 0;
+    // mhpmcounter3..31, mhpmevent3..31 and mseccfg exist with all-zero write masks in the default configuration (no performance
+    // counters configured, no Smepmp: CsRegs.cpp:4810, 4848-4866): they read zero, a write changes nothing and is still logged
+    if ((num >= 0xB03 && num <= 0xB1F) || (num >= 0x323 && num <= 0x33F) || num == 0x747) return 1;
+    if (num == 0x7C7) return -1;                                                        // c_matp (a custom register of the reference)
+    return 0;                                                                           // (dcsr / dpc: debug mode only, CsRegs.cpp:1252)
   }
   // CY/TM/IR of m/scounteren read as zero while cycle/time/instret are not implemented (CsRegs.cpp:1524-1539, 2117-2130)
   WSP_HD u64 counteren_rmask() const { return ext(ISA_ZICNTR) ? ~0ULL : ~7ULL; }

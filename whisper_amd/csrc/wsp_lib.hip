@@ -236,10 +236,15 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
   const u32 op = w0 & 0xff;
   WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0;
-  const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
-  int rm = 0;
-  if (uses_rm && !L.fp_rm((u32)imm & 7, rm)) return r;
-  L.exec_fp(rec, L.m.rx(rec_rs1(rec)), pc);
+  if (op == OP_ZB) {                                         // bit manipulation: registers only, cannot trap
+    const u64 b = (w0 & F_IMM) ? (u64)(i64)imm : L.m.rx(rec_rs2(rec));
+    L.wx(rec_rd(rec), L.exec_zb(rec_rs3(rec), (w0 & F_IMM) ? 0 : imm, L.m.rx(rec_rs1(rec)), b));
+  } else {
+    const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
+    int rm = 0;
+    if (uses_rm && !L.fp_rm((u32)imm & 7, rm)) return r;
+    L.exec_fp(rec, L.m.rx(rec_rs1(rec)), pc);
+  }
   L.template commit<TRACE>(pc, raw, (w0 & F_SIZE4) ? 4 : 2, PRV_M, 0);
   r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = 1;
   return r;
@@ -792,6 +797,17 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
           L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
           need_cold = false;
         }
+      }
+    }
+    if (need_cold && (d.isa & ISA_ZB_ANY) && (L.h.flags & HF_HOT)) {
+      // a Zba / Zbb / Zbs / Zbc / Zicond instruction of a hot hart: the same warm path (registers in LDS, nothing else)
+      Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
+      if (L.hot_fetch(recs, rec) && (rec.w0 & 0xff) == OP_ZB) {
+        const u32 ln2 = ln_of(d);
+        const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
+        const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr)
+                                        : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr);
+        if (w.handled) { L.h.pc += 4; L.h.exec++; L.h.thash = w.thash; need_cold = false; }
       }
     }
     if (d.vreg) {
@@ -1857,7 +1873,7 @@ extern "C" int wsp_batch_poke(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
       if (loc == 0) HIPOK(hipMemcpy(d.hot64 + ix * S + s, &v, 8, hipMemcpyHostToDevice));
       else if (loc == 1) { u32 f = (u32)v & 0xff; HIPOK(hipMemcpy(d.hot32 + ix * S + s, &f, 4, hipMemcpyHostToDevice)); }
       else if (loc == 2) {
-        if (ix >= CI_PMPCFG0) {   // pmpcfg / pmpaddr pokes are legalised and honour locks like CSR writes (PmpManager.hpp:480-551, CsRegs.cpp:6773)
+        if (ix >= CI_PMPCFG0 && ix < CI_PMPADDR0 + 64) {   // pmpcfg / pmpaddr pokes are legalised and honour locks like CSR writes (PmpManager.hpp:480-551, CsRegs.cpp:6773)
           u64 cfg[8]; for (u32 k = 0; k < 8; ++k) HIPOK(hipMemcpy(&cfg[k], d.cold + (size_t)(CI_PMPCFG0 + k) * S + s, 8, hipMemcpyDeviceToHost));
           auto cb = [&](u32 e) { return (u32)(cfg[e >> 3] >> (8 * (e & 7))) & 0xff; };
           if (ix < CI_PMPADDR0) v = Lane<DevMem>::legalize_pmpcfg(cfg[ix - CI_PMPCFG0], v) & 0x9f9f9f9f9f9f9f9fULL;

@@ -473,7 +473,8 @@ def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = Tr
     fp3 = ["fadd", "fsub", "fmul", "fdiv", "fsgnj", "fsgnjn", "fsgnjx", "fmin", "fmax"]
     safe_csrs = [CSR["mscratch"], CSR["mepc"], CSR["mcause"], CSR["mtval"], CSR["fflags"], CSR["frm"], CSR["fcsr"],
                  CSR["mcycle"], CSR["minstret"], CSR["mhartid"], CSR["misa"], CSR["mie"], CSR["mip"], CSR["mcounteren"],
-                 CSR["cycle"], CSR["sstatus"], CSR["sepc"], 0x7C0, CSR["mvendorid"], CSR["menvcfg"], CSR["mcountinhibit"], CSR["mstatus"]]
+                 CSR["cycle"], CSR["sstatus"], CSR["sepc"], 0x7C0, CSR["mvendorid"], CSR["menvcfg"], CSR["mcountinhibit"], CSR["mstatus"],
+                 0xB03, 0x33F, 0x747, 0x7B0]         # mhpmcounter3 / mhpmevent31 / mseccfg: hardwired zero; dcsr: debug mode only
     if interrupts:
         safe_csrs += [CSR["mie"], CSR["mip"], CSR["mip"], CSR["mideleg"], CSR["medeleg"], CSR["sie"], CSR["sip"], CSR["mstatus"]]
     for i in range(n):
@@ -1527,7 +1528,7 @@ def rv32_program(seed: int, n: int = 300, fp: bool = False) -> Program:
     regs = list(range(0, 30))
     rr = ["add", "sub", "sll", "slt", "sltu", "xor", "srl", "sra", "or_", "and_", "mul", "mulh", "mulhsu", "mulhu", "div", "divu", "rem", "remu"]
     ri = ["addi", "slti", "sltiu", "xori", "ori", "andi"]
-    csrs_rw = [0x340, 0x300, 0x304, 0x305, 0x341, 0x342, 0x343, 0x30A, 0x31A, 0x310, 0xB00, 0xB80, 0xB02, 0xB82, 0x3A0, 0x3A1, 0x3B0, 0x3B1, 0x306, 0x320]
+    csrs_rw = [0x340, 0x300, 0x304, 0x305, 0x341, 0x342, 0x343, 0x30A, 0x31A, 0x310, 0xB00, 0xB80, 0xB02, 0xB82, 0x3A0, 0x3A1, 0x3B0, 0x3B1, 0x306, 0x320, 0xB03, 0xB83, 0x323, 0x723, 0x747, 0x757]
     csrs_ro = [0x301, 0xF14, 0xC00, 0xC80, 0xC01, 0xC81, 0xC02, 0xC82, 0xF11, 0x344]
     labels = 0
     for i in range(n):
