@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--trace", action="store_true", help="fold the commit-trace digest while running")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nofp", action="store_true", help="diagnostic: integer-only variant of the kernel (not the BASELINE config)")
+    ap.add_argument("--workload", default="compute", choices=["compute", "sv39"],
+                    help="sv39 (diagnostic, not the BASELINE config): the same kernel booted the way an OS runs it - PMP opened, Sv39 page table, "
+                         "S mode: every fetch / load / store translated through the TLB model")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -151,7 +154,7 @@ def main():
     from whisper_amd import shard
     from whisper_amd import workloads as WL
 
-    prog = WL.compute_kernel(iters=args.iters, fp=not args.nofp)
+    prog = WL.compute_kernel(iters=args.iters, fp=not args.nofp, paged=args.workload == "sv39")
     n = args.harts
     base, _ = shard.weak_range(n, rank)
     gdev = torch.device("cuda", local_rank) if world > 1 else None
@@ -241,8 +244,10 @@ def main():
             "metric": "aggregate simulated instructions/sec (GIPS)", "value": gips, "unit": "GIPS",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64/softfloat-f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 4096 RV64IMAFD compute-kernel instances per GPU (CoreMark-style, per-instance seed), "
-                                   "run to tohost, state+memory digests", "harts_per_gpu": n, "iters": args.iters,
+            "config": {"workload": ("BASELINE configs[2]: 4096 RV64IMAFD compute-kernel instances per GPU (CoreMark-style, per-instance seed), "
+                                    "run to tohost, state+memory digests") if args.workload == "compute" else
+                                   "DIAGNOSTIC (not the BASELINE config): the compute kernel in S mode under Sv39 (PMP + page table set up by M-mode boot code)",
+                       "harts_per_gpu": n, "iters": args.iters,
                        "instructions_per_step_per_gpu": per_step_insts, "trace_hash": bool(args.trace), "lanes_per_wave": args.lanes,
                        "all_harts_pass": ok, "oracle_spot_check": parity},
             "roofline": roof,

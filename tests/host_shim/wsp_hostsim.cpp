@@ -34,12 +34,13 @@ struct HostMem {
   void st64(u64 o, u64 v) { memcpy(ram + o, &v, 8); }
 };
 
-struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<u8> vreg; std::vector<Rec> recs; u64 max_exec; u64 max_ret = ~0ULL; int use_fast = 1; };
+struct Sim { Lane<HostMem> L; std::vector<u8> ram; std::vector<u64> tlb; std::vector<u8> vreg; std::vector<Rec> recs; u64 max_exec; u64 max_ret = ~0ULL; int use_fast = 1; u64 fast_tr_steps = 0; };
 
 template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
 {
   Lane<HostMem>& L = s->L;
   L.update_hot_flag();
+  Lane<HostMem>::FastTr ft; bool tr_live = false;
   while (L.h.status == ST_RUNNING) {
     if (L.h.exec >= max_exec || L.h.retired >= s->max_ret) { L.h.status = ST_STOP_LIMIT; break; }
     if (L.h.pc == L.stop_pc) { L.h.status = ST_STOP_ADDR; break; }
@@ -55,6 +56,12 @@ template <bool TRACE> static void run_t(Sim* s, u64 max_exec)
       }
       L.h.pc = cur_pc;        // not in the inline subset: nothing was changed, take the general step
     }
+    // S / U-mode code under Sv39: the TLB-hit fast step (the kernel's wsp_swarm), its memo kept while fast steps follow one another
+    if (s->use_fast && !s->recs.empty() && L.fast_tr_allowed() && !(L.h.pc == L.stop_pc)) {
+      if (!tr_live) { L.fast_tr_begin(ft); tr_live = true; }
+      if (L.fast_step_translated<TRACE>(s->recs.data(), ft)) { L.h.exec++; L.h.cycle++; L.h.instret++; L.h.retired++; ++s->fast_tr_steps; continue; }
+    }
+    tr_live = false;
     L.cold_step<TRACE>(s->use_fast && !s->recs.empty() ? s->recs.data() : nullptr);
   }
 }
@@ -102,6 +109,8 @@ void hs_predecode(Sim* s, u64 addr, u64 n)
   s->L.text_lo = addr; s->L.text_hi = addr + n;
 }
 void hs_use_fast(Sim* s, int f) { s->use_fast = f; }
+u64 hs_tlb_word(Sim* s, u32 i) { return i < s->tlb.size() ? s->tlb[i] : 0; }
+u64 hs_fast_tr_steps(Sim* s) { return s->fast_tr_steps; }     // steps taken by the TLB-hit fast step (Lane::fast_step_translated)
 void hs_set_stop(Sim* s, u64 max_ret, u64 stop_pc) { s->max_ret = max_ret; s->L.stop_pc = stop_pc; }
 void hs_set_pc(Sim* s, u64 pc) { s->L.h.pc = pc & ~1ULL; }
 void hs_set_x(Sim* s, u32 i, u64 v) { if (i) s->L.m.x[i & 31] = s->L.rv32() ? (u64)(i64)(i32)v : v; }

@@ -90,6 +90,9 @@ def run_oracle(prog, seed_a0=None, seed_mem=None, max_inst=None, log_cap=0, hart
     return r, h, log
 
 
+last_fast_tr_steps = 0
+
+
 def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True, hart_id=0, features=0, max_ret=None, stop_pc=None):
     L = shim()
     s = L.hs_create3(rvoracle.isa_flags(prog.isa) | (512 if prog.isa.lower().startswith("rv32") else 0) | (features or prog.meta.get("features", 0)), prog.mem_base, prog.mem_size, prog.tohost if prog.tohost is not None else 2**64 - 1, hart_id,
@@ -113,6 +116,10 @@ def run_hostsim(prog, seed_a0=None, seed_mem=None, max_inst=None, predecode=True
                          L.hs_thash(s))
         xs = [L.hs_get_x(s, i) for i in range(32)]
         fs = [L.hs_get_f(s, i) for i in range(32)]
+        global last_fast_tr_steps
+        L.hs_fast_tr_steps.restype = C.c_uint64
+        L.hs_fast_tr_steps.argtypes = [C.c_void_p]
+        last_fast_tr_steps = L.hs_fast_tr_steps(s)          # steps the TLB-hit fast step took in this run
         return r, xs, fs
     finally:
         L.hs_destroy(s)

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--lanes", default="0")
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--workload", default="compute", choices=["compute", "compute_int", "sv39", "rvv", "rvvk", "fuzz"])
+    ap.add_argument("--workload", default="compute", choices=["compute", "compute_int", "compute_sv39", "compute_int_sv39", "sv39", "sv39x", "rvv", "rvvk", "fuzz"])
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--vlenb", type=int, default=64)
@@ -37,14 +37,14 @@ def main():
 
     for n in [int(x) for x in args.harts.split(",")]:
         for lanes in [int(x) for x in args.lanes.split(",")]:
-            if args.workload in ("compute", "compute_int"):
-                prog = WL.compute_kernel(iters=args.iters, fp=args.workload == "compute")
+            if args.workload in ("compute", "compute_int", "compute_sv39", "compute_int_sv39"):
+                prog = WL.compute_kernel(iters=args.iters, fp="int" not in args.workload, paged=args.workload.endswith("sv39"))
                 progs, reps = [prog], n
             elif args.workload == "rvvk":
                 prog = WL.rvv_kernel(n=args.n, iters=args.iters, vlenb=args.vlenb)
                 progs, reps = [prog], n
             else:
-                gen = {"sv39": WL.sv39_program, "rvv": WL.rvv_program, "fuzz": lambda s: WL.fuzz_program(s, 400)}[args.workload]
+                gen = {"sv39": WL.sv39_program, "sv39x": lambda s: WL.sv39_program(s, exec_body=True), "rvv": WL.rvv_program, "fuzz": lambda s: WL.fuzz_program(s, 400)}[args.workload]
                 k = min(n, 256)
                 progs, reps = [gen(s) for s in range(k)], n // k
                 n = k * reps

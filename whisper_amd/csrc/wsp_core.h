@@ -3343,6 +3343,141 @@ template <class MEM, bool DRY = false> struct Lane {
     update_hot_flag();
   }
 
+  // ---- The TLB-hit fast step: S / U-mode code under Sv39 without the general path (VirtMem::translate's hit case,
+  // VirtMem.cpp:261-310; Tlb::findEntryUpdateTime, Tlb.hpp:91-100; the fetch and load / store glue of Hart.cpp:3052-3206, 1988-2154).
+  // One instruction of the inline subset (exec_fast's register / branch / jump forms, aligned loads and stores) whose fetch and
+  // data translations both HIT the TLB with permission, whose pages lie whole inside one PMP region that allows the access,
+  // inside the arena, away from tohost and (stores) from the code image, and whose record comes from the pre-decoded image
+  // by PHYSICAL address.  Everything is checked before anything is changed: on `false` nothing has happened and the general
+  // step executes the instruction (misses and walks, faults, CSRs, traps, misaligned or page-crossing accesses, a straddling
+  // fetch ...).  On `true` the side effects are exactly the general path's: the replacement counters of the TLB entries used
+  // (fetch first, then data), the register / memory write, the pc.  The caller advances the four counters by one, as for a hot
+  // step, and has established: priv != M, satp.MODE = Sv39, code not dirty, no ring, no inhibited counter, no interrupt pending
+  // and enabled.  `FastTr` carries what stays valid from one fast step to the next (anything that could change it - a CSR
+  // write, sfence.vma, a trap, a TLB refill - is not a fast step and ends the run).
+  struct FastTr { u64 satp, fvpn, fpa, fe0, dpage; u32 fix, fok, dperm; };
+  WSP_HD void fast_tr_begin(FastTr& t) { t.satp = m.cold(CI_SATP); t.fok = 0; t.fvpn = 0; t.fpa = 0; t.fe0 = 0; t.fix = 0; t.dpage = ~0ULL; t.dperm = 0x80; }
+  WSP_HD bool fast_tr_allowed()
+  {
+    return h.priv != PRV_M && tlb_n != 0 && !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR | HF_RING)) && (m.cold(CI_SATP) >> 60) == 8 &&
+           (m.cold(CI_MIP) & m.cold(CI_MIE)) == 0;
+  }
+  // pmp_perm for a whole 4 KiB page: the permission bits when one region decides for every byte of it (or none matches any),
+  // 0x80 when the first region that touches the page covers only part of it
+  WSP_HD u32 pmp_perm_page(u32 pm, u64 page)
+  {
+    const u32 dflt = pm == PRV_M ? 7u : 0u;
+    if (!(h.flags & HF_PMP_ON) || (pm == PRV_M && !(h.flags & HF_PMP_MLOCK))) return dflt;
+    const u64 last = page + 4095;
+    for (u32 k = 0; k < 8; ++k) {
+      const u64 w = m.cold(CI_PMPCFG0 + k);
+      if (!(w & 0x1818181818181818ULL)) continue;
+      for (u32 j = 0; j < 8; ++j) {
+        const u32 cfg = (u32)(w >> (8 * j)) & 0xff, type = (cfg >> 3) & 3, ix = 8 * k + j;
+        if (!type) continue;
+        const u64 v = m.cold(CI_PMPADDR0 + ix);
+        u64 lo, hi;
+        if (type == 1) { lo = (ix ? m.cold(CI_PMPADDR0 + ix - 1) : 0) << 2; hi = v << 2; if (hi > 0) hi -= 1; }
+        else {
+          u64 size_m1 = 3, napot = v;
+          if (type == 3) { u32 rzi = 0; while (rzi < 64 && ((v >> rzi) & 1)) ++rzi; napot = rzi >= 64 ? 0 : ((v >> rzi) << rzi); size_m1 = rzi + 3 >= 64 ? ~0ULL : ((1ULL << (rzi + 3)) - 1); }
+          lo = napot << 2; hi = lo + size_m1;
+        }
+        const u64 a0 = (lo >> 2) << 2, a1 = ((hi >> 2) << 2) + 3;
+        if (a0 > a1 || last < a0 || page > a1) continue;                              // (an empty TOR range matches nothing)
+        if (page >= a0 && last <= a1) return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u);
+        return 0x80;
+      }
+    }
+    return dflt;
+  }
+  template <bool TRACE> WSP_HD bool fast_step_translated(const Rec* recs, FastTr& t)
+  {
+    const u32 pm = h.priv;
+    const u64 pc = h.pc, vpn = pc >> 12;
+    if (!t.fok || t.fvpn != vpn) {
+      const u32 ix = 2 * (u32)(vpn & (tlb_n - 1));
+      const u64 e0 = m.tlb(ix), e1 = m.tlb(ix + 1);
+      if (!Vm::tlb_match(e0, e1, vpn, t.satp)) return false;
+      const u32 fl = (u32)(e0 >> 56);
+      if ((pm == PRV_U && !(fl & TE_USER)) || (pm == PRV_S && (fl & TE_USER)) || (fl & (TE_X | TE_A)) != (TE_X | TE_A)) return false;
+      const u64 pap = (e1 & 0xfffffffffffULL) << 12;
+      if (!in_mem(pap, 4096)) return false;
+      const u32 perm = pmp_perm_page(pm, pap);
+      if ((perm & 0x80) || !(perm & 4)) return false;
+      t.fok = 1; t.fvpn = vpn; t.fpa = pap; t.fix = ix; t.fe0 = e0;
+    }
+    const u64 idx = (t.fpa | (pc & 0xfff)) - text_lo;
+    if (idx >= text_hi - text_lo) return false;
+    Rec rec;
+#if defined(__HIP_DEVICE_COMPILE__)
+    { const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (idx << 3)); rec.w0 = q.x; rec.imm = (i32)q.y; rec.pad = q.z; rec.raw = q.w; }
+#else
+    rec = recs[idx >> 1];
+#endif
+    const u32 op = rec.w0 & 0xff, size = (rec.w0 & F_SIZE4) ? 4 : 2;
+    if (size == 4 && (pc & 0xfff) == 0xffe) return false;                              // second half on the next page (Hart.cpp:3144-3156)
+    // ... and the reference translates the second half of a 4-byte instruction at a 2-byte-aligned pc AGAIN whenever the page
+    // number of the virtual pc + 2 differs from the first half's PHYSICAL page number (i.e. whenever VA != PA): one more hit
+    const bool second_lookup = size == 4 && (pc & 2) && ((t.fpa >> 12) != ((pc + 2) >> 12));
+    const u64 a = m.rx(rec_rs1(rec)), b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
+    const bool is_ld = op >= OP_LB && op <= OP_LWU, is_st = op >= OP_SB && op <= OP_SD;
+    u64 de0 = 0, off = 0, va = 0; u32 dix = 0, sz = 0;
+    if (is_ld || is_st) {
+      sz = is_ld ? 1u << ((op - OP_LB) & 3) : 1u << (op - OP_SB);
+      va = (a + (u64)(i64)rec.imm) & amask();
+      if (va & (sz - 1)) return false;
+      const u64 dvpn = va >> 12;
+      dix = 2 * (u32)(dvpn & (tlb_n - 1));
+      de0 = dix == t.fix ? t.fe0 : m.tlb(dix);
+      const u64 de1 = m.tlb(dix + 1);
+      if (!Vm::tlb_match(de0, de1, dvpn, t.satp)) return false;
+      const u32 fl = (u32)(de0 >> 56);
+      const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
+      if ((pm == PRV_U && !(fl & TE_USER)) || (pm == PRV_S && (fl & TE_USER) && !sum) || !(fl & TE_A)) return false;
+      if (is_ld ? !((fl & TE_R) || (mxr && (fl & TE_X))) : (fl & (TE_W | TE_D)) != (TE_W | TE_D)) return false;
+      const u64 dpage = (de1 & 0xfffffffffffULL) << 12, dpa = dpage | (va & 0xfff);
+      if (t.dpage != dpage) { t.dperm = pmp_perm_page(pm, dpage); t.dpage = dpage; }
+      if ((t.dperm & 0x80) || !(t.dperm & (is_ld ? 1u : 2u))) return false;
+      if (!in_mem(dpa, sz)) return false;
+      if (tohost != ~0ULL && dpa + sz > tohost && dpa < tohost + 8) return false;
+      if (is_st && dpa + sz > text_lo && dpa < text_hi) return false;
+      off = dpa - mem_base;
+    }
+    h.pc = (pc + size) & amask();
+    if (is_ld) {
+      u64 v;
+      switch (op - OP_LB) {
+        case 0: v = (u64)(i64)(int8_t)m.ld8(off); break; case 1: v = (u64)(i64)(int16_t)m.ld16(off); break;
+        case 2: v = (u64)(i64)(i32)m.ld32(off); break; case 3: v = m.ld64(off); break;
+        case 4: v = m.ld8(off); break; case 5: v = m.ld16(off); break; default: v = m.ld32(off); break;
+      }
+      if (TRACE) s.chg = 0;
+      wx_fast<TRACE>(rec_rd(rec), v);
+    } else if (is_st) {
+      const u64 sv = sz == 8 ? b : (b & ((1ULL << (8 * sz)) - 1));
+      switch (sz) { case 1: m.st8(off, (u8)sv); break; case 2: m.st16(off, (u16)sv); break; case 4: m.st32(off, (u32)sv); break; default: m.st64(off, sv); break; }
+      if (TRACE) { s.chg = CH_MEM; s.maddr = va; s.mval = sv; }                        // the log's m line carries the virtual address
+    } else if (!exec_fast<TRACE>(op, rec, a, b, pc)) { h.pc = pc; return false; }
+    // the replacement counters: the fetch's entry, then the data access's (the same entry when code and data share a page)
+    t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
+    if (second_lookup) t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
+    if ((is_ld || is_st) && dix == t.fix) t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
+    m.tlb(t.fix) = t.fe0;
+    if ((is_ld || is_st) && dix != t.fix) m.tlb(dix) = (de0 & ~(3ULL << 54)) | ((((de0 >> 54) + 1) & 3) << 54);
+    if (TRACE) {
+      u64 th = h.thash;
+      th = fold(th, pc);
+      th = fold(th, (u64)rec.raw | ((u64)pm << 32) | ((u64)size << 48));
+      u64 k = 1ULL << 60, v = 0;
+      if ((s.chg & CH_IREG) && s.ireg) { k = (u64)s.ireg ^ (1ULL << 60); v = s.ival; }
+      else if (s.chg & CH_MEM) { k = s.maddr ^ (4ULL << 60); v = s.mval; }
+      th = fold(th, k); th = fold(th, v);
+      h.thash = th;
+    }
+    return true;
+  }
+
   // ---- fold one commit record into the running trace hash
   // Commit record of one step.  The digest folds a word stream: pc, meta, then one (key, value) pair per change in the order the
   // reference's log prints them (printTrace.cpp:380-495), key = id ^ kind << 60.  With a commit ring configured

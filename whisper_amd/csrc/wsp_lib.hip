@@ -164,6 +164,10 @@ __device__ __forceinline__ void wsp_store_hot(const Lane<DevMem>& L, const DevSt
 // exactly one (HF_HOT guarantees no inhibit, no trap), so the HBM copies are brought up to date
 // from the difference between the register exec counter and the stored one.
 struct HotRegs { u64 pc, exec, thash, stop_at, slice_end; u32 flags, status, fcsr; };
+// In HotRegs.flags on the way INTO wsp_cold only (never stored): the translated warm path (wsp_swarm) has just made progress with
+// this hart, so the general path executes the one instruction that stopped it and hands the hart back, instead of keeping it for
+// a whole burst.
+static constexpr u32 HR_SWARM_LIVE = 1u << 31;
 
 // First value of the executed-instruction counter at which the hart must not start another instruction: the end of this launch's
 // slice, the instruction-count limit, or the retired-instruction limit, whichever comes first (Hart.cpp:6025-6026).  retired lags
@@ -199,7 +203,8 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
   wsp_load_hot(L, d, slot);
   const u64 dlt = hr.exec - L.h.exec;              // hot steps since the last sync: each advanced all four counters by one
   L.h.cycle += dlt; L.h.instret += dlt; L.h.retired += dlt;
-  L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
+  L.h.exec = hr.exec; L.h.pc = hr.pc; L.h.thash = hr.thash; L.h.flags = hr.flags & ~HR_SWARM_LIVE; L.h.status = hr.status; L.h.fcsr = hr.fcsr;
+  const u32 burst = (hr.flags & HR_SWARM_LIVE) ? 1u : WSP_COLD_BURST;
   const u64 max_exec = d.max_exec[slot], max_ret = d.max_ret[slot];
   u64 stop_at = hr.stop_at;
   u32 k = 0;
@@ -208,7 +213,7 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
     L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
     L.template cold_step<true>(recs);
     stop_at = wsp_stop_at(hr.slice_end, max_exec, max_ret, L.h.exec, L.h.retired);
-  } while (++k < WSP_COLD_BURST && L.h.status == ST_RUNNING && L.h.exec < stop_at &&
+  } while (++k < burst && L.h.status == ST_RUNNING && L.h.exec < stop_at &&
            !((L.h.flags & HF_HOT) && L.h.pc - L.text_lo < L.text_hi - L.text_lo));
   WSP_PROF_ADD(3, WSP_PROF_T() - pt1); WSP_PROF_ADD(6, k);
   wsp_store_hot(L, d, slot);
@@ -352,6 +357,45 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
   return r;
 }
 
+// The translated warm path: S / U-mode harts under Sv39 (never hot: the hot loops run M-mode code at physical addresses).  Each
+// lane runs its own hart through Lane::fast_step_translated - TLB-hit fetch and data translation, PMP by page, the pre-decoded
+// record by physical address, the inline instruction subset - for as long as every step is such a step (at most max_n); the
+// first instruction that is not (a TLB miss, a fault, a CSR access, ecall, a misaligned access ...) ends the lane's run with
+// nothing changed, and the general path executes it.  The hart is register resident: x registers in LDS, pc / privilege /
+// mstatus / digest in registers, the TLB and the PMP rows read from HBM; nothing of the hart's HBM state is loaded or stored
+// beyond that (the four counters advance with the executed count, as for hot steps).
+struct SWarmRet { u64 pc, thash; u32 n; };
+template <bool TRACE>
+__device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 max_n)
+{
+  const DevState& d = *dp;
+  const u32 lpw = wsp_uni32(d.lpw), lpw_shift = wsp_uni32(d.lpw_shift), S = wsp_uni32(d.S), tlb_n = wsp_uni32(d.tlb_n);
+  const u32 wave = blockIdx.x, ln = threadIdx.x, slot = wave * 64 + ln;
+  Lane<DevMem> L;
+  L.m.xs = wsp_lds + ln * WSP_XSLOTS;
+  L.m.fs = wsp_lds + (lpw + ln) * WSP_XSLOTS;
+  L.m.cold_ = (u64*)(size_t)wsp_uni64((u64)(size_t)d.cold) + slot;
+  L.m.tlb_ = (u64*)(size_t)wsp_uni64((u64)(size_t)d.tlb) + (size_t)(wave * lpw + ln) * 2 * tlb_n; L.tlb_n = tlb_n;
+  L.m.voff = 0; L.vlenb = 0; L.m.vcsr_ = nullptr;
+  L.ring_ = nullptr; L.ring_pos_ = nullptr; L.ring_cap = 0;
+  L.mem_base = wsp_uni64(d.mem_base); L.mem_size = wsp_uni64(d.mem_size); L.isa = wsp_uni32(d.isa);
+  L.m.arena = (u8*)(size_t)wsp_uni64((u64)(size_t)d.arena) + (size_t)wave * lpw * L.mem_size + (size_t)ln * 8;
+  L.m.S = S; L.m.lpw_shift = lpw_shift;
+  L.hart_id = 0; L.tohost = va.tohost; L.stop_pc = ~0ULL; L.text_lo = va.text_lo; L.text_hi = va.text_hi;
+  L.vsub = 0; L.vgrp = 1;
+  L.h.pc = pc; L.h.thash = thash; L.h.flags = flags; L.h.status = ST_RUNNING; L.h.fcsr = 0;
+  L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[(size_t)H64_MSTATUS * S + slot];
+  L.h.cycle = 0; L.h.instret = 0; L.h.exec = 0; L.h.retired = 0; L.h.lr_addr = 0; L.h.exec_last_ill = 0; L.h.stop_value = 0; L.h.consec_ill = 0; L.h.htif_dev = 0;
+  L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
+  SWarmRet r; r.pc = pc; r.thash = thash; r.n = 0;
+  if (!L.fast_tr_allowed()) return r;
+  Lane<DevMem>::FastTr t; L.fast_tr_begin(t);
+  u32 n = 0;
+  while (n < max_n && L.template fast_step_translated<TRACE>(va.recs, t)) ++n;
+  r.pc = L.h.pc; r.thash = L.h.thash; r.n = n;
+  return r;
+}
+
 // Wave-wide minimum of a u32 (all 64 lanes participate).
 __device__ __forceinline__ u32 wave_min_u32(u32 v)
 {
@@ -448,6 +492,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   // meets anything outside the inline subset (an op that is not inlined, a misaligned / out-of-arena / tohost / text
   // access, a control transfer leaving the text) changes nothing, raises `nc` and the loop is left after that iteration;
   // the general step then executes that same instruction in full.
+  u32 swarm_credit = 0;                                  // > 0: wsp_swarm made progress with this hart in one of its last four tries
   while (true) {
     const bool run = L.h.status == ST_RUNNING && L.h.exec < stop_at;
     if (!__any(run)) break;                              // every lane of the wave has stopped or used its budget
@@ -810,6 +855,19 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         if (w.handled) { L.h.pc += 4; L.h.exec++; L.h.thash = w.thash; need_cold = false; }
       }
     }
+#ifndef WSP_SWARM
+#define WSP_SWARM 1                                      // 0: build without the translated warm path (A/B measurements)
+#endif
+    if (WSP_SWARM && need_cold && active && d.tlb_n && recs && !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc) {
+      // S / U-mode code under Sv39: the translated warm path (wsp_swarm); a hart it does not take is back at once
+      VWarmArgs sa; sa.recs = recs; sa.text_lo = L.text_lo; sa.text_hi = L.text_hi; sa.tohost = L.tohost;
+      const u64 left = stop_at - L.h.exec;
+      const u32 smax = left > 1024 ? 1024u : (u32)left;
+      const SWarmRet w = (TRACE && tr) ? wsp_swarm<true>(dp, sa, L.h.pc, L.h.thash, L.h.flags, smax) : wsp_swarm<false>(dp, sa, L.h.pc, L.h.thash, L.h.flags, smax);
+      // (a run that ended before its budget ended on an instruction for the general path: it goes there now, for that one step)
+      if (w.n) { L.h.pc = w.pc; L.h.exec += w.n; L.h.thash = w.thash; need_cold = w.n < smax; swarm_credit = 4; }
+      else if (swarm_credit) --swarm_credit;
+    } else if (need_cold) swarm_credit = 0;
     if (d.vreg) {
       // Vector warm path (wsp_vwarm): hot harts with VS Dirty at a vector instruction; the idle lanes l + lpw, l + 2 lpw, ... join
       // hart l as its sub-group and get the instruction and the hart's live registers from its lane.
@@ -844,7 +902,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
       // A cold call is a context switch: every per-lane value of the hot loop is either passed through HotRegs or
       // rebuilt from the kernel arguments afterwards.
       HotRegs hr; hr.pc = L.h.pc; hr.exec = L.h.exec; hr.thash = L.h.thash; hr.stop_at = stop_at; hr.slice_end = slice_end;
-      hr.flags = L.h.flags; hr.status = L.h.status; hr.fcsr = L.h.fcsr;
+      hr.flags = L.h.flags | (swarm_credit ? HR_SWARM_LIVE : 0u); hr.status = L.h.status; hr.fcsr = L.h.fcsr;
       hr = wsp_cold(dp, hr);
       const u32 ln2 = ln_of(d);
       wsp_lane_setup(L, d, blockIdx.x, ln2, blockIdx.x * 64 + ln2, recs);

@@ -279,11 +279,14 @@ def compute_seed(i: int) -> int:
     return splitmix64(0xC0FFEE ^ i)
 
 
-def compute_kernel(iters: int = 4, fp: bool = True) -> Program:
+def compute_kernel(iters: int = 4, fp: bool = True, paged: bool = False) -> Program:
     """CoreMark-style mix, seed in a0 (per instance): LCG-filled 16x16 integer matrix multiply,
     linked-list walk, bit-serial CRC16 (data-dependent branches), then an FP section (daxpy,
     Horner fma, div/sqrt chain, fcvt round trips under every rounding mode, single precision mix).
-    Result words are stored to `results`; exit by writing 1 to tohost."""
+    Result words are stored to `results`; exit by writing 1 to tohost.
+    paged: the same kernel the way an operating system would run it - M-mode boot code opens the PMP, builds an Sv39 page
+    table (one 2 MiB identity megapage over the arena), turns translation on and drops to S mode; everything after that is
+    S-mode code whose every fetch, load and store is translated."""
     data_base = BASE + 0x2000
     a = Asm(BASE)
     d = Asm(data_base)
@@ -313,6 +316,15 @@ def compute_kernel(iters: int = 4, fp: bool = True) -> Program:
     a.li(T0, 0x6000 if fp else 0)
     if fp:
         a.csrs(CSR["mstatus"], T0)
+    if paged:
+        pt_root, pt_l1 = BASE + 0x8000, BASE + 0x9000
+        a.li(T0, (1 << 54) - 1); a.csrw(0x3B0, T0); a.li(T0, 0x1F); a.csrw(0x3A0, T0)        # pmp0: NAPOT over everything, RWX
+        a.li(T0, pt_root); a.li(T1, ((pt_l1 >> 12) << 10) | 1); a.sd(T1, 8 * ((BASE >> 30) & 511), T0)
+        a.li(T0, pt_l1); a.li(T1, ((BASE >> 12) << 10) | 0xCF); a.sd(T1, 8 * ((BASE >> 21) & 511), T0)   # V R W X A D, 2 MiB leaf
+        a.li(T0, (8 << 60) | (pt_root >> 12)); a.csrw(CSR["satp"], T0)
+        a.li(T0, 3 << 11); a.csrc(CSR["mstatus"], T0); a.li(T0, 1 << 11); a.csrs(CSR["mstatus"], T0)  # MPP = S
+        a.la(T0, "kernel"); a.csrw(CSR["mepc"], T0); a.mret()
+        a.label("kernel")
     a.li(RES, S["results"])
     a.li(20, 6364136223846793005); a.li(21, 1442695040888963407)
     a.li(T0, S["seed"]); a.ld(T1, 0, T0); a.xor(SEED, SEED, T1)
@@ -401,10 +413,13 @@ def compute_kernel(iters: int = 4, fp: bool = True) -> Program:
     a.beqz(ITER, "done")
     a.j("outer")
     a.label("done")
-    a.csrr(T0, CSR["minstret"]); a.sd(T0, 136, RES)
+    if not paged:
+        a.csrr(T0, CSR["minstret"]); a.sd(T0, 136, RES)
     _exit_tohost(a, S["tohost"])
     isa = "rv64imafdc_zicsr" if fp else "rv64imac_zicsr"
-    return _finish(a, "compute", isa, d, mem_size=1 << 16, max_inst=1 << 26, meta=dict(iters=iters))
+    if paged:
+        isa = isa.replace("c_zicsr", "csu_zicsr")
+    return _finish(a, "compute-sv39" if paged else "compute", isa, d, mem_size=1 << 16, max_inst=1 << 26, meta=dict(iters=iters))
 
 
 # ------------------------------------------------------------------------------------------ fuzz
@@ -798,7 +813,7 @@ def pmp_program(seed: int, n: int = 300) -> Program:
 _PTE_V, _PTE_R, _PTE_W, _PTE_X, _PTE_U, _PTE_G, _PTE_A, _PTE_D = 1, 2, 4, 8, 16, 32, 64, 128
 
 
-def sv39_program(seed: int, n: int = 300) -> Program:
+def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
     """Sv39 paging: M mode opens PMP, builds a three-level page table (4 KiB pages with mixed
     R/W/X/U/A/D bits, a 2 MiB window over the whole arena, a misaligned superpage, malformed PTEs), and drops to S (odd
     seeds) or U (even seeds) at a virtual address that is not the physical one.  The body mixes loads, stores, AMOs, LR/SC
@@ -807,7 +822,9 @@ def sv39_program(seed: int, n: int = 300) -> Program:
     window *without* sfence.vma (stale TLB entries are architecturally visible in the reference), the sfence.vma forms,
     sstatus.SUM / MXR toggles and satp rewrites (new ASID).  `ecall` services run in M mode: MPRV loads and stores (translated
     with the caller's privilege) and satp switches.  Every trap goes to one M handler that steps over the faulting
-    instruction (fetch faults resume at ra).  Run with a small `tlb_entries` so the replacement policy matters."""
+    instruction (fetch faults resume at ra).  Run with a small `tlb_entries` so the replacement policy matters.
+    exec_body: mark the body's segment executable in the ELF, so that the loader pre-decodes it too (the image then spans
+    boot code .. body, about 80 KiB) and S / U-mode steps can take the TLB-hit fast path."""
     rng = random.Random(0x5339 ^ seed)
     smode = bool(seed & 1)
     MEM = 1 << 18
@@ -1004,7 +1021,7 @@ def sv39_program(seed: int, n: int = 300) -> Program:
     b.addi(6, 6, 4); b.ret()
     code = b.assemble()
     text = a.assemble()
-    segs = [(a.base, text, PF_R | PF_X), (d.base, d.assemble(), PF_R | PF_W), (PA_CODE, code, PF_R)]   # code lands inside the data image's span: last
+    segs = [(a.base, text, PF_R | PF_X), (d.base, d.assemble(), PF_R | PF_W), (PA_CODE, code, PF_R | (PF_X if exec_body else 0))]   # code lands inside the data image's span: last
     syms = dict(a.symbols); syms.update(d.symbols)
     elf = write_elf(segs, syms["_start"], syms)
     return Program(f"sv39-{seed}", "rv64imafdcsu_zicsr", elf, syms["_start"], segs, syms, BASE, MEM, 60000, dict(seed=seed, tlb_entries=8))
