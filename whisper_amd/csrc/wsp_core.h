@@ -3355,8 +3355,28 @@ template <class MEM, bool DRY = false> struct Lane {
   // step, and has established: priv != M, satp.MODE = Sv39, code not dirty, no ring, no inhibited counter, no interrupt pending
   // and enabled.  `FastTr` carries what stays valid from one fast step to the next (anything that could change it - a CSR
   // write, sfence.vma, a trap, a TLB refill - is not a fast step and ends the run).
-  struct FastTr { u64 satp, fvpn, fpa, fe0, dpage; u32 fix, fok, dperm; };
-  WSP_HD void fast_tr_begin(FastTr& t) { t.satp = m.cold(CI_SATP); t.fok = 0; t.fvpn = 0; t.fpa = 0; t.fe0 = 0; t.fix = 0; t.dpage = ~0ULL; t.dperm = 0x80; }
+  struct FastTr {
+    u64 satp;
+    u64 fvpn, fpa, fe0, fe1; u32 fix, fok;            // the fetch page: its TLB entry (word 0 as last stored), physical page, TLB index
+    u64 dvpn, de0, de1, dpage; u32 dix, dok, dperm;    // the last data page: its TLB entry, physical page, PMP verdict
+    Rec nrec; u64 nidx; u32 nok;                       // the record that follows the current one in its page, fetched ahead
+  };
+  WSP_HD void fast_tr_begin(FastTr& t)
+  {
+    t.satp = m.cold(CI_SATP); t.fok = 0; t.fvpn = 0; t.fpa = 0; t.fe0 = 0; t.fe1 = 0; t.fix = 0;
+    t.dvpn = 0; t.de0 = 0; t.de1 = 0; t.dpage = ~0ULL; t.dix = 0; t.dok = 0; t.dperm = 0x80; t.nidx = 0; t.nok = 0;
+    t.nrec.w0 = 0; t.nrec.imm = 0; t.nrec.pad = 0; t.nrec.raw = 0;
+  }
+  WSP_HD static Rec fast_rec_load(const Rec* recs, u64 idx)
+  {
+    Rec rec;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (idx << 3)); rec.w0 = q.x; rec.imm = (i32)q.y; rec.pad = q.z; rec.raw = q.w;
+#else
+    rec = recs[idx >> 1];
+#endif
+    return rec;
+  }
   WSP_HD bool fast_tr_allowed()
   {
     return h.priv != PRV_M && tlb_n != 0 && !(h.flags & (HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR | HF_RING)) && (m.cold(CI_SATP) >> 60) == 8 &&
@@ -3405,17 +3425,15 @@ template <class MEM, bool DRY = false> struct Lane {
       if (!in_mem(pap, 4096)) return false;
       const u32 perm = pmp_perm_page(pm, pap);
       if ((perm & 0x80) || !(perm & 4)) return false;
-      t.fok = 1; t.fvpn = vpn; t.fpa = pap; t.fix = ix; t.fe0 = e0;
+      t.fok = 1; t.fvpn = vpn; t.fpa = pap; t.fix = ix; t.fe0 = e0; t.fe1 = e1;
+      if (t.dok && t.dix == ix) t.dok = 0;             // (one copy per TLB entry: the fetch side owns this one now)
     }
-    const u64 idx = (t.fpa | (pc & 0xfff)) - text_lo;
-    if (idx >= text_hi - text_lo) return false;
-    Rec rec;
-#if defined(__HIP_DEVICE_COMPILE__)
-    { const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(recs) + (idx << 3)); rec.w0 = q.x; rec.imm = (i32)q.y; rec.pad = q.z; rec.raw = q.w; }
-#else
-    rec = recs[idx >> 1];
-#endif
+    const u64 idx = (t.fpa | (pc & 0xfff)) - text_lo, text_len = text_hi - text_lo;
+    if (idx >= text_len) return false;
+    const Rec rec = (t.nok && t.nidx == idx) ? t.nrec : fast_rec_load(recs, idx);
     const u32 op = rec.w0 & 0xff, size = (rec.w0 & F_SIZE4) ? 4 : 2;
+    // the sequential successor's record, requested now so that it arrives while this instruction's data access is under way
+    if ((pc & 0xfff) + size < 0x1000 && idx + size < text_len) { t.nidx = idx + size; t.nrec = fast_rec_load(recs, t.nidx); t.nok = 1; } else t.nok = 0;
     if (size == 4 && (pc & 0xfff) == 0xffe) return false;                              // second half on the next page (Hart.cpp:3144-3156)
     // ... and the reference translates the second half of a 4-byte instruction at a 2-byte-aligned pc AGAIN whenever the page
     // number of the virtual pc + 2 differs from the first half's PHYSICAL page number (i.e. whenever VA != PA): one more hit
@@ -3429,8 +3447,10 @@ template <class MEM, bool DRY = false> struct Lane {
       if (va & (sz - 1)) return false;
       const u64 dvpn = va >> 12;
       dix = 2 * (u32)(dvpn & (tlb_n - 1));
-      de0 = dix == t.fix ? t.fe0 : m.tlb(dix);
-      const u64 de1 = m.tlb(dix + 1);
+      u64 de1;
+      if (dix == t.fix) { de0 = t.fe0; de1 = t.fe1; }
+      else if (t.dok && t.dvpn == dvpn) { de0 = t.de0; de1 = t.de1; }
+      else { de0 = m.tlb(dix); de1 = m.tlb(dix + 1); }
       if (!Vm::tlb_match(de0, de1, dvpn, t.satp)) return false;
       const u32 fl = (u32)(de0 >> 56);
       const bool sum = (h.mstatus & MST_SUM) != 0, mxr = (h.mstatus & MST_MXR) != 0;
@@ -3443,6 +3463,7 @@ template <class MEM, bool DRY = false> struct Lane {
       if (tohost != ~0ULL && dpa + sz > tohost && dpa < tohost + 8) return false;
       if (is_st && dpa + sz > text_lo && dpa < text_hi) return false;
       off = dpa - mem_base;
+      if (dix != t.fix) { t.dok = 1; t.dvpn = dvpn; t.dix = dix; t.de0 = de0; t.de1 = de1; }      // (nothing can fail from here on)
     }
     h.pc = (pc + size) & amask();
     if (is_ld) {
@@ -3464,7 +3485,7 @@ template <class MEM, bool DRY = false> struct Lane {
     if (second_lookup) t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
     if ((is_ld || is_st) && dix == t.fix) t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
     m.tlb(t.fix) = t.fe0;
-    if ((is_ld || is_st) && dix != t.fix) m.tlb(dix) = (de0 & ~(3ULL << 54)) | ((((de0 >> 54) + 1) & 3) << 54);
+    if ((is_ld || is_st) && dix != t.fix) { t.de0 = (de0 & ~(3ULL << 54)) | ((((de0 >> 54) + 1) & 3) << 54); m.tlb(dix) = t.de0; }
     if (TRACE) {
       u64 th = h.thash;
       th = fold(th, pc);
