@@ -3439,10 +3439,19 @@ template <class MEM, bool DRY = false> struct Lane {
     // number of the virtual pc + 2 differs from the first half's PHYSICAL page number (i.e. whenever VA != PA): one more hit
     const bool second_lookup = size == 4 && (pc & 2) && ((t.fpa >> 12) != ((pc + 2) >> 12));
     const u64 a = m.rx(rec_rs1(rec)), b = (rec.w0 & F_IMM) ? (u64)(i64)rec.imm : m.rx(rec_rs2(rec));
-    const bool is_ld = op >= OP_LB && op <= OP_LWU, is_st = op >= OP_SB && op <= OP_SD;
+    // F / D with mstatus.FS already Dirty (nothing of mstatus changes then): flw / fld / fsw / fsd like the integer accesses, the
+    // computational instructions through exec_fp (registers and fflags only); a reserved rounding mode is the general path's
+    const bool fs_dirty = ((h.mstatus >> MST_FS_SH) & 3) == 3;
+    const bool is_fls = fs_dirty && op >= OP_FLW && op <= OP_FSD, is_fp = fs_dirty && op >= OP_FADD && op <= OP_FMV_X2F;
+    const bool is_ld = (op >= OP_LB && op <= OP_LWU) || (is_fls && op <= OP_FLD), is_st = (op >= OP_SB && op <= OP_SD) || (is_fls && op >= OP_FSW);
+    if (is_fp) {
+      const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
+      int rm = 0;
+      if (uses_rm && !fp_rm((u32)rec.imm & 7, rm)) return false;
+    }
     u64 de0 = 0, off = 0, va = 0; u32 dix = 0, sz = 0;
     if (is_ld || is_st) {
-      sz = is_ld ? 1u << ((op - OP_LB) & 3) : 1u << (op - OP_SB);
+      sz = is_fls ? ((op == OP_FLW || op == OP_FSW) ? 4u : 8u) : is_ld ? 1u << ((op - OP_LB) & 3) : 1u << (op - OP_SB);
       va = (a + (u64)(i64)rec.imm) & amask();
       if (va & (sz - 1)) return false;
       const u64 dvpn = va >> 12;
@@ -3466,7 +3475,14 @@ template <class MEM, bool DRY = false> struct Lane {
       if (dix != t.fix) { t.dok = 1; t.dvpn = dvpn; t.dix = dix; t.de0 = de0; t.de1 = de1; }      // (nothing can fail from here on)
     }
     h.pc = (pc + size) & amask();
-    if (is_ld) {
+    if (is_fp) {
+      s.chg = 0; s.ireg = 0; s.freg = 0; s.gen_csr = 0; s.vgroup = 0;
+      exec_fp(rec, a, pc);
+    } else if (is_ld && is_fls) {
+      const u64 v = sz == 4 ? (u64)m.ld32(off) : m.ld64(off);
+      s.chg = 0;
+      if (op == OP_FLW) wf_s(rec_rd(rec), (u32)v); else wf(rec_rd(rec), v);
+    } else if (is_ld) {
       u64 v;
       switch (op - OP_LB) {
         case 0: v = (u64)(i64)(int8_t)m.ld8(off); break; case 1: v = (u64)(i64)(int16_t)m.ld16(off); break;
@@ -3476,7 +3492,8 @@ template <class MEM, bool DRY = false> struct Lane {
       if (TRACE) s.chg = 0;
       wx_fast<TRACE>(rec_rd(rec), v);
     } else if (is_st) {
-      const u64 sv = sz == 8 ? b : (b & ((1ULL << (8 * sz)) - 1));
+      const u64 sb = is_fls ? m.rf(rec_rs2(rec)) : b;
+      const u64 sv = sz == 8 ? sb : (sb & ((1ULL << (8 * sz)) - 1));
       switch (sz) { case 1: m.st8(off, (u8)sv); break; case 2: m.st16(off, (u16)sv); break; case 4: m.st32(off, (u32)sv); break; default: m.st64(off, sv); break; }
       if (TRACE) { s.chg = CH_MEM; s.maddr = va; s.mval = sv; }                        // the log's m line carries the virtual address
     } else if (!exec_fast<TRACE>(op, rec, a, b, pc)) { h.pc = pc; return false; }
@@ -3486,12 +3503,14 @@ template <class MEM, bool DRY = false> struct Lane {
     if ((is_ld || is_st) && dix == t.fix) t.fe0 = (t.fe0 & ~(3ULL << 54)) | ((((t.fe0 >> 54) + 1) & 3) << 54);
     m.tlb(t.fix) = t.fe0;
     if ((is_ld || is_st) && dix != t.fix) { t.de0 = (de0 & ~(3ULL << 54)) | ((((de0 >> 54) + 1) & 3) << 54); m.tlb(dix) = t.de0; }
-    if (TRACE) {
+    if (TRACE && is_fp) commit<true>(pc, rec.raw, size, pm, 0);        // (register and / or fcsr: the general record builder)
+    else if (TRACE) {
       u64 th = h.thash;
       th = fold(th, pc);
       th = fold(th, (u64)rec.raw | ((u64)pm << 32) | ((u64)size << 48));
       u64 k = 1ULL << 60, v = 0;
       if ((s.chg & CH_IREG) && s.ireg) { k = (u64)s.ireg ^ (1ULL << 60); v = s.ival; }
+      else if (s.chg & CH_FREG) { k = (u64)s.freg ^ (2ULL << 60); v = s.fval; }
       else if (s.chg & CH_MEM) { k = s.maddr ^ (4ULL << 60); v = s.mval; }
       th = fold(th, k); th = fold(th, v);
       h.thash = th;

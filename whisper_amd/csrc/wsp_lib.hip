@@ -364,9 +364,9 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
 // nothing changed, and the general path executes it.  The hart is register resident: x registers in LDS, pc / privilege /
 // mstatus / digest in registers, the TLB and the PMP rows read from HBM; nothing of the hart's HBM state is loaded or stored
 // beyond that (the four counters advance with the executed count, as for hot steps).
-struct SWarmRet { u64 pc, thash; u32 n; };
+struct SWarmRet { u64 pc, thash; u32 n, fcsr; };
 template <bool TRACE>
-__device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 max_n)
+__device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 fcsr, u32 max_n)
 {
   const DevState& d = *dp;
   const u32 lpw = wsp_uni32(d.lpw), lpw_shift = wsp_uni32(d.lpw_shift), S = wsp_uni32(d.S), tlb_n = wsp_uni32(d.tlb_n);
@@ -383,16 +383,16 @@ __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64
   L.m.S = S; L.m.lpw_shift = lpw_shift;
   L.hart_id = 0; L.tohost = va.tohost; L.stop_pc = ~0ULL; L.text_lo = va.text_lo; L.text_hi = va.text_hi;
   L.vsub = 0; L.vgrp = 1;
-  L.h.pc = pc; L.h.thash = thash; L.h.flags = flags; L.h.status = ST_RUNNING; L.h.fcsr = 0;
+  L.h.pc = pc; L.h.thash = thash; L.h.flags = flags; L.h.status = ST_RUNNING; L.h.fcsr = fcsr;
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[(size_t)H64_MSTATUS * S + slot];
   L.h.cycle = 0; L.h.instret = 0; L.h.exec = 0; L.h.retired = 0; L.h.lr_addr = 0; L.h.exec_last_ill = 0; L.h.stop_value = 0; L.h.consec_ill = 0; L.h.htif_dev = 0;
   L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
-  SWarmRet r; r.pc = pc; r.thash = thash; r.n = 0;
+  SWarmRet r; r.pc = pc; r.thash = thash; r.n = 0; r.fcsr = fcsr;
   if (!L.fast_tr_allowed()) return r;
   Lane<DevMem>::FastTr t; L.fast_tr_begin(t);
   u32 n = 0;
   while (n < max_n && L.template fast_step_translated<TRACE>(va.recs, t)) ++n;
-  r.pc = L.h.pc; r.thash = L.h.thash; r.n = n;
+  r.pc = L.h.pc; r.thash = L.h.thash; r.n = n; r.fcsr = L.h.fcsr;
   return r;
 }
 
@@ -492,7 +492,8 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   // meets anything outside the inline subset (an op that is not inlined, a misaligned / out-of-arena / tohost / text
   // access, a control transfer leaving the text) changes nothing, raises `nc` and the loop is left after that iteration;
   // the general step then executes that same instruction in full.
-  u32 swarm_credit = 0;                                  // > 0: wsp_swarm made progress with this hart in one of its last four tries
+  u32 swarm_credit = 0;                                  // > 0: wsp_swarm's last runs with this hart were long ones (see the call site)
+  u32 swarm_skip = 0, swarm_backoff = 0;                 // general-path rounds to let pass before wsp_swarm is tried again
   while (true) {
     const bool run = L.h.status == ST_RUNNING && L.h.exec < stop_at;
     if (!__any(run)) break;                              // every lane of the wave has stopped or used its budget
@@ -858,15 +859,24 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
 #ifndef WSP_SWARM
 #define WSP_SWARM 1                                      // 0: build without the translated warm path (A/B measurements)
 #endif
-    if (WSP_SWARM && need_cold && active && d.tlb_n && recs && !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc) {
+    const bool swarm_can = WSP_SWARM && need_cold && active && d.tlb_n && recs &&
+                           !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc;
+    if (swarm_can && swarm_skip) --swarm_skip;
+    else if (swarm_can) {
       // S / U-mode code under Sv39: the translated warm path (wsp_swarm); a hart it does not take is back at once
       VWarmArgs sa; sa.recs = recs; sa.text_lo = L.text_lo; sa.text_hi = L.text_hi; sa.tohost = L.tohost;
       const u64 left = stop_at - L.h.exec;
       const u32 smax = left > 1024 ? 1024u : (u32)left;
-      const SWarmRet w = (TRACE && tr) ? wsp_swarm<true>(dp, sa, L.h.pc, L.h.thash, L.h.flags, smax) : wsp_swarm<false>(dp, sa, L.h.pc, L.h.thash, L.h.flags, smax);
-      // (a run that ended before its budget ended on an instruction for the general path: it goes there now, for that one step)
-      if (w.n) { L.h.pc = w.pc; L.h.exec += w.n; L.h.thash = w.thash; need_cold = w.n < smax; swarm_credit = 4; }
-      else if (swarm_credit) --swarm_credit;
+      const SWarmRet w = (TRACE && tr) ? wsp_swarm<true>(dp, sa, L.h.pc, L.h.thash, L.h.flags, L.h.fcsr, smax)
+                                       : wsp_swarm<false>(dp, sa, L.h.pc, L.h.thash, L.h.flags, L.h.fcsr, smax);
+      if (w.n) {
+        // a run that ended before its budget ended on an instruction for the general path: it goes there now.  After a long
+        // run (code that mostly qualifies: the stop was a TLB refill or a lone CSR access) for that one step; after a short
+        // one (trap-heavy code) for a whole burst, whose start-up cost one step would not repay
+        L.h.pc = w.pc; L.h.exec += w.n; L.h.thash = w.thash; L.h.fcsr = w.fcsr; need_cold = w.n < smax;
+        swarm_credit = w.n >= 16 ? 2u : 0u; swarm_backoff = 0;
+      } else if (swarm_credit) --swarm_credit;
+      else { swarm_backoff = swarm_backoff < 15 ? 2 * swarm_backoff + 1 : 15u; swarm_skip = swarm_backoff; }   // not its kind of code: try again later
     } else if (need_cold) swarm_credit = 0;
     if (d.vreg) {
       // Vector warm path (wsp_vwarm): hot harts with VS Dirty at a vector instruction; the idle lanes l + lpw, l + 2 lpw, ... join
