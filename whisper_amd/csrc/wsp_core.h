@@ -3128,6 +3128,31 @@ template <class MEM, bool DRY = false> struct Lane {
     }
   }
 
+  // ---- M extension (Hart.cpp:13964-14170): registers only, never traps
+  WSP_HD u64 muldiv(u32 op, u64 a, u64 b) const
+  {
+    switch (op) {
+      case OP_MUL: return a * b;
+      case OP_MULH: case OP_MULHSU: case OP_MULHU:
+        if (rv32()) {                                                                        // Hart<uint32_t>: 32-bit operands
+          const u32 aw = (u32)a, bw = (u32)b;
+          return op == OP_MULH ? (u64)(((i64)(i32)aw * (i64)(i32)bw) >> 32) : op == OP_MULHSU ? (u64)(((i64)(i32)aw * (i64)(u64)bw) >> 32) : ((u64)aw * (u64)bw) >> 32;
+        }
+        if (op == OP_MULH) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; return hi; }
+        if (op == OP_MULHSU) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; return hi; }
+        return wsf::mul64x64(a, b).hi;
+      case OP_DIV: return b == 0 ? ~0ULL : ((i64)a == INT64_MIN && (i64)b == -1) ? a : (u64)((i64)a / (i64)b);
+      case OP_DIVU: return b == 0 ? ~0ULL : a / b;
+      case OP_REM: return b == 0 ? a : ((i64)a == INT64_MIN && (i64)b == -1) ? 0 : (u64)((i64)a % (i64)b);
+      case OP_REMU: return b == 0 ? a : a % b;
+      case OP_MULW: return (u64)(i64)(i32)((u32)a * (u32)b);
+      case OP_DIVW: { i32 x = (i32)a, y = (i32)b; return (u64)(i64)(y == 0 ? -1 : (x == INT32_MIN && y == -1) ? x : x / y); }
+      case OP_DIVUW: { u32 x = (u32)a, y = (u32)b; return (u64)(i64)(i32)(y == 0 ? ~0u : x / y); }
+      case OP_REMW: { i32 x = (i32)a, y = (i32)b; return (u64)(i64)(y == 0 ? x : (x == INT32_MIN && y == -1) ? 0 : x % y); }
+      default: { u32 x = (u32)a, y = (u32)b; return (u64)(i64)(i32)(y == 0 ? x : x % y); }   // OP_REMUW
+    }
+  }
+
   // ---- one decoded instruction. `op` is passed separately so the GPU kernel can hand in a
   // wave-uniform copy (scalar branch over the switch); a = x[rs1], b = second operand.
   WSP_HD void exec(u32 op, const Rec& r, u64 a, u64 b, u64 cur_pc)
@@ -3151,26 +3176,8 @@ template <class MEM, bool DRY = false> struct Lane {
       case OP_SLLW: wx(rd, (u64)(i64)(i32)((u32)a << (b & 31))); break;
       case OP_SRLW: wx(rd, (u64)(i64)(i32)((u32)a >> (b & 31))); break;
       case OP_SRAW: wx(rd, (u64)(i64)((i32)a >> (b & 31))); break;
-      case OP_MUL: wx(rd, a * b); break;                                                     // Hart.cpp:13964-14100
-      case OP_MULH: case OP_MULHSU: case OP_MULHU:
-        if (rv32()) {                                                                        // Hart<uint32_t>: 32-bit operands
-          const u32 aw = (u32)a, bw = (u32)b;
-          wx(rd, op == OP_MULH ? (u64)(((i64)(i32)aw * (i64)(i32)bw) >> 32) : op == OP_MULHSU ? (u64)(((i64)(i32)aw * (i64)(u64)bw) >> 32) : ((u64)aw * (u64)bw) >> 32);
-          break;
-        }
-        if (op == OP_MULH) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; if ((i64)b < 0) hi -= a; wx(rd, hi); }
-        else if (op == OP_MULHSU) { wsf::U128 p = wsf::mul64x64(a, b); u64 hi = p.hi; if ((i64)a < 0) hi -= b; wx(rd, hi); }
-        else wx(rd, wsf::mul64x64(a, b).hi);
-        break;
-      case OP_DIV: wx(rd, b == 0 ? ~0ULL : ((i64)a == INT64_MIN && (i64)b == -1) ? a : (u64)((i64)a / (i64)b)); break;   // Hart.cpp:14111-14170
-      case OP_DIVU: wx(rd, b == 0 ? ~0ULL : a / b); break;
-      case OP_REM: wx(rd, b == 0 ? a : ((i64)a == INT64_MIN && (i64)b == -1) ? 0 : (u64)((i64)a % (i64)b)); break;
-      case OP_REMU: wx(rd, b == 0 ? a : a % b); break;
-      case OP_MULW: wx(rd, (u64)(i64)(i32)((u32)a * (u32)b)); break;
-      case OP_DIVW: { i32 x = (i32)a, y = (i32)b; wx(rd, (u64)(i64)(y == 0 ? -1 : (x == INT32_MIN && y == -1) ? x : x / y)); break; }
-      case OP_DIVUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? ~0u : x / y)); break; }
-      case OP_REMW: { i32 x = (i32)a, y = (i32)b; wx(rd, (u64)(i64)(y == 0 ? x : (x == INT32_MIN && y == -1) ? 0 : x % y)); break; }
-      case OP_REMUW: { u32 x = (u32)a, y = (u32)b; wx(rd, (u64)(i64)(i32)(y == 0 ? x : x % y)); break; }
+      case OP_MUL: case OP_MULH: case OP_MULHSU: case OP_MULHU: case OP_DIV: case OP_DIVU: case OP_REM: case OP_REMU:
+      case OP_MULW: case OP_DIVW: case OP_DIVUW: case OP_REMW: case OP_REMUW: wx(rd, muldiv(op, a, b)); break;
       case OP_ZB: wx(rd, exec_zb(rec_rs3(r), (r.w0 & F_IMM) ? 0 : r.imm, a, b)); break;
       case OP_AUIPC: wx(rd, cur_pc + (u64)(i64)r.imm); break;
       case OP_JAL: {

@@ -227,13 +227,28 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
 // fflags, cannot trap once its rounding mode is known to be legal, and advances all counters by one like any hot step:
 // no HBM state is touched, and the function is small enough to need no callee-saved registers.  handled = 0 sends the
 // instruction to the general path (reserved rounding mode: illegal-instruction trap).
+// CSR accesses the warm path takes for a hot (M-mode) hart: registers that are plain storage behind their masks - a write has no
+// effect on anything but the register - and reads of whatever else does not depend on state the warm path does not hold
+// (mstatus / sstatus: its mstatus is synthetic; the counters: synchronised lazily; mhartid; the vector CSRs: staged in LDS).
+// fflags / frm / fcsr only with mstatus.FS already Dirty (else the access changes mstatus).  Everything else: the general path.
+__device__ __forceinline__ bool wsp_csr_warm_ok(u32 num, bool write, bool fs_dirty)
+{
+  if (num >= C_FFLAGS && num <= C_FCSR) return fs_dirty;
+  switch (num) {
+    case C_MSCRATCH: case C_MEPC: case C_MCAUSE: case C_MTVAL: case C_SSCRATCH: case C_SEPC: case C_SCAUSE: case C_STVAL: return true;
+    case C_MSTATUS: case C_SSTATUS: case C_MCYCLE: case C_MINSTRET: case C_CYCLE: case C_TIME: case C_INSTRET: case C_MHARTID: return false;
+    default: break;
+  }
+  if ((num >= 0x008 && num <= 0x00F) || (num >= 0xC20 && num <= 0xC22) || (num >= 0xB80 && num <= 0xB9F) || (num >= 0xC80 && num <= 0xC9F)) return false;
+  return !write;
+}
 struct WarmRet { u64 thash; u32 fcsr, handled; };
 template <bool TRACE>
-__device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr)
+__device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u64* cold, u32 S_fsd)
 {
   Lane<DevMem> L;
   L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = nullptr; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.S = 0; L.m.lpw_shift = 0;
+  L.m.cold_ = cold; L.m.S = S_fsd >> 1; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
   L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
@@ -244,6 +259,13 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   if (op == OP_ZB) {                                         // bit manipulation: registers only, cannot trap
     const u64 b = (w0 & F_IMM) ? (u64)(i64)imm : L.m.rx(rec_rs2(rec));
     L.wx(rec_rd(rec), L.exec_zb(rec_rs3(rec), (w0 & F_IMM) ? 0 : imm, L.m.rx(rec_rs1(rec)), b));
+  } else if (op >= OP_MUL && op <= OP_REMUW) {               // the M-extension forms the hot loops leave out (mulh*, div*, rem*)
+    L.wx(rec_rd(rec), L.muldiv(op, L.m.rx(rec_rs1(rec)), L.m.rx(rec_rs2(rec))));
+  } else if (op >= OP_CSRRW && op <= OP_CSRRC) {             // Zicsr on plain-storage registers (wsp_csr_warm_ok), M mode
+    const u32 num = (u32)imm & 0xfff;
+    const bool write = op == OP_CSRRW || rec_rs1(rec) != 0;
+    if (!wsp_csr_warm_ok(num, write, (S_fsd & 1) != 0) || L.csr_class(num) != 1) return r;
+    L.exec_csr(rec, op - OP_CSRRW, (w0 & F_IMM) ? (u64)rec_rs1(rec) : (L.m.rx(rec_rs1(rec)) & L.amask()), pc);
   } else {
     const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
     int rm = 0;
@@ -364,6 +386,9 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
 // nothing changed, and the general path executes it.  The hart is register resident: x registers in LDS, pc / privilege /
 // mstatus / digest in registers, the TLB and the PMP rows read from HBM; nothing of the hart's HBM state is loaded or stored
 // beyond that (the four counters advance with the executed count, as for hot steps).
+#ifndef WSP_SWARM
+#define WSP_SWARM 1                                      // 0: build without the translated warm path (A/B measurements)
+#endif
 struct SWarmRet { u64 pc, thash; u32 n, fcsr; };
 template <bool TRACE>
 __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 fcsr, u32 max_n)
@@ -831,34 +856,30 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         need_cold = ncv != 0;
       }
     }
-    if (FP && need_cold && (L.h.flags & (HF_HOT | HF_FS_DIRTY)) == (HF_HOT | HF_FS_DIRTY)) {
-      // F/D computational instruction of a hot hart with FS already Dirty: the warm path (LDS + fflags only)
+    if (need_cold && (L.h.flags & HF_HOT)) {
+      // The warm path (wsp_warm: LDS register files, fflags, plain-storage CSR rows; nothing else of the hart) for a hot hart at
+      // an F / D computational instruction with FS already Dirty, a bit-manipulation instruction, mulh* / div* / rem*, or a
+      // Zicsr access the path can take
       Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
-      if (L.hot_fetch(recs, rec) && (rec.w0 & 0xff) >= OP_FADD && (rec.w0 & 0xff) <= OP_FMV_X2F) {
-        const u32 ln2 = ln_of(d);
-        const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
-        const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr)
-                                        : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr);
-        if (w.handled) {
-          L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
-          need_cold = false;
+      if (L.hot_fetch(recs, rec)) {
+        const u32 wop = rec.w0 & 0xff;
+        const bool fsd = (L.h.flags & HF_FS_DIRTY) != 0;
+        const bool take = (FP && fsd && wop >= OP_FADD && wop <= OP_FMV_X2F) || wop == OP_ZB || (wop >= OP_MULH && wop <= OP_REMUW && wop != OP_MULW) ||
+                          (wop >= OP_CSRRW && wop <= OP_CSRRC);
+        if (take) {
+          const u32 ln2 = ln_of(d);
+          const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
+          u64* const cold = d.cold + (blockIdx.x * 64 + ln2);
+          const u32 sf = (d.S << 1) | (fsd ? 1u : 0u);
+          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, cold, sf)
+                                          : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, cold, sf);
+          if (w.handled) {
+            L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
+            need_cold = false;
+          }
         }
       }
     }
-    if (need_cold && (d.isa & ISA_ZB_ANY) && (L.h.flags & HF_HOT)) {
-      // a Zba / Zbb / Zbs / Zbc / Zicond instruction of a hot hart: the same warm path (registers in LDS, nothing else)
-      Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
-      if (L.hot_fetch(recs, rec) && (rec.w0 & 0xff) == OP_ZB) {
-        const u32 ln2 = ln_of(d);
-        const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
-        const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr)
-                                        : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr);
-        if (w.handled) { L.h.pc += 4; L.h.exec++; L.h.thash = w.thash; need_cold = false; }
-      }
-    }
-#ifndef WSP_SWARM
-#define WSP_SWARM 1                                      // 0: build without the translated warm path (A/B measurements)
-#endif
     const bool swarm_can = WSP_SWARM && need_cold && active && d.tlb_n && recs &&
                            !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc;
     if (swarm_can && swarm_skip) --swarm_skip;
