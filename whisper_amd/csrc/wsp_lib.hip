@@ -107,10 +107,15 @@ struct DevMem {
 };
 
 // ------------------------------------------------------------------------------------------ step kernel
-// Occupancy target: 4 waves per SIMD (128 VGPRs).  The hot loop needs < 64; the out-of-line general path spills a
-// little at this cap, which is cheap at its call frequency (measured: 2 -> 4.8, 4 -> 8.1, 8 -> 6.3 GIPS at 4096 harts).
+// Occupancy target: ONE wave per SIMD, i.e. the whole register file (256 VGPRs + 256 AGPRs) for each wave.  Round 1 ran one hart
+// per wave and needed 4 waves per SIMD to fill the machine (128 VGPRs; measured then: 2 -> 4.8, 4 -> 8.1, 8 -> 6.3 GIPS at 4096
+// harts).  Since the converged loop a wave carries up to 64 harts and one wave per SIMD already saturates the hot loop (196 GIPS
+// at 65536 harts = 1024 waves; batches of more waves simply run in turns), while under the 128-register cap the general path
+// kept the hart's `Lane` in scratch memory - thousands of waves' scratch lives in HBM - and paid ~51 k cycles per general step
+// (-DWSP_PROF).  Measured (profiles/r02/ab_waves_per_eu.jsonl, 4 -> 1): M/S/U fuzz 2.0 -> 6.6 GIPS, Sv39 fuzz 1.2 -> 2.8,
+// random RVV programs 0.59 -> 1.06, compute kernel 12.8 -> 13.0 at 4096 harts and 183 -> 197 at 262144.
 #ifndef WSP_WAVES_PER_EU
-#define WSP_WAVES_PER_EU 4
+#define WSP_WAVES_PER_EU 1
 #endif
 #ifndef WSP_CONVERGED_LOOP
 #define WSP_CONVERGED_LOOP 1
