@@ -1330,8 +1330,12 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     // 13.5 / 13.7 GIPS, 16384 harts lpw 4/16/64 -> 36 / 55 / 57, 65536 harts lpw 16/64 -> 140 / 207).
     lpw = 1;
     while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 1024) lpw <<= 1;
-    // V batches keep lanes free for the vector unit's element loops: at least 8 lanes per hart (the hart's sub-group, wsp_cold)
-    if ((isa & ISA_V) && lpw > 8) lpw = 8;
+    // V batches keep lanes free for the vector unit's element loops (the hart's sub-group, wsp_vwarm): at least 8 lanes per hart at
+    // VLEN 512 and above, 4 below (measured at 16384 harts, one wave per SIMD: vector kernels at VLEN 512 0.42 / 0.63 / 0.43 GIPS
+    // with 4 / 8 / 16 harts per wave, at VLEN 256 0.69 / 1.07 / 1.46 / 0.91 with 4 / 8 / 16 / 32)
+    const u32 vb0 = desc->vlen_bytes ? desc->vlen_bytes : cfg.vlen_bytes ? cfg.vlen_bytes : 64u;
+    const u32 vcap = vb0 >= 64 ? 8u : 16u;
+    if ((isa & ISA_V) && lpw > vcap) lpw = vcap;
   }
   if (lpw == 0 || lpw > 64 || (lpw & (lpw - 1))) return fail(WSP_EINVAL, "lanes_per_wave must be 0 or a power of two <= 64");
   if (isa & ISA_V) {
