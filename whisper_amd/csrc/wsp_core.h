@@ -444,7 +444,8 @@ enum : u32 { HF_CODE_DIRTY = 1, HF_LR_VALID = 2, HF_INH_CY = 4, HF_INH_IR = 8, H
              HF_PMP_ON = 64 /* some PMP entry is not Off */, HF_PMP_MLOCK = 128 /* some locked entry is on: M mode is checked too */,
              HF_RING = 256 /* a commit ring is recording: every step takes the general path, whose commit() writes it */,
              HF_NOTRACE = 512 /* this run folds no commit records (set per launch): commit() returns at once */,
-             HF_VS_DIRTY = 1024 /* mstatus.VS == Dirty (kept by update_hot_flag): a vector write changes no mstatus bit */ };
+             HF_VS_DIRTY = 1024 /* mstatus.VS == Dirty (kept by update_hot_flag): a vector write changes no mstatus bit */,
+             HF_PMP_E0ALL = 2048 /* PMP entry 0 is an active NAPOT region over the whole address space: it decides every access */ };
 
 // Everything a hart reads or writes on (almost) every step: lives in VGPRs during a run slice.
 struct Hot {
@@ -710,7 +711,9 @@ template <class MEM, bool DRY = false> struct Lane {
       if (on) f |= HF_PMP_ON;
       if ((on << 4) & w) f |= HF_PMP_MLOCK;                                               // ... and L (bit 7)
     }
-    h.flags = (h.flags & ~(u32)(HF_PMP_ON | HF_PMP_MLOCK)) | f;
+    // the usual "open everything" setup (pmpaddr0 all ones, NAPOT): entry 0 matches every address and is first in priority
+    if ((((u32)m.cold(CI_PMPCFG0) >> 3) & 3) == 3 && (m.cold(CI_PMPADDR0) & 0x003fffffffffffffULL) == 0x003fffffffffffffULL) f |= HF_PMP_E0ALL;
+    h.flags = (h.flags & ~(u32)(HF_PMP_ON | HF_PMP_MLOCK | HF_PMP_E0ALL)) | f;
   }
   // ---- The address-translation unit (PMP match, Sv39 walk, TLB) reads the hart but never changes it - its side effects are
   // TLB words in HBM - so it works on a small by-value context `Vm` instead of the whole Lane.  On the GPU its large, rarely
@@ -727,6 +730,7 @@ template <class MEM, bool DRY = false> struct Lane {
     {
       const u32 dflt = pm == PRV_M ? 7u : 0u;
       if (!(flags & HF_PMP_ON) || (pm == PRV_M && !(flags & HF_PMP_MLOCK))) return dflt;
+      if (flags & HF_PMP_E0ALL) { const u32 cfg = (u32)m.cold(CI_PMPCFG0) & 0xff; return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u); }
       for (u32 k = 0; k < 8; ++k) {
         const u64 w = m.cold(CI_PMPCFG0 + k);
         if (!(w & 0x1818181818181818ULL)) continue;
@@ -1193,7 +1197,7 @@ template <class MEM, bool DRY = false> struct Lane {
           m.cold(k) = legalize_pmpcfg(m.cold(k), v) & 0x9f9f9f9f9f9f9f9fULL;
           update_pmp_flags();
         } else if (num >= 0x3B0 && num <= 0x3EF) {
-          if (!pmpaddr_locked(num - 0x3B0)) m.cold(CI_PMPADDR0 + (num - 0x3B0)) = v & 0x003fffffffffffffULL;
+          if (!pmpaddr_locked(num - 0x3B0)) { m.cold(CI_PMPADDR0 + (num - 0x3B0)) = v & 0x003fffffffffffffULL; if (num == 0x3B0) update_pmp_flags(); }
         }
         break;
     }
@@ -3395,6 +3399,7 @@ template <class MEM, bool DRY = false> struct Lane {
   {
     const u32 dflt = pm == PRV_M ? 7u : 0u;
     if (!(h.flags & HF_PMP_ON) || (pm == PRV_M && !(h.flags & HF_PMP_MLOCK))) return dflt;
+    if (h.flags & HF_PMP_E0ALL) { const u32 cfg = (u32)m.cold(CI_PMPCFG0) & 0xff; return (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u); }
     const u64 last = page + 4095;
     for (u32 k = 0; k < 8; ++k) {
       const u64 w = m.cold(CI_PMPCFG0 + k);

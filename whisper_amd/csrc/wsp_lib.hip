@@ -233,34 +233,44 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
 // no HBM state is touched, and the function is small enough to need no callee-saved registers.  handled = 0 sends the
 // instruction to the general path (reserved rounding mode: illegal-instruction trap).
 // CSR accesses the warm path takes for a hot (M-mode) hart: registers that are plain storage behind their masks - a write has no
-// effect on anything but the register - and reads of whatever else does not depend on state the warm path does not hold
-// (mstatus / sstatus: its mstatus is synthetic; the counters: synchronised lazily; mhartid; the vector CSRs: staged in LDS).
-// fflags / frm / fcsr only with mstatus.FS already Dirty (else the access changes mstatus).  Everything else: the general path.
+// effect on anything but the register - mstatus / sstatus (the path loads the hart's mstatus for these, stores it back and
+// recomputes the hot / FS / VS flags), and reads of whatever else does not depend on state the warm path does not hold (the
+// counters: synchronised lazily; mhartid; the vector CSRs: staged in LDS).  fflags / frm / fcsr only with mstatus.FS already Dirty
+// (else the access changes mstatus).  Everything else - satp, mie / mip, the PMP file, mcountinhibit ... - is the general path's.
 __device__ __forceinline__ bool wsp_csr_warm_ok(u32 num, bool write, bool fs_dirty)
 {
   if (num >= C_FFLAGS && num <= C_FCSR) return fs_dirty;
   switch (num) {
     case C_MSCRATCH: case C_MEPC: case C_MCAUSE: case C_MTVAL: case C_SSCRATCH: case C_SEPC: case C_SCAUSE: case C_STVAL: return true;
-    case C_MSTATUS: case C_SSTATUS: case C_MCYCLE: case C_MINSTRET: case C_CYCLE: case C_TIME: case C_INSTRET: case C_MHARTID: return false;
+    case C_MSTATUS: case C_SSTATUS: return true;
+    case C_MCYCLE: case C_MINSTRET: case C_CYCLE: case C_TIME: case C_INSTRET: case C_MHARTID: return false;
     default: break;
   }
   if ((num >= 0x008 && num <= 0x00F) || (num >= 0xC20 && num <= 0xC22) || (num >= 0xB80 && num <= 0xB9F) || (num >= 0xC80 && num <= 0xC9F)) return false;
   return !write;
 }
-struct WarmRet { u64 thash; u32 fcsr, handled; };
+struct WarmRet { u64 thash, pc; u32 fcsr, handled, flags; };
 template <bool TRACE>
-__device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u64* cold, u32 S_fsd)
+__device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
 {
+  const DevState& d = *dp;
+  const u32 ln = ln_of(d), slot = blockIdx.x * 64 + ln, isa = d.isa;
+  const size_t S = d.S;
   Lane<DevMem> L;
-  L.m.xs = (u64*)((char*)wsp_lds + x_off); L.m.fs = (u64*)((char*)wsp_lds + f_off);
-  L.m.cold_ = cold; L.m.S = S_fsd >> 1; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.lpw_shift = 0;
+  L.m.xs = wsp_lds + ln * WSP_XSLOTS; L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
+  L.m.cold_ = d.cold + slot; L.m.S = d.S; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
-  L.h.flags = 0; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
+  L.h.flags = flags; L.h.status = ST_RUNNING; L.h.priv = PRV_M; L.h.exec = 0; L.h.cycle = 0; L.h.instret = 0; L.h.retired = 0;
   L.s.chg = 0; L.s.ireg = 0; L.s.freg = 0; L.s.gen_csr = 0; L.s.vreg = 0; L.s.vgroup = 0; L.s.ival = 0; L.s.fval = 0; L.s.maddr = 0; L.s.mval = 0; L.s.lva = 0; L.s.lpa = 0;
   Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = raw;
-  const u32 op = w0 & 0xff;
-  WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0;
+  const u32 op = w0 & 0xff, size = (w0 & F_SIZE4) ? 4 : 2;
+  WarmRet r; r.thash = thash; r.fcsr = fcsr; r.handled = 0; r.pc = pc + size; r.flags = flags;
+  // Zicsr and mret work on the hart's own mstatus (one HBM word in, and out again if it changed); the other cases never look at
+  // more of it than FS, which is Dirty whenever they are called
+  const bool sys = (op >= OP_CSRRW && op <= OP_CSRRC) || op == OP_MRET;
+  u64 mst0 = 0;
+  if (sys) { mst0 = d.hot64[(size_t)H64_MSTATUS * S + slot]; L.h.mstatus = mst0; }
   if (op == OP_ZB) {                                         // bit manipulation: registers only, cannot trap
     const u64 b = (w0 & F_IMM) ? (u64)(i64)imm : L.m.rx(rec_rs2(rec));
     L.wx(rec_rd(rec), L.exec_zb(rec_rs3(rec), (w0 & F_IMM) ? 0 : imm, L.m.rx(rec_rs1(rec)), b));
@@ -269,15 +279,30 @@ __device__ __noinline__ WarmRet wsp_warm(u32 isa, u32 x_off, u32 f_off, u32 w0, 
   } else if (op >= OP_CSRRW && op <= OP_CSRRC) {             // Zicsr on plain-storage registers (wsp_csr_warm_ok), M mode
     const u32 num = (u32)imm & 0xfff;
     const bool write = op == OP_CSRRW || rec_rs1(rec) != 0;
-    if (!wsp_csr_warm_ok(num, write, (S_fsd & 1) != 0) || L.csr_class(num) != 1) return r;
+    if (!wsp_csr_warm_ok(num, write, (flags & HF_FS_DIRTY) != 0) || L.csr_class(num) != 1) return r;
     L.exec_csr(rec, op - OP_CSRRW, (w0 & F_IMM) ? (u64)rec_rs1(rec) : (L.m.rx(rec_rs1(rec)) & L.amask()), pc);
+  } else if (op == OP_MRET) {                                // mret from M mode (Hart.cpp:12247-12336): mstatus, privilege, pc = mepc
+    u64 v = L.h.mstatus; const u32 saved = (u32)(v >> MST_MPP_SH) & 3;
+    v = (v & ~MST_MIE) | ((v & MST_MPIE) ? MST_MIE : 0);
+    const u32 least = L.ext(ISA_U) ? PRV_U : L.ext(ISA_S) ? PRV_S : PRV_M;
+    v = (v & ~(3ULL << MST_MPP_SH)) | ((u64)least << MST_MPP_SH);
+    v |= MST_MPIE;
+    if (saved != PRV_M && !L.ext(CFG_KEEP_MPRV)) v &= ~MST_MPRV;
+    L.csr_store(C_MSTATUS, v); L.s.chg |= CH_MSTATUS;
+    r.pc = L.m.cold(CI_MEPC) & L.epc_rmask(); L.h.priv = saved;
+    d.hot32[(size_t)H32_PRIV * S + slot] = saved;
   } else {
     const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
     int rm = 0;
     if (uses_rm && !L.fp_rm((u32)imm & 7, rm)) return r;
     L.exec_fp(rec, L.m.rx(rec_rs1(rec)), pc);
   }
-  L.template commit<TRACE>(pc, raw, (w0 & F_SIZE4) ? 4 : 2, PRV_M, 0);
+  L.template commit<TRACE>(pc, raw, size, PRV_M, 0);
+  if (sys) {
+    if (L.h.mstatus != mst0) d.hot64[(size_t)H64_MSTATUS * S + slot] = L.h.mstatus;
+    L.update_hot_flag();                                     // privilege / MPRV / FS / VS may have changed (as the general step does)
+    r.flags = L.h.flags;
+  }
   r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = 1;
   return r;
 }
@@ -870,16 +895,12 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         const u32 wop = rec.w0 & 0xff;
         const bool fsd = (L.h.flags & HF_FS_DIRTY) != 0;
         const bool take = (FP && fsd && wop >= OP_FADD && wop <= OP_FMV_X2F) || wop == OP_ZB || (wop >= OP_MULH && wop <= OP_REMUW && wop != OP_MULW) ||
-                          (wop >= OP_CSRRW && wop <= OP_CSRRC);
+                          (wop >= OP_CSRRW && wop <= OP_CSRRC) || wop == OP_MRET;
         if (take) {
-          const u32 ln2 = ln_of(d);
-          const u32 xo = ln2 * (WSP_XSLOTS * 8), fo = (d.lpw + ln2) * (WSP_XSLOTS * 8);
-          u64* const cold = d.cold + (blockIdx.x * 64 + ln2);
-          const u32 sf = (d.S << 1) | (fsd ? 1u : 0u);
-          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, cold, sf)
-                                          : wsp_warm<false>(d.isa, xo, fo, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, cold, sf);
+          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(dp, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags)
+                                          : wsp_warm<false>(dp, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags);
           if (w.handled) {
-            L.h.pc += (rec.w0 & F_SIZE4) ? 4 : 2; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr;
+            L.h.pc = w.pc; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; L.h.flags = w.flags;
             need_cold = false;
           }
         }
