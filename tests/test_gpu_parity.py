@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact on
 status, stop value, pc, executed/retired counts, state digest, memory digest and commit-trace
 digest for every hart."""
+import re
+
 import pytest
 
 import simutil as S
@@ -490,3 +492,13 @@ def test_cli_and_riscof_batch(tmp_path):
     assert cli.main(["--isa", rp.isa, "--target", str(e), "--maxinst", "3", "--quiet"]) == 0
     assert cli.main(["--isa", rp.isa, "--target", str(e), "--maxinst", "3", "--failoninstlimit", "--quiet"]) == 1
     assert cli.main(["--isa", rp.isa, "--target", str(e), "--harts", "5", "--quiet"]) == 0
+    # BASELINE configs[0] as the README runs it: the rv32imc program, `--xlen 32` alone and with an explicit ISA, log == the oracle's
+    r32 = WL.readme_rv32_program()
+    e32, log32 = tmp_path / "r32.elf", tmp_path / "r32.log"
+    e32.write_bytes(r32.elf)
+    assert cli.main(["--xlen", "32", "--target", str(e32), "--quiet"]) == 0
+    assert cli.main(["--isa", r32.isa, "--target", str(e32), "--logfile", str(log32), "--quiet"]) == 0
+    ro32, _, olog32 = S.run_oracle(r32, log_cap=1000)
+    lines32 = log32.read_text().splitlines()
+    assert len([ln for ln in lines32 if not ln.endswith("+")]) == len(olog32) == ro32["exec"]
+    assert all(re.match(r"#\d+ 0  M [0-9a-f]{8} ", ln) for ln in lines32)                     # RV32 layout: 8-digit pc column

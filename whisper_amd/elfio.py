@@ -110,22 +110,36 @@ def write_elf32(segments, entry, symbols=None) -> bytes:
 
 
 def read_elf(elf: bytes):
-    """Returns (entry, [(paddr, bytes, flags)], {symbol: addr}). Test helper mirroring the C++ loader."""
-    assert elf[:4] == b"\x7fELF" and elf[4] == 2 and elf[5] == 1
-    (_, _, _, entry, phoff, shoff, _, _, phentsize, phnum, shentsize, shnum, shstrndx) = struct.unpack_from(
-        "<HHIQQQIHHHHHH", elf, 16)
+    """Returns (entry, [(paddr, bytes, flags)], {symbol: addr}) of a little-endian ELF64 or ELF32 image, as the C++ loader reads it."""
+    if elf[:4] != b"\x7fELF" or elf[4] not in (1, 2) or elf[5] != 1:
+        raise ValueError("not a little-endian ELF32 / ELF64 image")
+    wide = elf[4] == 2
+    if wide:
+        (_, _, _, entry, phoff, shoff, _, _, phentsize, phnum, shentsize, shnum, shstrndx) = struct.unpack_from("<HHIQQQIHHHHHH", elf, 16)
+    else:
+        (_, _, _, entry, phoff, shoff, _, _, phentsize, phnum, shentsize, shnum, shstrndx) = struct.unpack_from("<HHIIIIIHHHHHH", elf, 16)
     segs = []
     for i in range(phnum):
-        t, fl, o, va, pa, fsz, msz, al = struct.unpack_from("<IIQQQQQQ", elf, phoff + i * phentsize)
+        if wide:
+            t, fl, o, va, pa, fsz, msz, al = struct.unpack_from("<IIQQQQQQ", elf, phoff + i * phentsize)
+        else:
+            t, o, va, pa, fsz, msz, fl, al = struct.unpack_from("<IIIIIIII", elf, phoff + i * phentsize)
         if t == 1 and fsz:
             segs.append((pa, elf[o:o + fsz], fl))
     syms = {}
-    shs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+    if wide:
+        shs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+    else:
+        shs = [struct.unpack_from("<IIIIIIIIII", elf, shoff + i * shentsize) for i in range(shnum)]
     for sh in shs:
-        if sh[1] == 2:
+        if sh[1] == 2:                                       # SHT_SYMTAB: name type flags addr offset size link info addralign entsize
             st = shs[sh[6]]
-            for k in range(sh[5] // 24):
-                n, info, other, shndx, val, size = struct.unpack_from("<IBBHQQ", elf, sh[4] + k * 24)
+            esz = 24 if wide else 16
+            for k in range(sh[5] // esz):
+                if wide:
+                    n, info, other, shndx, val, size = struct.unpack_from("<IBBHQQ", elf, sh[4] + k * esz)
+                else:
+                    n, val, size, info, other, shndx = struct.unpack_from("<IIIBBH", elf, sh[4] + k * esz)
                 end = elf.index(b"\0", st[4] + n)
                 name = elf[st[4] + n:end].decode()
                 if name:
