@@ -74,6 +74,79 @@ def test_snapshot_directory_format(tmp_path):
         SN.load(FakeBatch(0x80000000, 3 << 20, vlenb=16), 0, d, 0x80000000, 3 << 20)
 
 
+class StrictBatch(FakeBatch):
+    """FakeBatch that refuses pokes of CSRs outside the device's file exactly as wsp_batch_poke does (csr_loc in wsp_lib.hip)."""
+    MODELLED = ({0x001, 0x002, 0x003, 0x100, 0x104, 0x105, 0x106, 0x10A, 0x140, 0x141, 0x142, 0x143, 0x144, 0x180, 0x300, 0x302, 0x303,
+                 0x304, 0x305, 0x306, 0x30A, 0x320, 0x340, 0x341, 0x342, 0x343, 0x344, 0xB00, 0xB02, 0x008, 0x00F, 0xC20, 0xC21}
+                | set(range(0x3A0, 0x3B0, 2)) | set(range(0x3B0, 0x3F0)))
+
+    def poke(self, hart, res, idx, value):
+        if res == W.RES_CSR and idx not in self.MODELLED:
+            raise W.WspError(W.EUNSUPPORTED, "CSR not modelled")
+        super().poke(hart, res, idx, value)
+
+
+def _reference_registers_file(vlenb):
+    """The line set Hart::saveSnapshotRegs writes for a default rv64imafdcvsu hart that has run a little (snapshot.cpp:29-100): the
+    header lines, non-zero x / f registers, misa first, then every implemented CSR that is non-zero or resets to non-zero in number
+    order - which always includes dcsr (reset 0x40000003, CsRegs.cpp:5328-5331), vlenb on a V hart, the cycle / time / instret
+    shadows once the counters moved, mhartid when non-zero - then all 32 vector registers."""
+    lines = ["pm 3", "vm 0", "po 1234", "pr 1200", "pb 0x0", "pc 0x80000040", "elp 0",
+             "x 1 0x80000004", "x 10 0xffffffffffffffff", "f 2 0xffffffff3f800000",
+             "c 0x301 0x800000000034112d",
+             "c 0x1 0x1", "c 0x3 0x21", "c 0x100 0x200006000", "c 0x300 0xa00007800", "c 0x305 0x80000100", "c 0x341 0x8000003c",
+             "c 0x342 0x2", "c 0x3a0 0x1f", "c 0x3b0 0x3fffffffffffff", "c 0x7b0 0x40000003", "c 0xb00 0x4d2", "c 0xb02 0x4b0",
+             "c 0xc00 0x4d2", "c 0xc01 0x4d2", "c 0xc02 0x4b0", "c 0xc22 0x%x" % vlenb, "c 0xf14 0x5"]
+    lines += ["v %d 0x%s" % (i, "%02x" % i * vlenb) for i in range(32)]
+    return "\n".join(lines) + "\n"
+
+
+def test_snapshot_load_accepts_what_the_reference_writes(tmp_path):
+    d = tmp_path / "ref"
+    d.mkdir()
+    (d / "registers").write_text(_reference_registers_file(64))
+    (d / "usedblocks").write_text(f"{0x80000000} {1 << 20}\n")
+    with gzip.open(d / "memory", "wb") as gz:
+        gz.write(bytes(range(256)) * 4096)
+    (d / "time").write_text("1234\n")
+    (d / "mtimecmp").write_text("0x0\n")
+    b = StrictBatch(0x80000000, 1 << 20, vlenb=64)
+    SN.load(b, 0, str(d), b.base, b.size)
+    assert b.reg[(W.RES_PC, 0)] == 0x80000040 and b.reg[(W.RES_PC, 1)] == 1234 and b.reg[(W.RES_PC, 2)] == 1200 and b.reg[(W.RES_PC, 3)] == 3
+    assert b.reg[(W.RES_CSR, 0x300)] == 0xa00007800 and b.reg[(W.RES_CSR, 0x3B0)] == 0x3fffffffffffff and b.reg[(W.RES_CSR, 0xB02)] == 0x4b0
+    assert b.reg[(W.RES_CSR, 0x003)] == 0x21
+    assert (W.RES_CSR, 0x7B0) not in b.reg and (W.RES_CSR, 0xC22) not in b.reg and (W.RES_CSR, 0xC00) not in b.reg and (W.RES_CSR, 0xF14) not in b.reg
+    assert b.reg[(W.RES_V, 7)] == bytes([7]) * 64
+    assert bytes(b.mem[:256]) == bytes(range(256))
+    # state this library cannot hold is refused, not dropped: a dcsr away from reset, a vlenb of another size, an unmodelled CSR
+    for bad in ("c 0x7b0 0x40000003", "c 0x7b0 0x400000c3"), ("c 0xc22 0x40", "c 0xc22 0x20"), ("c 0xf14 0x5", "c 0x7a1 0x1"):
+        (d / "registers").write_text(_reference_registers_file(64).replace(*bad))
+        with pytest.raises((ValueError, W.WspError)):
+            SN.load(StrictBatch(0x80000000, 1 << 20, vlenb=64), 0, str(d), 0x80000000, 1 << 20)
+
+
+@pytest.mark.gpu
+def test_snapshot_load_of_a_reference_style_directory_on_the_device(tmp_path):
+    """The same directory into a real batch: wsp_batch_poke takes every line that carries state."""
+    d = tmp_path / "ref"
+    d.mkdir()
+    (d / "registers").write_text(_reference_registers_file(64))
+    (d / "usedblocks").write_text(f"{0x80000000} {1 << 16}\n")
+    with gzip.open(d / "memory", "wb") as gz:
+        gz.write(bytes(range(256)) * 256)
+    b = W.Batch(2, isa="rv64imafdcvsu_zicsr", mem_base=0x80000000, mem_size=1 << 16, vlen_bytes=64)
+    try:
+        SN.load(b, 1, str(d), 0x80000000, 1 << 16)
+        assert b.peek(1, W.RES_PC, 0) == 0x80000040 and b.peek(1, W.RES_PC, 1) == 1234 and b.peek(1, W.RES_PC, 3) == 3
+        assert b.peek(1, W.RES_X, 10) == 2**64 - 1 and b.peek(1, W.RES_F, 2) == 0xffffffff3f800000
+        assert b.peek(1, W.RES_CSR, 0x3B0) == 0x3fffffffffffff and b.peek(1, W.RES_CSR, 0x3A0) == 0x1f and b.peek(1, W.RES_CSR, 0x003) == 0x21
+        assert b.peek(1, W.RES_V, 9) == bytes([9]) * 64
+        assert b.peek(1, W.RES_MEM, 0x80000000, 16) == bytes(range(16))
+        assert b.peek(0, W.RES_PC, 1) == 0
+    finally:
+        b.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["fuzz", "sv39", "rvv", "rv32"])
 def test_snapshot_resume_equals_uninterrupted_run(kind, tmp_path):

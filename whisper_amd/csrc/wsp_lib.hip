@@ -197,6 +197,9 @@ __device__ __forceinline__ u64 wsp_stop_at(u64 slice_end, u64 max_exec, u64 max_
 // One compiled body serves traced and untraced runs (HF_NOTRACE in the lane's flags makes commit() return at once): what an
 // untraced run executes here is exactly what the traced parity tests execute.  The arguments fit the 16 argument registers (2 for
 // dp + 13 for HotRegs), so HotRegs travels in registers; wave and lane are recomputed here.
+#ifdef WSP_INSPECT   // tuning aid (tools/inspect_step.sh): the step kernels alone, the out-of-line paths as external calls
+__device__ HotRegs wsp_cold(const DevState* dp, HotRegs hr);
+#else
 __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
 {
   const DevState& d = *dp;
@@ -226,6 +229,7 @@ __device__ __noinline__ HotRegs wsp_cold(const DevState* dp, HotRegs hr)
   WSP_PROF_ADD(2, WSP_PROF_T() - pt0); WSP_PROF_ADD(1, 1);
   return r;
 }
+#endif
 
 // The "warm" path: one F/D computational instruction (arithmetic, convert, compare, move, classify) of a hart that is
 // hot and whose mstatus.FS is already Dirty.  Such an instruction reads and writes only the LDS register files and
@@ -250,6 +254,9 @@ __device__ __forceinline__ bool wsp_csr_warm_ok(u32 num, bool write, bool fs_dir
   return !write;
 }
 struct WarmRet { u64 thash, pc; u32 fcsr, handled, flags; };
+#ifdef WSP_INSPECT
+template <bool TRACE> __device__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags);
+#else
 template <bool TRACE>
 __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
 {
@@ -306,6 +313,7 @@ __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u3
   r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = 1;
   return r;
 }
+#endif
 
 // The vector warm path: one vector instruction (OP-V, unit-stride / strided / mask load or store) of a hart that is hot and whose
 // mstatus.VS is already Dirty, executed by the hart's whole SUB-GROUP - its own lane l and the otherwise idle lanes l + lpw,
@@ -324,6 +332,9 @@ __device__ __forceinline__ u64 wsp_uni64(u64 v) { return (u64)wsp_uni32((u32)v) 
 // in scalar registers - the unit's decode and dispatch then run on the scalar unit (the sub-groups of a wave of replicas hold the
 // same word, and even a mixed wave pays no more than the divergent form would).
 struct VWarmArgs { const Rec* recs; u64 text_lo, text_hi, tohost; };
+#ifdef WSP_INSPECT
+__device__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags, u32 max_n);
+#else
 __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags, u32 max_n)
 {
   const DevState& d = *dp;
@@ -408,6 +419,7 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
   WarmRet r; r.thash = L.h.thash; r.fcsr = L.h.fcsr; r.handled = n_done;
   return r;
 }
+#endif
 
 // The translated warm path: S / U-mode harts under Sv39 (never hot: the hot loops run M-mode code at physical addresses).  Each
 // lane runs its own hart through Lane::fast_step_translated - TLB-hit fetch and data translation, PMP by page, the pre-decoded
@@ -420,6 +432,9 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
 #define WSP_SWARM 1                                      // 0: build without the translated warm path (A/B measurements)
 #endif
 struct SWarmRet { u64 pc, thash; u32 n, fcsr; };
+#ifdef WSP_INSPECT
+template <bool TRACE> __device__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 fcsr, u32 max_n);
+#else
 template <bool TRACE>
 __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64 pc, u64 thash, u32 flags, u32 fcsr, u32 max_n)
 {
@@ -450,6 +465,7 @@ __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64
   r.pc = L.h.pc; r.thash = L.h.thash; r.n = n; r.fcsr = L.h.fcsr;
   return r;
 }
+#endif
 
 // Wave-wide minimum of a u32 (all 64 lanes participate).
 __device__ __forceinline__ u32 wave_min_u32(u32 v)

@@ -31,6 +31,30 @@ _BLOCK = 1 << 20
 _VIEWS = {0x001, 0x002, 0x100, 0x104, 0x144, 0x009, 0x00A}
 
 
+_DCSR_RESET = 0x40000003                                     # CsRegs.cpp:5328-5331: prv = M, the rest clear
+
+
+def _derived_or_fixed(b, n, v):
+    """CSR lines every snapshot written by the reference holds (saveSnapshotRegs walks all implemented CSRs that are non-zero or
+    reset to non-zero, snapshot.cpp:72-83) but that carry no state of their own here: True = skip the line.  A value that would
+    need state this library does not model raises instead of being dropped."""
+    if n == 0x7B0:                                           # dcsr: debug mode is not modelled; anything but its reset value is state
+        if v != _DCSR_RESET:
+            raise ValueError(f"snapshot dcsr {v:#x}: debug-mode state is not modelled")
+        return True
+    if n in (0x7B1, 0x7B2, 0x7B3):                           # dpc, dscratch0/1: meaningful only in debug mode
+        return True
+    if n == 0xC22:                                           # vlenb: fixed by the batch
+        if b.vlen_bytes and v != b.vlen_bytes:
+            raise ValueError(f"snapshot vlenb {v} does not match the batch's vector register size {b.vlen_bytes}")
+        return True
+    if 0xC00 <= n <= 0xC1F or 0xC80 <= n <= 0xC9F:           # cycle / time / instret / hpmcounter shadows of the M-mode counters
+        return True
+    if n in (0xF11, 0xF12, 0xF13, 0xF14, 0xF15):             # mvendorid marchid mimpid mhartid mconfigptr: read-only identity
+        return True
+    return False
+
+
 def _peek_csr(b, hart, n):
     try:
         return b.peek(hart, W.RES_CSR, n)
@@ -129,6 +153,8 @@ def load(b: "W.Batch", hart: int, path: str, mem_base: int, mem_size: int) -> No
                     continue
                 if n in (0xC20, 0xC21, 0x008, 0x00F):
                     deferred.append((n, v))
+                    continue
+                if _derived_or_fixed(b, n, v):
                     continue
                 try:
                     b.poke(hart, W.RES_CSR, n, v)
