@@ -36,7 +36,8 @@ enum { WSP_ST_RUNNING = 0,
 
 /* Resources for peek/poke (Hart::peekIntReg/pokeIntReg ... Hart.hpp:219-325, Hart.cpp:1345-1560). */
 /* WSP_RES_PC takes an index: 0 pc; 1 executed-instruction count (the log's tag, the snapshot's "po"); 2 retired-instruction count
- * ("pr"); 3 privilege mode ("pm": 0 U, 1 S, 3 M; Hart::privilegeMode / setPrivilegeMode, snapshot.cpp:40, 270). */
+ * ("pr"); 3 privilege mode ("pm": 0 U, 1 S, 3 M; Hart::privilegeMode / setPrivilegeMode, snapshot.cpp:40, 270); 4 (peek only) the
+ * hart's stop state WSP_ST_* (Hart::hasTargetProgramFinished is `== WSP_ST_STOP_TOHOST`). */
 enum { WSP_RES_PC = 0, WSP_RES_X = 1, WSP_RES_F = 2, WSP_RES_CSR = 3, WSP_RES_MEM = 4, WSP_RES_V = 5 /* whole vector register, vlen_bytes bytes */ };
 
 /* wsp_batch_run flags */

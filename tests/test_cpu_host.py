@@ -413,6 +413,21 @@ allrec = (W.Result * (per * world)).from_buffer_copy(b"".join(parts))
 ok = len(parts) == world and tmax == float(world) and tot == sum(r.exec_count for r in allrec)
 mine = [(r.state_hash, r.exec_count) for r in allrec[lo:hi]] == [(r.state_hash, r.exec_count) for r in recs]
 distinct = len(set(r.state_hash for r in allrec)) == per * world
+# strong split of ONE list of 7 systems over the ranks (uneven: 3 + 4), gathered, against the whole list run by one rank
+total = 7
+slo, shi = shard.partition(total, world)[rank]
+def one(i):
+    r, _, _ = S.run_oracle(p, seed_a0=WL.compute_seed(i), seed_mem=i, hart_id=i, max_inst=2000)
+    return (r["status"], r["exec"], r["state_hash"], r["mem_hash"], r["trace_hash"])
+srecs = (W.Result * (shi - slo))()
+for k, i in enumerate(range(slo, shi)):
+    st, ex, sh, mh, th = one(i)
+    srecs[k].status = st; srecs[k].exec_count = ex; srecs[k].state_hash = sh; srecs[k].mem_hash = mh; srecs[k].trace_hash = th
+sparts = shard.gather_results(bytes(srecs), dist)
+sall = (W.Result * total).from_buffer_copy(b"".join(sparts))
+strong_ok = [len(x) // C.sizeof(W.Result) for x in sparts] == [hi_ - lo_ for lo_, hi_ in shard.partition(total, world)]
+strong_ok = strong_ok and [(r.status, r.exec_count, r.state_hash, r.mem_hash, r.trace_hash) for r in sall] == [one(i) for i in range(total)]
+ok = ok and strong_ok
 # one write per rank: print() with several arguments writes them piece by piece, and the two ranks share one pipe
 # (that interleaving - "RANK RANK1  0OK" - was the intermittent failure of this test)
 sys.stdout.write("RANK %d %s\n" % (rank, "OK" if ok and mine and distinct else "BAD")); sys.stdout.flush()

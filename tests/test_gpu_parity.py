@@ -376,24 +376,7 @@ def test_commit_ring_against_reference_rvv_capture():
         b.close()
 
 
-def _variant(p, k):
-    """A distinct program from a generated one: the k-th variant XORs k into the immediate field of one 32-bit word of the code
-    (both in the ELF image and in the segment list the oracle loads).  Whatever the patched word decodes to - another immediate,
-    another instruction, an illegal one - device and oracle run the same bytes."""
-    if k == 0:
-        return p
-    import copy
-    paddr, data, flags = p.segments[0]
-    off = (len(data) // 2 + 4 * (k % 17)) & ~3
-    word = int.from_bytes(data[off:off + 4], "little") ^ ((k & 0xfff) << 20)
-    q = copy.copy(p)
-    nd = data[:off] + word.to_bytes(4, "little") + data[off + 4:]
-    q.segments = [(paddr, nd, flags)] + list(p.segments[1:])
-    at = p.elf.find(data)
-    assert at >= 0
-    q.elf = p.elf[:at] + nd + p.elf[at + len(data):]
-    q.name = f"{p.name}.v{k}"
-    return q
+_variant = WL.variant
 
 
 def test_load_elf_many_equals_one_by_one():

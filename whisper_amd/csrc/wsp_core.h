@@ -87,7 +87,7 @@ enum Op : u32 {
 struct Rec {
   u32 w0;     // op[7:0] rd[12:8] rs1[17:13] rs2[22:18] rs3[27:23] F_SIZE4[28] F_IMM[29] F_DBL[30]
   i32 imm;
-  u32 pad;    // hot-loop operand offsets, filled by finish_rec(): LDS byte offset of x[rs1] | x[rs2] << 16 (x0 -> zero slot 32)
+  u32 pad;    // hot-loop operand fields, filled by finish_rec(): LDS byte offset of x[rs1] | handler class << 9 | offset of x[rs2] << 16
   u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval.  Last: the untraced hot loop
               // loads only the first three words
 };
@@ -97,10 +97,29 @@ WSP_HD u32 rec_rd(const Rec& r) { return (r.w0 >> 8) & 31; }
 WSP_HD u32 rec_rs1(const Rec& r) { return (r.w0 >> 13) & 31; }
 WSP_HD u32 rec_rs2(const Rec& r) { return (r.w0 >> 18) & 31; }
 WSP_HD u32 rec_rs3(const Rec& r) { return (r.w0 >> 23) & 31; }
+// Handler classes of the hand-written converged loop (wsp_conv_core.h): Rec.pad bits 15:9.  0 = not in its inline subset.
+enum : u32 { HC_BAD = 0, HC_ADD, HC_SUB, HC_SLL, HC_SLT, HC_SLTU, HC_XOR, HC_SRL, HC_SRA, HC_OR, HC_AND, HC_ADDW, HC_SUBW, HC_SLLW,
+             HC_SRLW, HC_SRAW, HC_MUL, HC_MULW, HC_AUIPC, HC_JAL, HC_JALR, HC_BEQ, HC_BNE, HC_BLT, HC_BGE, HC_BLTU, HC_BGEU,
+             HC_LB, HC_LH, HC_LW, HC_LD, HC_LBU, HC_LHU, HC_LWU, HC_SB, HC_SH, HC_SW, HC_SD, HC_NOP, HC_FLW, HC_FLD, HC_FSW,
+             HC_FSD, HC_COUNT };
+WSP_HD u32 hclass_of(u32 op)
+{
+  if (op >= OP_ADD && op <= OP_SRAW) return HC_ADD + (op - OP_ADD);
+  if (op >= OP_BEQ && op <= OP_BGEU) return HC_BEQ + (op - OP_BEQ);
+  if (op >= OP_LB && op <= OP_LWU) return HC_LB + (op - OP_LB);
+  if (op >= OP_SB && op <= OP_SD) return HC_SB + (op - OP_SB);
+  if (op >= OP_FLW && op <= OP_FSD) return HC_FLW + (op - OP_FLW);
+  switch (op) {
+    case OP_MUL: return HC_MUL; case OP_MULW: return HC_MULW; case OP_AUIPC: return HC_AUIPC; case OP_JAL: return HC_JAL;
+    case OP_JALR: return HC_JALR; case OP_NOP: return HC_NOP; default: return HC_BAD;
+  }
+}
+// hot-loop operand fields: LDS byte offsets of x[rs1] (bits 8:0) and x[rs2] (bits 24:16; x0 and immediate forms -> the zero slot
+// 32), handler class (bits 15:9)
 WSP_HD void finish_rec(Rec& r)
 {
   const u32 s1 = rec_rs1(r), s2 = (r.w0 & F_IMM) ? 0 : rec_rs2(r);
-  r.pad = ((s1 ? s1 : 32u) * 8u) | (((s2 ? s2 : 32u) * 8u) << 16);
+  r.pad = ((s1 ? s1 : 32u) * 8u) | (((s2 ? s2 : 32u) * 8u) << 16) | (hclass_of(r.w0 & 0xff) << 9);
 }
 WSP_HD Rec mk(u32 op, u32 rd, u32 rs1, u32 rs2, i32 imm, u32 flags = 0, u32 rs3 = 0)
 { Rec r; r.w0 = op | (rd << 8) | (rs1 << 13) | (rs2 << 18) | (rs3 << 23) | flags; r.imm = imm; r.raw = 0; r.pad = 0; return r; }

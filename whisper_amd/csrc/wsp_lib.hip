@@ -26,6 +26,7 @@ __device__ unsigned long long wsp_prof[16];
 #define WSP_PROF_T() 0ULL
 #endif
 #include "wsp_core.h"
+#include "wsp_conv_core.h"
 #include "wsp_config.h"
 #include "wsp_disasm.h"
 #include "../../include/whisper_amd.h"
@@ -119,6 +120,9 @@ struct DevMem {
 #endif
 #ifndef WSP_CONVERGED_LOOP
 #define WSP_CONVERGED_LOOP 1
+#endif
+#ifndef WSP_CONV_ASM
+#define WSP_CONV_ASM 1                                   // 0: untraced converged waves run the C++ loop too (A/B measurements)
 #endif
 
 __device__ __forceinline__ u32 ln_of(const DevState& d)
@@ -604,13 +608,24 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         u8* const gsink = (u8*)(d.cold + (size_t)CI_COUNT * S + (blockIdx.x * 64 + ln_of(d)));
         u32 vpc = can ? (u32)off64 : 0xffffffffu;          // lanes that take no part never match a scheduled pc
         u32 vit = 0, ncv = 0, left_it = n;
+#if WSP_CONV_ASM
+        // untraced: the hand-written loop (wsp_conv_core.h), same contract; its record offsets are 32-bit (text below 512 MiB)
+        const bool use_asm = !(TRACE && tr) && tlen <= (1u << 29);
+        if (use_asm) {
+          const bool fsd_all = FP && __all(!can || fsd);
+          const u32 cfg = (u32)__builtin_amdgcn_readfirstlane((int)((rv32 ? 2u : 0u) | (fsd_all ? 4u : 0u) | (boxd ? 8u : 0u)));
+          const u32 amhi = (u32)__builtin_amdgcn_readfirstlane((int)(rv32 ? 0u : 0xffffffffu));
+          const u32 tlen_ct = (u32)__builtin_amdgcn_readfirstlane((int)(zca ? tlen : 0u));
+          conv_core(recs_u, 0 - mbase, msize, tlo, thi, 0 - tlo, tlen_ct, amhi, cfg, d.lpw_shift, foff, n, xb, L.m.arena, tohost, vpc, vit, ncv);
+        } else {
+#endif
         u32 upc = wave_min_dpp(vpc);
         SQ q = *(SQP)(recs_u + ((u64)upc << 3));
         do {
           // operand reads first (every lane reads its own block: lanes outside the group discard the values), the rest of
           // the decode runs on the scalar unit while they are in flight
           const u32 ofs = q.z;
-          u64 a = *(const u64*)(ldsb + (xb + (ofs & 0xffffu)));
+          u64 a = *(const u64*)(ldsb + (xb + (ofs & 0x1ffu)));
           u64 b2 = *(const u64*)(ldsb + (xb + (ofs >> 16)));
           const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 raw = q.w;
           const u32 op = w0 & 0xff;
@@ -738,6 +753,9 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
           if (nupc != spc) q = *(SQP)(recs_u + ((u64)nupc << 3));
           upc = nupc;
         } while (--left_it);
+#if WSP_CONV_ASM
+        }
+#endif
         if (can) { L.h.exec += vit; L.h.pc = tlo + vpc; }
         need_cold = ncv != 0;
       } else if (can) {
@@ -760,7 +778,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         do {
           const u32 w0 = q.x; const i32 imm = (i32)q.y; const u32 ofs = q.z; const u32 raw = RecQ<TRACE>::raw(q);
           const u32 op = w0 & 0xff;
-          const u64 a = *(const u64*)(ldsb + (xb + (ofs & 0xffffu)));
+          const u64 a = *(const u64*)(ldsb + (xb + (ofs & 0x1ffu)));
           const u64 b2 = *(const u64*)(ldsb + (xb + (ofs >> 16)));         // x[rs2]; the zero slot for immediate forms
           u64* const rdp = (u64*)(ldsb + (xb + ((w0 >> 5) & 0xf8u)));      // rd * 8 (slot 0 = sink)
           const u64 simm = (u64)(i64)imm;
@@ -1527,6 +1545,11 @@ static int patch_stop(wsp_batch* b, u32 pg, u64 stop_pc)
   if ((w0 & 0xff) == OP_SLOWFETCH || (w0 & 0xff) == OP_STOPCHK) return WSP_OK;
   w0 = (w0 & ~0xffu) | OP_STOPCHK;
   HIPOK(hipMemcpy(w0p, &w0, 4, hipMemcpyHostToDevice));
+  // ... and out of the hand-written loop's inline subset too (its dispatch goes by the handler class in Rec.pad)
+  u32* padp = &p.d_recs[(stop_pc - p.text_lo) / 2].pad; u32 pad = 0;
+  HIPOK(hipMemcpy(&pad, padp, 4, hipMemcpyDeviceToHost));
+  pad &= ~0xfe00u;
+  HIPOK(hipMemcpy(padp, &pad, 4, hipMemcpyHostToDevice));
   return WSP_OK;
 }
 
@@ -1934,9 +1957,9 @@ extern "C" int wsp_batch_peek(wsp_batch* b, uint32_t hart, uint32_t res, uint64_
   DevState& d = b->d; u32 s = slot_of(d, hart); size_t S = d.S;
   u64 v = 0;
   switch (res) {
-    case WSP_RES_PC: {   // idx 0: pc; 1: executed-instruction count (the log's tag, snapshot "po"); 2: retired-instruction count ("pr"); 3: privilege mode ("pm")
-      if (idx > 3) return fail(WSP_ERANGE, "pc resource index");
-      if (idx == 3) { u32 pm; HIPOK(hipMemcpy(&pm, d.hot32 + H32_PRIV * S + s, 4, hipMemcpyDeviceToHost)); v = pm; memcpy(val, &v, std::min<size_t>(size, 8)); return WSP_OK; }
+    case WSP_RES_PC: {   // idx 0: pc; 1: executed-instruction count (the log's tag, snapshot "po"); 2: retired-instruction count ("pr"); 3: privilege mode ("pm"); 4: stop state (WSP_ST_*, peek only)
+      if (idx > 4) return fail(WSP_ERANGE, "pc resource index");
+      if (idx >= 3) { u32 pm; HIPOK(hipMemcpy(&pm, d.hot32 + (idx == 3 ? H32_PRIV : H32_STATUS) * S + s, 4, hipMemcpyDeviceToHost)); v = pm; memcpy(val, &v, std::min<size_t>(size, 8)); return WSP_OK; }
       const u32 row = idx == 0 ? H64_PC : idx == 1 ? H64_EXEC : H64_RETIRED;
       HIPOK(hipMemcpy(&v, d.hot64 + row * S + s, 8, hipMemcpyDeviceToHost));
       if (idx) { memcpy(val, &v, std::min<size_t>(size, 8)); return WSP_OK; }

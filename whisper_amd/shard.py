@@ -21,16 +21,25 @@ def weak_range(per_rank: int, rank: int) -> tuple[int, int]:
 
 
 def gather_results(raw: bytes, dist=None, device=None) -> list[bytes]:
-    """All-gather the packed wsp_result records of every rank (equal length per rank).  Returns the
-    list of byte strings in rank (= hart) order; world size 1 or dist None returns [raw]."""
+    """All-gather the packed wsp_result records of every rank.  Ranks may hold different numbers of records (a strong split of a
+    list that does not divide evenly): lengths are exchanged first and the payloads padded to the longest.  Returns the list of
+    byte strings in rank (= hart) order; world size 1 or dist None returns [raw]."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [bytes(raw)]
-    rec = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    world = dist.get_world_size()
+    n = torch.tensor([len(raw)], dtype=torch.int64)
+    if device is not None:
+        n = n.to(device)
+    lens = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(t.item()) for t in lens]
+    longest = max(lens)
+    rec = torch.frombuffer(bytearray(raw) + bytearray(longest - len(raw)), dtype=torch.uint8) if longest else torch.empty(0, dtype=torch.uint8)
     if device is not None:
         rec = rec.to(device)
-    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    out = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(out, rec)
-    return [bytes(t.cpu().numpy().tobytes()) for t in out]
+    return [bytes(t.cpu().numpy().tobytes())[:k] for t, k in zip(out, lens)]
 
 
 def reduce_totals(seconds: float, units: float, dist=None, device=None) -> tuple[float, float]:

@@ -422,6 +422,26 @@ def compute_kernel(iters: int = 4, fp: bool = True, paged: bool = False) -> Prog
     return _finish(a, "compute-sv39" if paged else "compute", isa, d, mem_size=1 << 16, max_inst=1 << 26, meta=dict(iters=iters))
 
 
+def variant(p: "Program", k: int) -> "Program":
+    """A distinct program from a generated one: the k-th variant XORs k into the immediate field of one 32-bit word of the code
+    (both in the ELF image and in the segment list the oracle loads).  Whatever the patched word decodes to - another immediate,
+    another instruction, an illegal one - device and oracle run the same bytes."""
+    if k == 0:
+        return p
+    import copy
+    paddr, data, flags = p.segments[0]
+    off = (len(data) // 2 + 4 * (k % 17)) & ~3
+    word = int.from_bytes(data[off:off + 4], "little") ^ ((k & 0xfff) << 20)
+    q = copy.copy(p)
+    nd = data[:off] + word.to_bytes(4, "little") + data[off + 4:]
+    q.segments = [(paddr, nd, flags)] + list(p.segments[1:])
+    at = p.elf.find(data)
+    assert at >= 0
+    q.elf = p.elf[:at] + nd + p.elf[at + len(data):]
+    q.name = f"{p.name}.v{k}"
+    return q
+
+
 # ------------------------------------------------------------------------------------------ fuzz
 def fuzz_program(seed: int, n: int = 400, fp: bool = True, compressed: bool = True, interrupts: bool = False) -> Program:
     """Random instruction mix (M-mode, bare): ALU, loads/stores into mapped and unmapped addresses,
