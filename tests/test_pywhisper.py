@@ -29,7 +29,7 @@ def test_module_layout_matches_py_bindings():
 
 @pytest.mark.gpu
 def test_step_run_and_attributes_against_the_oracle(tmp_path):
-    p = WL.fuzz_program(11, n=120)
+    p = WL.fuzz_program(12, n=120)                      # ends with a tohost write (Hart.run has no instruction limit of its own)
     cfg = tmp_path / "cfg.json"; cfg.write_text(json.dumps({"isa": p.isa, "xlen": 64}))
     elf = tmp_path / "p.elf"; elf.write_bytes(p.elf)
     with pytest.raises(ValueError):
@@ -75,7 +75,7 @@ def test_step_run_and_attributes_against_the_oracle(tmp_path):
             h1.nonsense = 1
         m = sy.memory(1)
         m.poke32(p.mem_base + 0x100, 0xdeadbeef); m.poke8(p.mem_base + 0x104, 0x7f)
-        assert m.peek32(p.mem_base + 0x100) == 0xdeadbeef and m.peek16(p.mem_base + 0x102) == 0xdead and m.peek64(p.mem_base + 0x100) == 0x7fdeadbeef
+        assert m.peek32(p.mem_base + 0x100) == 0xdeadbeef and m.peek16(p.mem_base + 0x102) == 0xdead and m.peek64(p.mem_base + 0x100) & 0xffffffffff == 0x7fdeadbeef
         with pytest.raises(RuntimeError):
             m.peek32(p.mem_base - 4)
         assert h0.disass_inst(0x00a58533) == W.disassemble(0x00a58533)

@@ -87,7 +87,7 @@ enum Op : u32 {
 struct Rec {
   u32 w0;     // op[7:0] rd[12:8] rs1[17:13] rs2[22:18] rs3[27:23] F_SIZE4[28] F_IMM[29] F_DBL[30]
   i32 imm;
-  u32 pad;    // hot-loop operand fields, filled by finish_rec(): LDS byte offset of x[rs1] | handler class << 9 | offset of x[rs2] << 16
+  u32 pad;    // hot-loop operand offsets, filled by finish_rec(): LDS byte offset of x[rs1] | x[rs2] << 16 (x0 -> zero slot 32)
   u32 raw;    // instruction bits as fetched (16-bit masked when compressed): trace + mtval.  Last: the untraced hot loop
               // loads only the first three words
 };
@@ -97,29 +97,11 @@ WSP_HD u32 rec_rd(const Rec& r) { return (r.w0 >> 8) & 31; }
 WSP_HD u32 rec_rs1(const Rec& r) { return (r.w0 >> 13) & 31; }
 WSP_HD u32 rec_rs2(const Rec& r) { return (r.w0 >> 18) & 31; }
 WSP_HD u32 rec_rs3(const Rec& r) { return (r.w0 >> 23) & 31; }
-// Handler classes of the hand-written converged loop (wsp_conv_core.h): Rec.pad bits 15:9.  0 = not in its inline subset.
-enum : u32 { HC_BAD = 0, HC_ADD, HC_SUB, HC_SLL, HC_SLT, HC_SLTU, HC_XOR, HC_SRL, HC_SRA, HC_OR, HC_AND, HC_ADDW, HC_SUBW, HC_SLLW,
-             HC_SRLW, HC_SRAW, HC_MUL, HC_MULW, HC_AUIPC, HC_JAL, HC_JALR, HC_BEQ, HC_BNE, HC_BLT, HC_BGE, HC_BLTU, HC_BGEU,
-             HC_LB, HC_LH, HC_LW, HC_LD, HC_LBU, HC_LHU, HC_LWU, HC_SB, HC_SH, HC_SW, HC_SD, HC_NOP, HC_FLW, HC_FLD, HC_FSW,
-             HC_FSD, HC_COUNT };
-WSP_HD u32 hclass_of(u32 op)
-{
-  if (op >= OP_ADD && op <= OP_SRAW) return HC_ADD + (op - OP_ADD);
-  if (op >= OP_BEQ && op <= OP_BGEU) return HC_BEQ + (op - OP_BEQ);
-  if (op >= OP_LB && op <= OP_LWU) return HC_LB + (op - OP_LB);
-  if (op >= OP_SB && op <= OP_SD) return HC_SB + (op - OP_SB);
-  if (op >= OP_FLW && op <= OP_FSD) return HC_FLW + (op - OP_FLW);
-  switch (op) {
-    case OP_MUL: return HC_MUL; case OP_MULW: return HC_MULW; case OP_AUIPC: return HC_AUIPC; case OP_JAL: return HC_JAL;
-    case OP_JALR: return HC_JALR; case OP_NOP: return HC_NOP; default: return HC_BAD;
-  }
-}
-// hot-loop operand fields: LDS byte offsets of x[rs1] (bits 8:0) and x[rs2] (bits 24:16; x0 and immediate forms -> the zero slot
-// 32), handler class (bits 15:9)
+// hot-loop operand fields: LDS byte offsets of x[rs1] (low half) and x[rs2] (high half; x0 and immediate forms -> the zero slot 32)
 WSP_HD void finish_rec(Rec& r)
 {
   const u32 s1 = rec_rs1(r), s2 = (r.w0 & F_IMM) ? 0 : rec_rs2(r);
-  r.pad = ((s1 ? s1 : 32u) * 8u) | (((s2 ? s2 : 32u) * 8u) << 16) | (hclass_of(r.w0 & 0xff) << 9);
+  r.pad = ((s1 ? s1 : 32u) * 8u) | (((s2 ? s2 : 32u) * 8u) << 16);
 }
 WSP_HD Rec mk(u32 op, u32 rd, u32 rs1, u32 rs2, i32 imm, u32 flags = 0, u32 rs3 = 0)
 { Rec r; r.w0 = op | (rd << 8) | (rs1 << 13) | (rs2 << 18) | (rs3 << 23) | flags; r.imm = imm; r.raw = 0; r.pad = 0; return r; }
@@ -145,6 +127,62 @@ WSP_HD Rec lower_rv32(Rec r)
   }
   r.w0 = (r.w0 & ~0xffu) | n;
   return r;
+}
+
+// ---------------------------------------------------------------------------------- hot records
+// The hand-written converged loop (wsp_conv_core.h) reads its own image of the program: one 32-byte record per 2-byte slot, every
+// field already in the form the loop uses it, so that a step spends no scalar instruction on decoding:
+//   w0 handler offset (class * 512)   w1 instruction size   w2:w3 immediate, sign-extended to 64 bits
+//   w4 / w5 VGPR index (slot * 2) of x[rs1] / x[rs2]; x0, immediate forms, loads, stores and jumps -> the zero slot 32
+//   w6 class-specific: VGPR index of x[rd]; stores: of the data register; flw / fld / fsw / fsd: LDS byte offset of the f register
+//   w7 class-specific: branches / jal: the target as a text offset; HC_PURE_*: Rec.w0
+// What does not depend on the hart is folded at pre-decode: auipc is an add of the constant pc + imm to the zero slot, jal's link
+// value is its immediate, branch targets are checked against the text once (a target outside it - or any taken transfer without
+// the C extension, which can trap - gets a class that is fine only while nobody takes it).
+enum : u32 { HC_BAD = 0, HC_ADD, HC_SUB, HC_SLL, HC_SLT, HC_SLTU, HC_XOR, HC_SRL, HC_SRA, HC_OR, HC_AND, HC_ADDW, HC_SUBW, HC_SLLW,
+             HC_SRLW, HC_SRAW, HC_MUL, HC_MULW, HC_JAL, HC_JALR,
+             HC_BEQ, HC_BNE, HC_BLT, HC_BGE, HC_BLTU, HC_BGEU,                    // forward: falls through when nobody takes it
+             HC_BEQ_B, HC_BNE_B, HC_BLT_B, HC_BGE_B, HC_BLTU_B, HC_BGEU_B,        // backward: falls through when everybody takes it
+             HC_BEQ_O, HC_BNE_O, HC_BLT_O, HC_BGE_O, HC_BLTU_O, HC_BGEU_O,        // target cannot be inlined: fine while not taken
+             HC_LB, HC_LH, HC_LW, HC_LD, HC_LBU, HC_LHU, HC_LWU, HC_SB, HC_SH, HC_SW, HC_SD, HC_NOP, HC_FLW, HC_FLD, HC_FSW, HC_FSD,
+             HC_PURE_INT,                                                         // mulh* div* rem* Zb*: x[rd] = f(x[rs1], x[rs2] | imm)
+             HC_PURE_FP_F, HC_PURE_FP_X,                                          // F / D computational: result to f[rd] / to x[rd]
+             HC_COUNT };
+struct HRec { u32 w[8]; };
+WSP_HD HRec mk_hrec(const Rec& r, u32 isa, u64 text_lo, u32 text_len, u32 upc)
+{
+  const u32 op = r.w0 & 0xff, rs1 = rec_rs1(r), rs2 = rec_rs2(r), rd = rec_rd(r);
+  const bool rv32 = (isa & ISA_RV32) != 0, zca = (isa & ISA_C) != 0;
+  const u32 size = (r.w0 & F_SIZE4) ? 4u : 2u, zero = 64u;
+  u32 hc = HC_BAD, i1 = (rs1 ? rs1 : 32u) * 2u, i2 = ((r.w0 & F_IMM) || !rs2) ? zero : rs2 * 2u, i3 = rd * 2u, aux = 0;
+  i64 simm = (i64)r.imm;
+  const u64 pc = text_lo + upc;
+  if (op >= OP_ADD && op <= OP_SRAW) hc = HC_ADD + (op - OP_ADD);
+  else if (op == OP_MUL) hc = HC_MUL;
+  else if (op == OP_MULW) hc = HC_MULW;
+  else if (op == OP_NOP) hc = HC_NOP;
+  else if (op == OP_AUIPC) { const u64 v = pc + (u64)(i64)r.imm; simm = rv32 ? (i64)(i32)v : (i64)v; hc = HC_ADD; i1 = zero; i2 = zero; }
+  else if (op == OP_JAL) {
+    const u32 t = upc + (u32)r.imm;
+    if (zca && t < text_len) { const u64 link = pc + size; simm = rv32 ? (i64)(i32)link : (i64)link; hc = HC_JAL; i1 = zero; i2 = zero; aux = t & ~1u; }
+  } else if (op == OP_JALR) { if (zca) { hc = HC_JALR; i2 = zero; } }
+  else if (op >= OP_BEQ && op <= OP_BGEU) {
+    const u32 t = upc + (u32)r.imm;
+    i2 = rs2 ? rs2 * 2u : zero;
+    if (zca && t < text_len) { hc = (r.imm < 0 ? HC_BEQ_B : HC_BEQ) + (op - OP_BEQ); aux = t & ~1u; }
+    else hc = HC_BEQ_O + (op - OP_BEQ);
+  } else if (op >= OP_LB && op <= OP_LWU) { hc = HC_LB + (op - OP_LB); i2 = zero; }
+  else if (op >= OP_SB && op <= OP_SD) { hc = HC_SB + (op - OP_SB); i2 = zero; i3 = (rs2 ? rs2 : 32u) * 2u; }
+  else if (op == OP_FLW || op == OP_FLD) { hc = HC_FLW + (op - OP_FLW); i2 = zero; i3 = rd * 8u; }
+  else if (op == OP_FSW || op == OP_FSD) { hc = HC_FLW + (op - OP_FLW); i2 = zero; i3 = rs2 * 8u; }
+  else if ((op >= OP_MULH && op <= OP_REMUW) || op == OP_ZB) { hc = HC_PURE_INT; aux = r.w0; }
+  else if (op >= OP_FADD && op <= OP_FMV_X2F) {
+    const bool to_x = op == OP_FCMP || op == OP_FCVT_F2I || op == OP_FMV_F2X || op == OP_FCLASS;
+    hc = to_x ? HC_PURE_FP_X : HC_PURE_FP_F; i2 = zero; aux = r.w0;
+  }
+  HRec h;
+  h.w[0] = hc << 9; h.w[1] = size; h.w[2] = (u32)(u64)simm; h.w[3] = (u32)((u64)simm >> 32); h.w[4] = i1; h.w[5] = i2; h.w[6] = i3; h.w[7] = aux;
+  return h;
 }
 
 // OP_ZB functions.  Register forms keep a parameter in Rec.imm (ZB_SHADD: shift | 8 for the .uw forms; ZB_CLZ / CTZ / CPOP / REV8:

@@ -257,6 +257,8 @@ __device__ __forceinline__ bool wsp_csr_warm_ok(u32 num, bool write, bool fs_dir
   if ((num >= 0x008 && num <= 0x00F) || (num >= 0xC20 && num <= 0xC22) || (num >= 0xB80 && num <= 0xB9F) || (num >= 0xC80 && num <= 0xC9F)) return false;
   return !write;
 }
+__device__ __forceinline__ u32 wsp_uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 wsp_uni64(u64 v) { return (u64)wsp_uni32((u32)v) | ((u64)wsp_uni32((u32)(v >> 32)) << 32); }
 struct WarmRet { u64 thash, pc; u32 fcsr, handled, flags; };
 #ifdef WSP_INSPECT
 template <bool TRACE> __device__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags);
@@ -265,10 +267,14 @@ template <bool TRACE>
 __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
 {
   const DevState& d = *dp;
-  const u32 ln = ln_of(d), slot = blockIdx.x * 64 + ln, isa = d.isa;
-  const size_t S = d.S;
+  // Every lane active at the call holds the SAME instruction (the call site groups lanes by instruction): the record goes into
+  // scalar registers, and with it the whole dispatch below - which operation, which format, which rounding mode - runs as scalar
+  // branches instead of exec-masked regions every lane walks through (measured: 3.3 us -> see profiles/r03_ubench_*.jsonl).
+  w0 = wsp_uni32(w0); imm = (i32)wsp_uni32((u32)imm); raw = wsp_uni32(raw);
+  const u32 ln = ln_of(d), slot = blockIdx.x * 64 + ln, isa = wsp_uni32(d.isa);
+  const size_t S = wsp_uni32(d.S);
   Lane<DevMem> L;
-  L.m.xs = wsp_lds + ln * WSP_XSLOTS; L.m.fs = wsp_lds + (d.lpw + ln) * WSP_XSLOTS;
+  L.m.xs = wsp_lds + ln * WSP_XSLOTS; L.m.fs = wsp_lds + (wsp_uni32(d.lpw) + ln) * WSP_XSLOTS;
   L.m.cold_ = d.cold + slot; L.m.S = d.S; L.m.vcsr_ = nullptr; L.m.tlb_ = nullptr; L.tlb_n = 0; L.m.voff = 0; L.vlenb = 0; L.m.arena = nullptr; L.m.lpw_shift = 0;
   L.isa = isa; L.mem_base = 0; L.mem_size = 0; L.tohost = ~0ULL; L.text_lo = 0; L.text_hi = 0; L.hart_id = 0;
   L.h.pc = pc; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.fcsr = fcsr; L.h.thash = thash;
@@ -328,8 +334,6 @@ __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u3
 // vector-ls.cpp:156-247).  The unit runs dry (Lane<DevMem, true>): whatever would trap, stop the hart or change mstatus changes nothing and
 // comes back as handled = 0; the general path then executes that instruction in full.  mstatus is synthetic: M mode, VS Dirty, FS
 // Dirty or Off (Off sends an FP vector instruction of a hart whose FS is not Dirty yet to the general path).
-__device__ __forceinline__ u32 wsp_uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ u64 wsp_uni64(u64 v) { return (u64)wsp_uni32((u32)v) | ((u64)wsp_uni32((u32)(v >> 32)) << 32); }
 // Returns in `handled` the number of instructions completed: the call goes on with the instructions that follow while they are
 // vector instructions too (at most max_n, the hart's remaining budget), so that a strip-mined loop body costs one call.
 // Lanes are grouped by instruction word: each distinct word present is executed once, for the lanes that hold it, with the word
@@ -920,24 +924,39 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         need_cold = ncv != 0;
       }
     }
+    bool wtake = false; Rec wrec; wrec.w0 = 0; wrec.imm = 0; wrec.raw = 0; wrec.pad = 0;
     if (need_cold && (L.h.flags & HF_HOT)) {
       // The warm path (wsp_warm: LDS register files, fflags, plain-storage CSR rows; nothing else of the hart) for a hot hart at
       // an F / D computational instruction with FS already Dirty, a bit-manipulation instruction, mulh* / div* / rem*, or a
       // Zicsr access the path can take
       Rec rec; rec.w0 = 0; rec.imm = 0; rec.raw = 0; rec.pad = 0;
       if (L.hot_fetch(recs, rec)) {
+        wrec = rec;
         const u32 wop = rec.w0 & 0xff;
         const bool fsd = (L.h.flags & HF_FS_DIRTY) != 0;
         const bool take = (FP && fsd && wop >= OP_FADD && wop <= OP_FMV_X2F) || wop == OP_ZB || (wop >= OP_MULH && wop <= OP_REMUW && wop != OP_MULW) ||
                           (wop >= OP_CSRRW && wop <= OP_CSRRC) || wop == OP_MRET;
-        if (take) {
-          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(dp, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags)
-                                          : wsp_warm<false>(dp, rec.w0, rec.imm, rec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags);
+        wtake = take;
+      }
+    }
+    // one call per distinct instruction among the lanes that take the warm path (a converged wave: one call for all of them)
+    if (__any(wtake)) {
+      unsigned long long pend = __ballot(wtake);
+      while (pend) {
+        const int leader = __ffsll((long long)pend) - 1;
+        const u32 uw0 = (u32)__builtin_amdgcn_readlane((int)wrec.w0, leader), uraw = (u32)__builtin_amdgcn_readlane((int)wrec.raw, leader);
+        const u32 uimm = (u32)__builtin_amdgcn_readlane((int)wrec.imm, leader);
+        const bool mine = wtake && wrec.w0 == uw0 && wrec.raw == uraw && (u32)wrec.imm == uimm;
+        if (mine) {
+          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags)
+                                          : wsp_warm<false>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags);
           if (w.handled) {
             L.h.pc = w.pc; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; L.h.flags = w.flags;
             need_cold = false;
           }
+          wtake = false;
         }
+        pend &= ~__ballot(mine);
       }
     }
     const bool swarm_can = WSP_SWARM && need_cold && active && d.tlb_n && recs &&
