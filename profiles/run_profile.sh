@@ -5,8 +5,8 @@
 # (FETCH_SIZE and WRITE_SIZE need separate runs: 3 + 2 TCC counters), 5. SQ instruction mix.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02_a}; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03_a}; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-traced-leg"
 timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/kt.json 2> $O/kt.err
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py $ARGS > $O/pmc_fetch.json 2> $O/pmc_fetch.err

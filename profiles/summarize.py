@@ -29,5 +29,7 @@ for p in ("pmc_fetch", "pmc_write", "pmc_sq"):
             e[f"{c}_per_launch"] = v / len(disp[k])
 if len(sys.argv) > 3:
     out["_commit"] = sys.argv[3]
+# the kernel sources this profile describes (bench.py drops counter-derived fields when they have changed since)
+out["_csrc_digest"] = json.load(open(os.path.join(src, "bench.json")))["config"].get("csrc_digest")
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_per_launch.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "step" in k or k == "_commit"}, indent=1))
