@@ -245,3 +245,38 @@ def test_gpu_stop_address_and_retired_limit(lanes):
         assert res[i] == ro, i
         lag += ro["exec"] > ro["retired"]
     assert lag > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trace", [True, False])
+def test_gpu_stop_address_is_virtual_under_sv39(trace):
+    """The stop address is compared with the pc (Hart.cpp:6025), a virtual address: S / U code mapped at VA != PA runs on the
+    translated warm path, whose records sit at physical slots - the pc compare there ends the run, not a record patch."""
+    progs, stops, want = [], [], []
+    for s in range(24):
+        p = WL.sv39_program(s)
+        _, _, log = S.run_oracle(p, log_cap=p.max_inst)
+        body = [k for k, c in enumerate(log) if 0x10000 <= c.pc < 0x14000]
+        if len(body) < 40:
+            continue
+        k = body[len(body) // 2 + (s % 7)]
+        progs.append(p); stops.append({"stop_pc": log[k].pc})
+        ro, _, _ = S.run_oracle(p, hart_id=len(progs) - 1, stop_pc=log[k].pc)
+        assert ro["status"] == rvoracle.STOP_ADDR and ro["pc"] == log[k].pc
+        want.append(ro)
+    assert len(progs) >= 12
+    p0 = progs[0]
+    b = W.Batch(len(progs), isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, tlb_entries=p0.meta.get("tlb_entries", 0))
+    try:
+        for i, p in enumerate(progs):
+            b.load_elf_bytes(p.elf, i, i + 1)
+            b.set_stop(max_inst=p.max_inst, stop_pc=stops[i]["stop_pc"], lo=i, hi=i + 1)
+        assert b.run(trace_hash=trace) == 0
+        res = [r.as_dict() for r in b.results()]
+    finally:
+        b.close()
+    for i, ro in enumerate(want):
+        ro = dict(ro)
+        if not trace:
+            ro["trace_hash"] = 0
+        assert res[i] == ro, (i, progs[i].name)

@@ -63,7 +63,7 @@ def make(kind, iters):
     a.addi(9, 9, -1)
     a.bnez(9, "loop")
     WL._exit_tohost(a, S["tohost"])
-    return WL._finish(a, "ubench-" + kind, "rv64imafdc_zicsr", d, mem_size=1 << 16, max_inst=1 << 40)
+    return WL._finish(a, "ubench-" + kind, "rv64imafdc_zicsr", d, mem_size=1 << 16, max_inst=iters * 66 + 4096)
 
 
 def main():

@@ -5,32 +5,49 @@
 // inline subset.  Measured on the C++ loop (tools/ubench.py, 4096 harts = one wave per SIMD, profiles/r03_ubench_*.jsonl): an
 // `add` step took 487 clocks for ~60 wave instructions, and every extra level of the compiler's compare-chain dispatch cost ~38
 // clocks (`xor`, 15 levels down: 870 clocks) - with one wave per SIMD a taken branch is a full instruction-fetch restart and
-// nothing hides it.  So this loop has exactly two taken branches per simulated instruction (the dispatch jump and the back edge):
+// nothing hides it; an F / D instruction cost 7 000 clocks, almost all of it the way out of the loop and back.  So:
 //
-//  * threaded dispatch: the pre-decoded record carries a handler class (Rec.pad bits 15:9, HC_*), handlers sit at a fixed
-//    512-byte stride and the dispatch is `s_and / s_add / s_addc / s_setpc_b64`;
+//  * threaded dispatch, two taken branches per simulated instruction: the loop reads its own 32-byte "hot records" (HRec,
+//    wsp_core.h: handler offset, size, 64-bit immediate, VGPR indices of the operands, branch target - nothing left to decode),
+//    handlers sit at a fixed 512-byte stride, and the dispatch is `s_add / s_addc / s_swappc_b64`; the handler returns with
+//    `s_setpc_b64` into the step's epilogue, which falls through into the next step's code (three record buffers A / B / T in
+//    rotation, so records are never copied);
 //  * the x register file of every lane lives in VGPRs v[128:193] (slot s = x[s] for 1..31, slot 0 = write sink for rd = x0,
 //    slot 32 = constant zero which reads of x0 and immediate forms are redirected to), indexed with s_set_gpr_idx_on by the
 //    wave-uniform register numbers - no LDS round trip on the dependent chain; LDS <-> VGPR copies happen at entry and exit only;
-//  * records come through the scalar cache, one step ahead; taken branches prefetch their target record while the compare runs;
+//  * two modes.  Converged: every eligible lane stands at the scheduled pc - no membership test, no per-lane pc or retire-count
+//    update (both are implied by the scalar state and written back when the mode is left).  Diverged: exactly the lanes whose pc
+//    is the scheduled one execute; after every control transfer the minimum pc over all lanes is scheduled (min-pc
+//    reconvergence), and the loop is back in converged mode as soon as all lanes agree;
+//  * records come through the scalar cache, one step ahead; branches and jal request their target's record while the compare runs;
+//  * F / D computational instructions, mulh* / div* / rem* and Zb* never leave the loop: their handlers marshal the operands and
+//    call the compiled C++ semantics (wsp_pure_fp / wsp_pure_int in wsp_lib.hip: pure functions of their arguments) through the
+//    standard calling convention.  Everything this loop keeps lives in registers that convention preserves or that the callees do
+//    not reach (VGPRs >= 128: the build checks the callees' register counts; callee-saved SGPRs); the record buffers are re-read after a call;
 //  * a step whose lanes are not all fine (access outside the arena, tohost, text, misaligned, target outside the text, an op
-//    outside the inline subset) changes nothing for ANY lane of the group and ends the loop with ncv = 1 on those lanes: the
-//    general path executes that instruction (same contract as the C++ loop, coarser grain: rare events only).
+//    outside the inline subset, a reserved rounding mode) changes nothing for ANY lane of the group and ends the loop with ncv = 1
+//    on those lanes: the general path executes that instruction (same contract as the C++ loop, coarser grain: rare events only).
 //
 // gfx940-family wait states observed by hand (nothing inside an asm statement is padded by the compiler): VALU write of an
-// SGPR / VCC -> VALU read of it: 2; VALU write of a VGPR -> v_readlane / DPP read: 1 / 2; v_cmp -> s_and_saveexec: interlocked.
+// SGPR / VCC -> VALU read of it: 2; VALU write of a VGPR -> v_readlane / v_readfirstlane / DPP read: 1 / 1 / 2.
 #pragma once
 
 #if defined(__HIP_DEVICE_COMPILE__)
 
-// ---- fixed registers (all in the clobber list)
-//  s[40:43] q (current record)   s[44:47] qn (sequential successor)   s[48:51] qt (branch / jump target)
-//  s52 upc  s53 spc  s54 iterations left  s55 s56 scratch  s57 rd * 2  s[58:59] sign-extended immediate
-//  s[60:61] handler table base  s[62:63] exec at loop top  s[64:65] dispatch target  s[66:71] scratch pairs
-//  s[72:73] exec at entry  s[74:75] -mem_base  s[76:77] mem_size  s[78:79] text_lo  s[80:81] text_hi  s[82:83] -text_lo
-//  s[84:85] eligible lanes  s[86:87] record base  s88 text length (0 when control transfers cannot be inlined)
-//  s89 high address mask (rv32: 0)  s90 cfg (bit 1 rv32, bit 2 FS dirty, bit 3 D)  s91 lpw shift  s92 f block offset  s93 target  s98 next pc
+// ---- fixed registers (all in the clobber list, together with everything a callee may clobber: s0-s31, vcc, the caller-saved VGPRs).
+// The calling convention keeps s34-s39, s48-s55, s64-s71, s80-s87 (and s96+) across a call: what must survive the calls of
+// wsp_pure_* lives there.  The record buffers and scratch sit in the blocks a callee may overwrite: after such a call the loop
+// re-reads the next record (L_resume).
+//  callee-saved: s34 upc  s35 spc  s36 steps left - 1  s37 its value when converged mode was entered  s38 record word 6  s39 word 7
+//                s48 mode (0 converged, 1 diverged)  s49 cfg (bit 1 rv32, bit 2 FS dirty, bit 3 D)  s50 lpw shift  s51 f block offset
+//                s52 isa  s53 text length  s[54:55] return address of the step  s[64:65] handler table
+//                s[66:67] exec before the membership test (diverged mode)  s[68:69] exec at entry  s[70:71] eligible lanes
+//                s[80:81] hot records  s[82:83] text_lo
+//  clobbered by calls: s[40:47] record buffer A  s[56:63] buffer B  s[72:79] buffer T (branch / jump target)
+//                s88 s89 scratch  s[90:91] dispatch target  s[92:93] s[94:95] scratch pairs
 //  v[128:193] x file  v[194:195] a  v[196:197] b  v[198:199] b + imm  v[200:201] result  v[202:209] scratch  v[210:211] tohost + 4
+//  v[212:213] -mem_base  v[214:221] mem_size - 1 / 2 / 4 / 8  v[222:223] text_lo  v[224:225] text_hi  v[226:227] -text_lo
+//  v228 high address mask  v229 xb  v[230:231] arena  v[232:233] tohost  v234 pc  v235 retired  v236 ncv  v237 fcsr  v[238:241] scratch
 
 #define CC_DPPMIN(src, dst_s)                                                           \
   "v_mov_b32 v202, " src "\n"                                                           \
@@ -49,386 +66,458 @@
   "s_nop 1\n"                                                                           \
   "v_readlane_b32 " dst_s ", v202, 63\n"
 
-// x[rd] = v[200:201] for the lanes of the group
+// one step's front end for the record in buffer Q (words Q0..Q7, immediate pair Q23): request the sequential successor into QN,
+// read both operands, dispatch.  The handler comes back to the instruction after the s_swappc_b64.
+#define CC_FETCH(Q1, QN)                                                                \
+  "s_add_u32 s35, s34, " Q1 "\n"                                                        \
+  "s_lshl_b32 s88, s35, 4\n"                                                            \
+  "s_load_dwordx8 " QN ", s[80:81], s88\n"
+#define CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                               \
+  "s_set_gpr_idx_on " Q4 ", gpr_idx(SRC0)\n"                                            \
+  "v_mov_b32 v194, v128\n"                                                              \
+  "v_mov_b32 v195, v129\n"                                                              \
+  "s_set_gpr_idx_idx " Q5 "\n"                                                          \
+  "v_mov_b32 v196, v128\n"                                                              \
+  "v_mov_b32 v197, v129\n"                                                              \
+  "s_set_gpr_idx_off\n"                                                                 \
+  "s_mov_b32 s38, " Q6 "\n"                                                             \
+  "s_mov_b32 s39, " Q7 "\n"                                                             \
+  "s_add_u32 s90, s64, " Q0 "\n"                                                        \
+  "s_addc_u32 s91, s65, 0\n"                                                            \
+  "v_lshl_add_u64 v[198:199], v[196:197], 0, " Q23 "\n"                                 \
+  "s_swappc_b64 s[54:55], s[90:91]\n"
+// converged mode: every eligible lane is in; the epilogue only moves the scalar state on
+#define CC_CSTEP(Q0, Q1, Q23, Q4, Q5, Q6, Q7, QN)                                       \
+  CC_FETCH(Q1, QN) CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                    \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  "s_mov_b32 s34, s35\n"                                                                \
+  "s_sub_u32 s36, s36, 1\n"                                                             \
+  "s_cbranch_scc1 L_exit_conv_%=\n"
+// diverged mode: the group = lanes whose pc is the scheduled one; they retire and move on in the epilogue
+#define CC_DSTEP(Q0, Q1, Q23, Q4, Q5, Q6, Q7, QN)                                       \
+  CC_FETCH(Q1, QN)                                                                      \
+  "v_cmp_eq_u32_e32 vcc, s34, v234\n"                                                   \
+  "s_and_saveexec_b64 s[66:67], vcc\n"                                                  \
+  CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                                     \
+  "v_mov_b32 v234, s35\n"                                                               \
+  "v_add_u32 v235, 1, v235\n"                                                           \
+  "s_mov_b64 exec, s[66:67]\n"                                                          \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  "s_mov_b32 s34, s35\n"                                                                \
+  "s_sub_u32 s36, s36, 1\n"                                                             \
+  "s_cbranch_scc1 L_exit_%=\n"
+#define CC_QA "s40", "s41", "s[42:43]", "s44", "s45", "s46", "s47", "s[56:63]"
+#define CC_QB "s56", "s57", "s[58:59]", "s60", "s61", "s62", "s63", "s[40:47]"
+#define CC_QT "s72", "s73", "s[74:75]", "s76", "s77", "s78", "s79", "s[40:47]"
+#define CC_CSTEP_(...) CC_CSTEP(__VA_ARGS__)
+#define CC_DSTEP_(...) CC_DSTEP(__VA_ARGS__)
+
+// x[rd] = v[200:201] for the lanes of the group; back to the step's epilogue
 #define CC_WR                                                                           \
-  "s_set_gpr_idx_on s57, gpr_idx(DST)\n"                                                \
+  "s_set_gpr_idx_on s38, gpr_idx(DST)\n"                                                \
   "v_mov_b32 v128, v200\n"                                                              \
   "v_mov_b32 v129, v201\n"                                                              \
   "s_set_gpr_idx_off\n"
-
-// the lanes of the group retire this instruction and go on to its sequential successor
-#define CC_LANES_SEQ                                                                    \
-  "v_mov_b32 %[vpc], s53\n"                                                             \
-  "v_add_u32 %[vit], 1, %[vit]\n"
-
-// back to the loop top with the sequential successor's record (already requested)
-#define CC_NEXT_SEQ                                                                     \
-  "s_mov_b64 exec, s[62:63]\n"                                                          \
-  "s_waitcnt lgkmcnt(0)\n"                                                              \
-  "s_mov_b64 s[40:41], s[44:45]\n"                                                      \
-  "s_mov_b64 s[42:43], s[46:47]\n"                                                      \
-  "s_mov_b32 s52, s53\n"                                                                \
-  "s_sub_u32 s54, s54, 1\n"                                                             \
-  "s_cmp_lg_u32 s54, 0\n"                                                               \
-  "s_cbranch_scc1 L_top_%=\n"                                                           \
-  "s_branch L_exit_%=\n"
-
-#define CC_TAIL_WR CC_WR CC_LANES_SEQ CC_NEXT_SEQ
+#define CC_RET "s_setpc_b64 s[54:55]\n"
+#define CC_WR_RET CC_WR CC_RET
 #define CC_H(k) ".org L_htab_%= + 512 * " #k "\n"
+// leaving converged mode: the steps taken in it reach the lanes' retire counts
+#define CC_FLUSH                                                                        \
+  "s_sub_u32 s88, s37, s36\n"                                                           \
+  "v_add_u32 v235, s88, v235\n"
 
-// address of a load / store: va = (a + imm) & am -> v[202:203], arena offset -> v[204:205]; s[68:69] = lanes that are fine so far
-// (inside the arena with `SZ` bytes to spare, aligned, not tohost)
-#define CC_ADDR(SZ, SZM1)                                                               \
-  "v_lshl_add_u64 v[202:203], v[194:195], 0, s[58:59]\n"                                \
-  "s_sub_u32 s66, s76, " SZ "\n"                                                        \
-  "s_subb_u32 s67, s77, 0\n"                                                            \
-  "v_and_b32 v203, s89, v203\n"                                                         \
-  "v_lshl_add_u64 v[204:205], v[202:203], 0, s[74:75]\n"                                \
-  "v_cmp_ne_u64_e64 s[70:71], v[202:203], %[tohost]\n"                                  \
+// address of a load / store: va = (a + imm) & am -> v[202:203], arena offset -> v[204:205]; s[92:93] = lanes that are fine so far
+// (inside the arena with the access size to spare, aligned, not tohost)
+#define CC_ADDR(LIM, SZM1)                                                              \
+  "v_lshl_add_u64 v[202:203], v[194:195], 0, v[198:199]\n"                              \
+  "v_and_b32 v203, v228, v203\n"                                                        \
+  "v_lshl_add_u64 v[204:205], v[202:203], 0, v[212:213]\n"                              \
+  "v_cmp_ne_u64_e64 s[92:93], v[202:203], v[232:233]\n"                                 \
   "v_and_b32 v206, " SZM1 ", v202\n"                                                    \
-  "v_cmp_ge_u64_e64 s[68:69], s[66:67], v[204:205]\n"                                   \
+  "v_cmp_ge_u64_e64 s[94:95], " LIM ", v[204:205]\n"                                    \
   "v_cmp_eq_u32_e32 vcc, 0, v206\n"                                                     \
-  "s_and_b64 s[68:69], s[68:69], s[70:71]\n"                                            \
-  "s_and_b64 s[68:69], s[68:69], vcc\n"
-
+  "s_and_b64 s[92:93], s[92:93], s[94:95]\n"                                            \
+  "s_and_b64 s[92:93], s[92:93], vcc\n"
+#define CC_ALLOK                                                                        \
+  "s_xor_b64 s[92:93], s[92:93], exec\n"                                                \
+  "s_cbranch_scc1 L_bad_%=\n"
 // lane address of arena offset v[204:205] -> v[206:207] (8-byte interleave across the wave's harts, DevMem::p)
 #define CC_LANEPTR                                                                      \
   "v_and_b32 v206, -8, v204\n"                                                          \
   "v_mov_b32 v207, v205\n"                                                              \
-  "v_lshlrev_b64 v[206:207], s91, v[206:207]\n"                                         \
+  "v_lshlrev_b64 v[206:207], s50, v[206:207]\n"                                         \
   "v_and_or_b32 v206, v204, 7, v206\n"                                                  \
-  "v_lshl_add_u64 v[206:207], v[206:207], 0, %[arena]\n"
-
-// integer load: LDOP the global_load mnemonic, EXT the instruction(s) that make v201 from v200
-#define CC_LOAD(SZ, SZM1, LDOP, EXT)                                                    \
-  CC_ADDR(SZ, SZM1)                                                                     \
-  "s_xor_b64 s[68:69], s[68:69], exec\n"                                                \
-  "s_cbranch_scc1 L_bad_%=\n"                                                           \
-  CC_LANEPTR                                                                            \
+  "v_lshl_add_u64 v[206:207], v[206:207], 0, v[230:231]\n"
+#define CC_LOAD(LIM, SZM1, LDOP, EXT)                                                   \
+  CC_ADDR(LIM, SZM1) CC_ALLOK CC_LANEPTR                                                \
   LDOP " v[206:207], off\n"                                                             \
-  CC_LANES_SEQ                                                                          \
   "s_waitcnt vmcnt(0)\n"                                                                \
-  EXT                                                                                   \
-  CC_WR CC_NEXT_SEQ
-
-// the extra conditions of a store: not tohost + 4, not into the text -> s[68:69] updated
+  EXT CC_WR_RET
+// stores: the data register's index is record word 6; also not tohost + 4 and not into the text
+#define CC_STDATA                                                                       \
+  "s_set_gpr_idx_on s38, gpr_idx(SRC0)\n"                                               \
+  "v_mov_b32 v196, v128\n"                                                              \
+  "v_mov_b32 v197, v129\n"                                                              \
+  "s_set_gpr_idx_off\n"
 #define CC_STCHK(SZ)                                                                    \
   "v_lshl_add_u64 v[208:209], v[202:203], 0, " SZ "\n"                                  \
-  "v_cmp_ne_u64_e64 s[70:71], v[202:203], v[210:211]\n"                                 \
-  "v_cmp_gt_u64_e64 s[66:67], v[208:209], s[78:79]\n"                                   \
-  "v_cmp_lt_u64_e64 vcc, v[202:203], s[80:81]\n"                                        \
-  "s_and_b64 s[68:69], s[68:69], s[70:71]\n"                                            \
-  "s_and_b64 s[66:67], s[66:67], vcc\n"                                                 \
-  "s_andn2_b64 s[68:69], s[68:69], s[66:67]\n"
+  "v_cmp_ne_u64_e64 s[94:95], v[202:203], v[210:211]\n"                                 \
+  "v_cmp_gt_u64_e64 s[88:89], v[208:209], v[222:223]\n"                                 \
+  "v_cmp_lt_u64_e32 vcc, v[202:203], v[224:225]\n"                                      \
+  "s_and_b64 s[92:93], s[92:93], s[94:95]\n"                                            \
+  "s_and_b64 s[88:89], s[88:89], vcc\n"                                                 \
+  "s_andn2_b64 s[92:93], s[92:93], s[88:89]\n"
+#define CC_STORE(LIM, SZ, SZM1, STOP)                                                   \
+  CC_STDATA CC_ADDR(LIM, SZM1) CC_STCHK(SZ) CC_ALLOK CC_LANEPTR                         \
+  STOP "\n" CC_RET
+#define CC_FADDR(dst) "s_add_u32 s88, s38, s51\n" "v_add_u32 " dst ", s88, v229\n"      /* LDS address of the f register of word 6 */
+#define CC_FPON "s_bitcmp1_b32 s49, 2\n" "s_cbranch_scc0 L_bad_%=\n"
 
-#define CC_STORE(SZ, SZM1, STOP)                                                        \
-  CC_ADDR(SZ, SZM1)                                                                     \
-  CC_STCHK(SZ)                                                                          \
-  "s_xor_b64 s[68:69], s[68:69], exec\n"                                                \
+// branches: vcc = lanes that take it (the compare sits in front), s39 = target; its record is requested into buffer T
+#define CC_BR_HEAD                                                                      \
+  "s_lshl_b32 s88, s39, 4\n"                                                            \
+  "s_load_dwordx8 s[72:79], s[80:81], s88\n"                                            \
+  "s_cmp_lg_u32 s48, 0\n"                                                               \
+  "s_cbranch_scc1 L_br_div_%=\n"
+#define CC_TAKEN_ALL                                                                    \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  "s_mov_b32 s34, s39\n"                                                                \
+  "s_sub_u32 s36, s36, 1\n"                                                             \
+  "s_cbranch_scc1 L_exit_conv_%=\n"                                                     \
+  "s_branch L_CT_T_%=\n"
+#define CC_BR_FWD(CMP)                                                                  \
+  CMP " vcc, v[194:195], v[196:197]\n" CC_BR_HEAD                                       \
+  "s_cmp_lg_u64 vcc, 0\n"                                                               \
+  "s_cbranch_scc1 L_br_some_%=\n"                                                       \
+  CC_RET
+#define CC_BR_BACK(CMP)                                                                 \
+  CMP " vcc, v[194:195], v[196:197]\n" CC_BR_HEAD                                       \
+  "s_cmp_eq_u64 vcc, s[70:71]\n"                                                        \
+  "s_cbranch_scc0 L_br_notall_%=\n"                                                     \
+  CC_TAKEN_ALL
+#define CC_BR_OUT(CMP)                                                                  \
+  CMP " vcc, v[194:195], v[196:197]\n"                                                  \
+  "s_cmp_lg_u64 vcc, 0\n"                                                               \
   "s_cbranch_scc1 L_bad_%=\n"                                                           \
-  CC_LANEPTR                                                                            \
-  STOP "\n"                                                                             \
-  CC_LANES_SEQ CC_NEXT_SEQ
+  CC_RET
 
-// conditional branch: vcc = lanes that take it (set by the compare in front of this)
-#define CC_BRANCH                                                                       \
-  "s_add_u32 s93, s52, s41\n"                                                           \
-  "s_cmp_ge_u32 s93, s88\n"                                                             \
-  "s_cbranch_scc1 L_br_out_%=\n"                                                        \
-  "s_lshl_b32 s55, s93, 3\n"                                                            \
-  "s_load_dwordx4 s[48:51], s[86:87], s55\n"                                            \
-  "s_branch L_br_%=\n"
+// a call of compiled C++ (standard calling convention; the callee keeps s34+ and never reaches v128+)
+#define CC_CALL(fn)                                                                     \
+  "s_getpc_b64 s[92:93]\n"                                                              \
+  "s_add_u32 s92, s92, " fn "@rel32@lo+4\n"                                             \
+  "s_addc_u32 s93, s93, " fn "@rel32@hi+12\n"                                           \
+  "s_swappc_b64 s[30:31], s[92:93]\n"
+#define CC_FREG_READ(FIELD, dst)                                                        \
+  "s_bfe_u32 s88, s39, " FIELD "\n"                                                     \
+  "s_lshl_b32 s88, s88, 3\n"                                                            \
+  "s_add_u32 s88, s88, s51\n"                                                           \
+  "v_add_u32 v238, s88, v229\n"                                                         \
+  "ds_read_b64 " dst ", v238\n"
+#define CC_PURE_FP_CALL                                                                 \
+  CC_FPON                                                                               \
+  CC_FREG_READ("0x5000d", "v[4:5]") CC_FREG_READ("0x50012", "v[6:7]") CC_FREG_READ("0x50017", "v[8:9]")   \
+  "s_bfe_u32 s88, s39, 0x50008\n"                                                       \
+  "s_lshl_b32 s88, s88, 3\n"                                                            \
+  "s_add_u32 s88, s88, s51\n"                                                           \
+  "v_add_u32 v241, s88, v229\n"                                                         \
+  "v_mov_b32 v0, s39\n"                                                                 \
+  "v_sub_u32 v1, v198, v196\n"                                                          \
+  "v_mov_b32 v2, v194\n"                                                                \
+  "v_mov_b32 v3, v195\n"                                                                \
+  "v_mov_b32 v10, v237\n"                                                               \
+  "v_mov_b32 v11, s52\n"                                                                \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  CC_CALL("wsp_pure_fp")                                                                \
+  "v_cmp_ne_u32_e32 vcc, 0, v3\n"                                                       \
+  "s_xor_b64 s[92:93], vcc, exec\n"                                                     \
+  "s_cbranch_scc1 L_bad_%=\n"                                                           \
+  "v_mov_b32 v237, v2\n"
 
-#define CC_CLOBBERS                                                                                                                     \
-  "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",     \
-  "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",     \
-  "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175",     \
-  "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191",     \
-  "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",     \
-  "v208", "v209", "v210", "v211",                                                                                                     \
-  "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",       \
-  "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",       \
-  "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",       \
-  "s98", "vcc", "scc", "memory"
+#define CC_CLOBBERS \
+  "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+  "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", \
+  "v38", "v39", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", \
+  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v112", \
+  "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", \
+  "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", \
+  "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", \
+  "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
+  "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", \
+  "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", \
+  "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", \
+  "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+  "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", \
+  "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s34", "s35", "s36", "s37", "s38", "s39", \
+  "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", \
+  "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", \
+  "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", \
+  "s94", "s95", "m0", "vcc", "scc", "memory"
 
 namespace wsp {
 
-// One run of the converged loop.  Uniform inputs must be provably wave-uniform (kernel arguments / readfirstlane).
-//   recs: record image of the wave's program; tlen_ct: text length in bytes, or 0 when taken control transfers cannot be inlined
-//   (no C extension); cfg: bit 1 rv32, bit 2 mstatus.FS dirty (flw / fld / fsw / fsd inline), bit 3 D extension (flw boxes);
-//   xb: LDS byte offset of the lane's x block; arena: the lane's arena base (DevMem::arena); vpc: the lane's pc as a text offset,
-//   0xffffffff for lanes that take no part; n: iterations (>= 1).  Out: vit = instructions retired by the lane, ncv != 0 = the lane
-//   stands at an instruction for the general path.
-__device__ __forceinline__ void conv_core(const void* recs, u64 nmbase, u64 msize, u64 tlo, u64 thi, u64 ntlo, u32 tlen_ct, u32 amhi,
-                                          u32 cfg, u32 lpw_shift, u32 foff, u32 n, u32 xb, const void* arena, u64 tohost,
-                                          u32& vpc, u32& vit, u32& ncv)
+// One run of the converged loop.  Arguments that are the same for the whole wave may sit in any lane's registers (they are read
+// with v_readfirstlane).  hrecs: hot-record image of the wave's program; cfg: bit 1 rv32, bit 2 mstatus.FS dirty in every lane that
+// takes part (flw / fld / fsw / fsd and F / D arithmetic inline), bit 3 D extension (flw boxes); xb: LDS byte offset of the lane's x
+// block; arena: the lane's arena base (DevMem::arena); vpc: the lane's pc as a text offset, 0xffffffff for lanes that take no part;
+// fcsr: the lane's fcsr; n: iterations (>= 1).  Out: vit = instructions retired by the lane, ncv != 0 = the lane stands at an
+// instruction for the general path.
+__device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg, u32 lpw_shift,
+                                          u32 foff, u32 n, u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr, u32& vit, u32& ncv)
 {
   u32 vit_ = 0, ncv_ = 0;
   asm volatile(
-    // ------------------------------------------------------------------ entry
-    "s_mov_b64 s[72:73], exec\n"
-    "ds_read_b64 v[130:131], %[xb] offset:8\n"    "ds_read_b64 v[132:133], %[xb] offset:16\n"   "ds_read_b64 v[134:135], %[xb] offset:24\n"
-    "ds_read_b64 v[136:137], %[xb] offset:32\n"   "ds_read_b64 v[138:139], %[xb] offset:40\n"   "ds_read_b64 v[140:141], %[xb] offset:48\n"
-    "ds_read_b64 v[142:143], %[xb] offset:56\n"   "ds_read_b64 v[144:145], %[xb] offset:64\n"   "ds_read_b64 v[146:147], %[xb] offset:72\n"
-    "ds_read_b64 v[148:149], %[xb] offset:80\n"   "ds_read_b64 v[150:151], %[xb] offset:88\n"   "ds_read_b64 v[152:153], %[xb] offset:96\n"
-    "ds_read_b64 v[154:155], %[xb] offset:104\n"  "ds_read_b64 v[156:157], %[xb] offset:112\n"  "ds_read_b64 v[158:159], %[xb] offset:120\n"
-    "ds_read_b64 v[160:161], %[xb] offset:128\n"  "ds_read_b64 v[162:163], %[xb] offset:136\n"  "ds_read_b64 v[164:165], %[xb] offset:144\n"
-    "ds_read_b64 v[166:167], %[xb] offset:152\n"  "ds_read_b64 v[168:169], %[xb] offset:160\n"  "ds_read_b64 v[170:171], %[xb] offset:168\n"
-    "ds_read_b64 v[172:173], %[xb] offset:176\n"  "ds_read_b64 v[174:175], %[xb] offset:184\n"  "ds_read_b64 v[176:177], %[xb] offset:192\n"
-    "ds_read_b64 v[178:179], %[xb] offset:200\n"  "ds_read_b64 v[180:181], %[xb] offset:208\n"  "ds_read_b64 v[182:183], %[xb] offset:216\n"
-    "ds_read_b64 v[184:185], %[xb] offset:224\n"  "ds_read_b64 v[186:187], %[xb] offset:232\n"  "ds_read_b64 v[188:189], %[xb] offset:240\n"
-    "ds_read_b64 v[190:191], %[xb] offset:248\n"
+    // ------------------------------------------------------------------ entry (exec = all lanes of the wave)
+    "s_mov_b64 s[68:69], exec\n"
+    "v_mov_b32 v229, %[xb]\n"          "v_mov_b64 v[230:231], %[arena]\n"   "v_mov_b64 v[232:233], %[tohost]\n"
+    "v_mov_b32 v234, %[vpc]\n"         "v_mov_b32 v237, %[fcsr]\n"          "v_mov_b32 v235, 0\n"               "v_mov_b32 v236, 0\n"
+    "v_mov_b64 v[202:203], %[recs]\n"  "v_mov_b64 v[204:205], %[mbase]\n"   "v_mov_b64 v[206:207], %[msize]\n"
+    "v_mov_b64 v[222:223], %[tlo]\n"   "v_mov_b64 v[224:225], %[thi]\n"
+    "v_mov_b32 v208, %[cfg]\n"         "v_mov_b32 v209, %[lpwsh]\n"         "v_mov_b32 v238, %[foff]\n"         "v_mov_b32 v239, %[n]\n"
+    "v_mov_b32 v240, %[isa]\n"         "v_mov_b32 v241, %[tlen]\n"
+    "ds_read_b64 v[130:131], v229 offset:8\n"    "ds_read_b64 v[132:133], v229 offset:16\n"   "ds_read_b64 v[134:135], v229 offset:24\n"
+    "ds_read_b64 v[136:137], v229 offset:32\n"   "ds_read_b64 v[138:139], v229 offset:40\n"   "ds_read_b64 v[140:141], v229 offset:48\n"
+    "ds_read_b64 v[142:143], v229 offset:56\n"   "ds_read_b64 v[144:145], v229 offset:64\n"   "ds_read_b64 v[146:147], v229 offset:72\n"
+    "ds_read_b64 v[148:149], v229 offset:80\n"   "ds_read_b64 v[150:151], v229 offset:88\n"   "ds_read_b64 v[152:153], v229 offset:96\n"
+    "ds_read_b64 v[154:155], v229 offset:104\n"  "ds_read_b64 v[156:157], v229 offset:112\n"  "ds_read_b64 v[158:159], v229 offset:120\n"
+    "ds_read_b64 v[160:161], v229 offset:128\n"  "ds_read_b64 v[162:163], v229 offset:136\n"  "ds_read_b64 v[164:165], v229 offset:144\n"
+    "ds_read_b64 v[166:167], v229 offset:152\n"  "ds_read_b64 v[168:169], v229 offset:160\n"  "ds_read_b64 v[170:171], v229 offset:168\n"
+    "ds_read_b64 v[172:173], v229 offset:176\n"  "ds_read_b64 v[174:175], v229 offset:184\n"  "ds_read_b64 v[176:177], v229 offset:192\n"
+    "ds_read_b64 v[178:179], v229 offset:200\n"  "ds_read_b64 v[180:181], v229 offset:208\n"  "ds_read_b64 v[182:183], v229 offset:216\n"
+    "ds_read_b64 v[184:185], v229 offset:224\n"  "ds_read_b64 v[186:187], v229 offset:232\n"  "ds_read_b64 v[188:189], v229 offset:240\n"
+    "ds_read_b64 v[190:191], v229 offset:248\n"
     "v_mov_b32 v192, 0\n"  "v_mov_b32 v193, 0\n"  "v_mov_b32 v128, 0\n"  "v_mov_b32 v129, 0\n"
-    "s_mov_b64 s[86:87], %[recs]\n"   "s_mov_b64 s[74:75], %[nmbase]\n"  "s_mov_b64 s[76:77], %[msize]\n"  "s_mov_b64 s[78:79], %[tlo]\n"
-    "s_mov_b64 s[80:81], %[thi]\n"    "s_mov_b64 s[82:83], %[ntlo]\n"    "s_mov_b32 s88, %[tlen]\n"        "s_mov_b32 s89, %[amhi]\n"
-    "s_mov_b32 s90, %[cfg]\n"         "s_mov_b32 s91, %[lpwsh]\n"        "s_mov_b32 s92, %[foff]\n"        "s_mov_b32 s54, %[n]\n"
-    "s_mov_b32 s93, -1\n"
-    "s_getpc_b64 s[60:61]\n"
+    "v_readfirstlane_b32 s80, v202\n"  "v_readfirstlane_b32 s81, v203\n"  "v_readfirstlane_b32 s82, v222\n"  "v_readfirstlane_b32 s83, v223\n"
+    "v_readfirstlane_b32 s49, v208\n"  "v_readfirstlane_b32 s50, v209\n"  "v_readfirstlane_b32 s51, v238\n"  "v_readfirstlane_b32 s36, v239\n"
+    "v_readfirstlane_b32 s52, v240\n"  "v_readfirstlane_b32 s53, v241\n"
+    "v_sub_co_u32_e32 v212, vcc, 0, v204\n"
+    "v_lshl_add_u64 v[214:215], v[206:207], 0, -1\n"
+    "v_lshl_add_u64 v[216:217], v[206:207], 0, -2\n"
+    "v_subb_co_u32_e32 v213, vcc, 0, v205, vcc\n"
+    "v_lshl_add_u64 v[218:219], v[206:207], 0, -4\n"
+    "v_lshl_add_u64 v[220:221], v[206:207], 0, -8\n"
+    "v_sub_co_u32_e32 v226, vcc, 0, v222\n"
+    "v_lshl_add_u64 v[210:211], v[232:233], 0, 4\n"
+    "s_bitcmp1_b32 s49, 1\n"
+    "s_nop 0\n"
+    "v_subb_co_u32_e32 v227, vcc, 0, v223, vcc\n"
+    "s_cselect_b32 s88, 0, -1\n"
+    "v_mov_b32 v228, s88\n"
+    "s_sub_u32 s36, s36, 1\n"
+    "s_getpc_b64 s[64:65]\n"
     "L_anchor_%=:\n"
-    "s_add_u32 s60, s60, L_htab_%=-L_anchor_%=\n"
-    "s_addc_u32 s61, s61, 0\n"
-    "v_cmp_ne_u32_e64 s[84:85], -1, %[vpc]\n"
-    "v_lshl_add_u64 v[210:211], %[tohost], 0, 4\n"
-    CC_DPPMIN("%[vpc]", "s52")
-    "s_lshl_b32 s55, s52, 3\n"
-    "s_load_dwordx4 s[40:43], s[86:87], s55\n"
+    "s_add_u32 s64, s64, L_htab_%=-L_anchor_%=\n"
+    "s_addc_u32 s65, s65, 0\n"
+    "v_cmp_ne_u32_e64 s[70:71], -1, v234\n"
+    // ------------------------------------------------------------------ schedule: the minimum pc over all lanes; converged if all agree
+    "L_sched_%=:\n"
+    "s_mov_b64 exec, s[68:69]\n"
+    CC_DPPMIN("v234", "s34")
+    "s_lshl_b32 s88, s34, 4\n"
+    "s_waitcnt lgkmcnt(0)\n"                      // a successor record may still be on its way into buffer A: scalar loads land in any order
+    "s_load_dwordx8 s[40:47], s[80:81], s88\n"
+    "v_cmp_eq_u32_e32 vcc, s34, v234\n"
+    "s_mov_b64 exec, s[70:71]\n"                  // from here on only lanes that take part are ever active
+    "s_cmp_eq_u64 vcc, s[70:71]\n"
     "s_waitcnt lgkmcnt(0)\n"
-    // ------------------------------------------------------------------ one step: s[40:43] = record at upc (s52)
-    "L_top_%=:\n"
-    "s_bfe_u32 s55, s40, 0x1001c\n"               // F_SIZE4
-    "s_lshl1_add_u32 s53, s55, s52\n"
-    "s_add_u32 s53, s53, 2\n"                     // spc
-    "s_lshl_b32 s55, s53, 3\n"
-    "s_load_dwordx4 s[44:47], s[86:87], s55\n"    // sequential successor, in flight for the rest of the step
-    "v_cmp_eq_u32_e32 vcc, s52, %[vpc]\n"
-    "s_and_saveexec_b64 s[62:63], vcc\n"          // the group: lanes whose pc is the scheduled one
-    "s_bfe_u32 s55, s42, 0x70002\n"               // slot(rs1) * 2
-    "s_bfe_u32 s56, s42, 0x70012\n"               // slot(rs2) * 2 (zero slot for immediate forms)
-    "s_set_gpr_idx_on s55, gpr_idx(SRC0)\n"
-    "v_mov_b32 v194, v128\n"
-    "v_mov_b32 v195, v129\n"
-    "s_set_gpr_idx_idx s56\n"
-    "v_mov_b32 v196, v128\n"
-    "v_mov_b32 v197, v129\n"
-    "s_set_gpr_idx_off\n"
-    "s_mov_b32 s58, s41\n"
-    "s_ashr_i32 s59, s41, 31\n"
-    "s_bfe_u32 s57, s40, 0x60007\n"               // rd * 2
-    "s_and_b32 s55, s42, 0xfe00\n"                // handler class * 512
-    "s_add_u32 s64, s60, s55\n"
-    "s_addc_u32 s65, s61, 0\n"
-    "v_lshl_add_u64 v[198:199], v[196:197], 0, s[58:59]\n"
-    "s_setpc_b64 s[64:65]\n"
+    "s_cbranch_scc0 L_go_div_%=\n"
+    "s_mov_b32 s48, 0\n"
+    "s_mov_b32 s37, s36\n"
+    "s_branch L_CT_A_%=\n"
+    "L_go_div_%=:\n"
+    "s_mov_b32 s48, 1\n"
+    "s_branch L_DT_A_%=\n"
+    // ------------------------------------------------------------------ the steps, converged mode
+    "L_CT_T_%=:\n" CC_CSTEP_(CC_QT)
+    "L_CT_A_%=:\n" CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB) CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB)
+    "s_branch L_CT_A_%=\n"
+    // ------------------------------------------------------------------ the steps, diverged mode
+    "L_DT_A_%=:\n" CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB) CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB)
+    "s_branch L_DT_A_%=\n"
     // ------------------------------------------------------------------ shared pieces
     "L_bad_%=:\n"                                  // nobody of the group executes: general path
-    "v_mov_b32 %[ncv], 1\n"
-    "s_mov_b64 exec, s[62:63]\n"
+    "v_mov_b32 v236, 1\n"
+    "s_cmp_eq_u32 s48, 0\n"
+    "s_cbranch_scc1 L_exit_conv_%=\n"
+    "s_mov_b64 exec, s[66:67]\n"
     "s_branch L_exit_%=\n"
-    // conditional branch, target inside the text: vcc = takers, s93 = target, its record requested into s[48:51]
-    "L_br_%=:\n"
-    "v_mov_b32 v202, s53\n"
-    "v_mov_b32 v203, s93\n"
-    "s_mov_b64 s[66:67], vcc\n"
-    "s_xor_b64 s[68:69], exec, s[84:85]\n"        // scc: the group is not every eligible lane
-    "v_cndmask_b32_e32 %[vpc], v202, v203, vcc\n"
-    "v_add_u32 %[vit], 1, %[vit]\n"
-    "s_mov_b64 exec, s[62:63]\n"
-    "s_cbranch_scc1 L_sched_%=\n"
-    "s_cmp_eq_u64 s[66:67], 0\n"
-    "s_cbranch_scc1 L_nseq_%=\n"                   // nobody took it
-    "s_cmp_eq_u64 s[66:67], s[84:85]\n"
-    "s_cbranch_scc0 L_sched_%=\n"                  // some did, some did not
-    "L_ntgt_%=:\n"                                 // everybody goes to the target
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_mov_b64 s[40:41], s[48:49]\n"
-    "s_mov_b64 s[42:43], s[50:51]\n"
-    "s_mov_b32 s52, s93\n"
-    "s_sub_u32 s54, s54, 1\n"
-    "s_cmp_lg_u32 s54, 0\n"
-    "s_cbranch_scc1 L_top_%=\n"
+    "L_exit_conv_%=:\n"                            // converged mode ends: pc and retire count of every lane from the scalar state
+    CC_FLUSH
+    "v_mov_b32 v234, s34\n"
     "s_branch L_exit_%=\n"
-    "L_nseq_%=:\n"
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_mov_b64 s[40:41], s[44:45]\n"
-    "s_mov_b64 s[42:43], s[46:47]\n"
-    "s_mov_b32 s52, s53\n"
-    "s_sub_u32 s54, s54, 1\n"
-    "s_cmp_lg_u32 s54, 0\n"
-    "s_cbranch_scc1 L_top_%=\n"
-    "s_branch L_exit_%=\n"
-    // conditional branch whose target lies outside the text (or no C extension): fine while nobody takes it
-    "L_br_out_%=:\n"
+    "L_br_some_%=:\n"                              // converged, forward branch, somebody takes it
+    "s_cmp_eq_u64 vcc, s[70:71]\n"
+    "s_cbranch_scc0 L_br_mixed_%=\n"
+    CC_TAKEN_ALL
+    "L_br_notall_%=:\n"                            // converged, backward branch, not everybody takes it
     "s_cmp_eq_u64 vcc, 0\n"
-    "s_cbranch_scc0 L_bad_%=\n"
-    CC_LANES_SEQ CC_NEXT_SEQ
-    // after a control transfer: the next scheduled pc is the minimum over all eligible lanes (exec = all lanes here)
-    "L_sched_%=:\n"
-    "s_sub_u32 s54, s54, 1\n"
-    "s_cmp_eq_u32 s54, 0\n"
+    "s_cbranch_scc0 L_br_mixed_%=\n"
+    CC_RET
+    "L_br_mixed_%=:\n"                             // the wave diverges here
+    "v_mov_b32 v202, s35\n"
+    "v_mov_b32 v203, s39\n"
+    CC_FLUSH
+    "v_add_u32 v235, 1, v235\n"
+    "v_cndmask_b32_e32 v234, v202, v203, vcc\n"
+    "s_branch L_sched_count_%=\n"
+    "L_br_div_%=:\n"                               // diverged mode: the group's lanes go their ways
+    "v_mov_b32 v202, s35\n"
+    "v_mov_b32 v203, s39\n"
+    "v_add_u32 v235, 1, v235\n"
+    "v_cndmask_b32_e32 v234, v202, v203, vcc\n"
+    "s_mov_b64 exec, s[66:67]\n"
+    "L_sched_count_%=:\n"
+    "s_sub_u32 s36, s36, 1\n"
+    "s_cbranch_scc0 L_sched_%=\n"
+    "s_branch L_exit_%=\n"
+    "L_resume_%=:\n"                               // after a call: the step's epilogue by hand, then the next record again
+    "s_cmp_lg_u32 s48, 0\n"
+    "s_cbranch_scc0 L_resume2_%=\n"
+    "v_mov_b32 v234, s35\n"
+    "v_add_u32 v235, 1, v235\n"
+    "s_mov_b64 exec, s[66:67]\n"
+    "L_resume2_%=:\n"
+    "s_mov_b32 s34, s35\n"
+    "s_lshl_b32 s88, s34, 4\n"
+    "s_load_dwordx8 s[40:47], s[80:81], s88\n"
+    "s_sub_u32 s36, s36, 1\n"
+    "s_cbranch_scc1 L_exit_any_%=\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "s_cmp_lg_u32 s48, 0\n"
+    "s_cbranch_scc1 L_DT_A_%=\n"
+    "s_branch L_CT_A_%=\n"
+    "L_exit_any_%=:\n"
+    "s_cmp_lg_u32 s48, 0\n"
     "s_cbranch_scc1 L_exit_%=\n"
-    CC_DPPMIN("%[vpc]", "s98")
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_cmp_eq_u32 s98, s53\n"
-    "s_cbranch_scc1 L_sched_seq_%=\n"
-    "s_cmp_eq_u32 s98, s93\n"
-    "s_cbranch_scc1 L_sched_tgt_%=\n"
-    "s_lshl_b32 s55, s98, 3\n"
-    "s_load_dwordx4 s[40:43], s[86:87], s55\n"
-    "s_mov_b32 s52, s98\n"
-    "s_waitcnt lgkmcnt(0)\n"
-    "s_branch L_top_%=\n"
-    "L_sched_seq_%=:\n"
-    "s_mov_b64 s[40:41], s[44:45]\n"
-    "s_mov_b64 s[42:43], s[46:47]\n"
-    "s_mov_b32 s52, s98\n"
-    "s_branch L_top_%=\n"
-    "L_sched_tgt_%=:\n"
-    "s_mov_b64 s[40:41], s[48:49]\n"
-    "s_mov_b64 s[42:43], s[50:51]\n"
-    "s_mov_b32 s52, s98\n"
-    "s_branch L_top_%=\n"
-    // jal / jalr tail: link in s[66:67] (64-bit), lanes' new pc in v203, s93 = uniform target or -1; the target's record may be in flight
-    "L_jump_%=:\n"
-    "s_ashr_i32 s55, s66, 31\n"
-    "s_bitcmp1_b32 s90, 1\n"
-    "s_cselect_b32 s67, s55, s67\n"               // rv32: the link register holds the sign-extended 32-bit pc
-    "v_mov_b32 v200, s66\n"
-    "v_mov_b32 v201, s67\n"
-    CC_WR
-    "v_mov_b32 %[vpc], v203\n"
-    "v_add_u32 %[vit], 1, %[vit]\n"
-    "s_xor_b64 s[68:69], exec, s[84:85]\n"
-    "s_mov_b64 exec, s[62:63]\n"
-    "s_cbranch_scc1 L_sched_%=\n"
-    "s_cmp_eq_u32 s93, -1\n"
-    "s_cbranch_scc1 L_sched_%=\n"
-    "s_branch L_ntgt_%=\n"
-    // ------------------------------------------------------------------ handlers, 512 bytes apart
+    "s_branch L_exit_conv_%=\n"
+    "L_jal_div_%=:\n"
+    "v_mov_b32 v234, s39\n"
+    "v_add_u32 v235, 1, v235\n"
+    "s_mov_b64 exec, s[66:67]\n"
+    "s_branch L_sched_count_%=\n"
+    "L_jalr_tail_%=:\n"                            // lanes' targets in v202, link written
+    "v_mov_b32 v234, v202\n"
+    "v_add_u32 v235, 1, v235\n"
+    "s_cmp_lg_u32 s48, 0\n"
+    "s_cbranch_scc1 L_jalr_div_%=\n"
+    CC_FLUSH
+    "s_branch L_sched_count_%=\n"
+    "L_jalr_div_%=:\n"
+    "s_mov_b64 exec, s[66:67]\n"
+    "s_branch L_sched_count_%=\n"
+    // ------------------------------------------------------------------ handlers, 512 bytes apart (class order: HC_* in wsp_core.h)
     ".p2align 9\n"
     "L_htab_%=:\n"
     "s_branch L_bad_%=\n"                                                                                   // HC_BAD
-    CC_H(1)  "v_lshl_add_u64 v[200:201], v[194:195], 0, v[198:199]\n" CC_TAIL_WR                            // add
-    CC_H(2)  "v_sub_co_u32_e32 v200, vcc, v194, v198\n" "s_nop 1\n" "v_subb_co_u32_e32 v201, vcc, v195, v199, vcc\n" CC_TAIL_WR
-    CC_H(3)  "v_lshlrev_b64 v[200:201], v198, v[194:195]\n" CC_TAIL_WR                                      // sll
-    CC_H(4)  "v_cmp_lt_i64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_TAIL_WR
-    CC_H(5)  "v_cmp_lt_u64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_TAIL_WR
-    CC_H(6)  "v_xor_b32 v200, v194, v198\n" "v_xor_b32 v201, v195, v199\n" CC_TAIL_WR
-    CC_H(7)  "v_lshrrev_b64 v[200:201], v198, v[194:195]\n" CC_TAIL_WR                                      // srl
-    CC_H(8)  "v_ashrrev_i64 v[200:201], v198, v[194:195]\n" CC_TAIL_WR                                      // sra
-    CC_H(9)  "v_or_b32 v200, v194, v198\n" "v_or_b32 v201, v195, v199\n" CC_TAIL_WR
-    CC_H(10) "v_and_b32 v200, v194, v198\n" "v_and_b32 v201, v195, v199\n" CC_TAIL_WR
-    CC_H(11) "v_add_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                     // addw
-    CC_H(12) "v_sub_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                     // subw
-    CC_H(13) "v_lshlrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                 // sllw
-    CC_H(14) "v_lshrrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                 // srlw
-    CC_H(15) "v_ashrrev_i32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                 // sraw
-    CC_H(16) "v_mad_u64_u32 v[200:201], s[66:67], v194, v198, 0\n" "v_mul_lo_u32 v202, v195, v198\n" "v_mul_lo_u32 v203, v194, v199\n"
-             "v_add3_u32 v201, v201, v202, v203\n" CC_TAIL_WR                                               // mul
-    CC_H(17) "v_mul_lo_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_TAIL_WR                  // mulw
-    CC_H(18) "s_add_u32 s66, s78, s52\n" "s_addc_u32 s67, s79, 0\n" "s_add_u32 s66, s66, s58\n" "s_addc_u32 s67, s67, s59\n"   // auipc
-             "s_ashr_i32 s55, s66, 31\n" "s_bitcmp1_b32 s90, 1\n" "s_cselect_b32 s67, s55, s67\n"
-             "v_mov_b32 v200, s66\n" "v_mov_b32 v201, s67\n" CC_TAIL_WR
-    CC_H(19) "s_add_u32 s93, s52, s41\n"                                                                    // jal
-             "s_cmp_ge_u32 s93, s88\n"
-             "s_cbranch_scc1 L_bad_%=\n"
-             "s_lshl_b32 s55, s93, 3\n"
-             "s_load_dwordx4 s[48:51], s[86:87], s55\n"
-             "s_add_u32 s66, s78, s53\n" "s_addc_u32 s67, s79, 0\n"
-             "v_mov_b32 v203, s93\n"
-             "s_branch L_jump_%=\n"
-    CC_H(20) "v_lshl_add_u64 v[202:203], v[194:195], 0, s[58:59]\n"                                         // jalr
-             "v_and_b32 v203, s89, v203\n"
+    CC_H(1)  "v_lshl_add_u64 v[200:201], v[194:195], 0, v[198:199]\n" CC_WR_RET                             // add
+    CC_H(2)  "v_sub_co_u32_e32 v200, vcc, v194, v198\n" "s_nop 1\n" "v_subb_co_u32_e32 v201, vcc, v195, v199, vcc\n" CC_WR_RET
+    CC_H(3)  "v_lshlrev_b64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // sll
+    CC_H(4)  "v_cmp_lt_i64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_WR_RET
+    CC_H(5)  "v_cmp_lt_u64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_WR_RET
+    CC_H(6)  "v_xor_b32 v200, v194, v198\n" "v_xor_b32 v201, v195, v199\n" CC_WR_RET
+    CC_H(7)  "v_lshrrev_b64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // srl
+    CC_H(8)  "v_ashrrev_i64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // sra
+    CC_H(9)  "v_or_b32 v200, v194, v198\n" "v_or_b32 v201, v195, v199\n" CC_WR_RET
+    CC_H(10) "v_and_b32 v200, v194, v198\n" "v_and_b32 v201, v195, v199\n" CC_WR_RET
+    CC_H(11) "v_add_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                      // addw
+    CC_H(12) "v_sub_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                      // subw
+    CC_H(13) "v_lshlrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // sllw
+    CC_H(14) "v_lshrrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // srlw
+    CC_H(15) "v_ashrrev_i32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // sraw
+    CC_H(16) "v_mad_u64_u32 v[200:201], s[92:93], v194, v198, 0\n" "v_mul_lo_u32 v202, v195, v198\n" "v_mul_lo_u32 v203, v194, v199\n"
+             "v_add3_u32 v201, v201, v202, v203\n" CC_WR_RET                                                // mul
+    CC_H(17) "v_mul_lo_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                   // mulw
+    CC_H(18) "s_lshl_b32 s88, s39, 4\n"                                                                     // jal: link = the immediate
+             "s_load_dwordx8 s[72:79], s[80:81], s88\n"
+             "v_mov_b32 v200, v198\n" "v_mov_b32 v201, v199\n" CC_WR
+             "s_cmp_lg_u32 s48, 0\n"
+             "s_cbranch_scc1 L_jal_div_%=\n"
+             CC_TAKEN_ALL
+    CC_H(19) "v_lshl_add_u64 v[202:203], v[194:195], 0, v[198:199]\n"                                       // jalr
+             "v_and_b32 v203, v228, v203\n"
              "v_and_b32 v202, -2, v202\n"
-             "v_lshl_add_u64 v[202:203], v[202:203], 0, s[82:83]\n"
-             "s_add_u32 s66, s78, s53\n" "s_addc_u32 s67, s79, 0\n"
-             "v_cmp_eq_u32_e64 s[68:69], 0, v203\n"
-             "v_cmp_gt_u32_e32 vcc, s88, v202\n"
-             "s_and_b64 s[68:69], s[68:69], vcc\n"
-             "s_xor_b64 s[68:69], s[68:69], exec\n"
-             "s_cbranch_scc1 L_bad_%=\n"
-             "v_mov_b32 v203, v202\n"
-             "s_mov_b32 s93, -1\n"
-             "s_branch L_jump_%=\n"
-    CC_H(21) "v_cmp_eq_u64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(22) "v_cmp_ne_u64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(23) "v_cmp_lt_i64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(24) "v_cmp_ge_i64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(25) "v_cmp_lt_u64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(26) "v_cmp_ge_u64_e32 vcc, v[194:195], v[196:197]\n" CC_BRANCH
-    CC_H(27) CC_LOAD("1", "0", "global_load_sbyte v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(28) CC_LOAD("2", "1", "global_load_sshort v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(29) CC_LOAD("4", "3", "global_load_dword v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(30) CC_LOAD("8", "7", "global_load_dwordx2 v[200:201],", "")
-    CC_H(31) CC_LOAD("1", "0", "global_load_ubyte v200,", "v_mov_b32 v201, 0\n")
-    CC_H(32) CC_LOAD("2", "1", "global_load_ushort v200,", "v_mov_b32 v201, 0\n")
-    CC_H(33) CC_LOAD("4", "3", "global_load_dword v200,", "v_mov_b32 v201, 0\n")
-    CC_H(34) CC_STORE("1", "0", "global_store_byte v[206:207], v196, off")
-    CC_H(35) CC_STORE("2", "1", "global_store_short v[206:207], v196, off")
-    CC_H(36) CC_STORE("4", "3", "global_store_dword v[206:207], v196, off")
-    CC_H(37) CC_STORE("8", "7", "global_store_dwordx2 v[206:207], v[196:197], off")
-    CC_H(38) CC_LANES_SEQ CC_NEXT_SEQ                                                                       // nop
-    CC_H(39) "s_bitcmp1_b32 s90, 2\n" "s_cbranch_scc0 L_bad_%=\n"                                           // flw
-             CC_ADDR("4", "3")
-             "s_xor_b64 s[68:69], s[68:69], exec\n" "s_cbranch_scc1 L_bad_%=\n"
-             CC_LANEPTR
+             "v_lshl_add_u64 v[202:203], v[202:203], 0, v[226:227]\n"
+             "s_add_u32 s94, s82, s35\n" "s_addc_u32 s95, s83, 0\n"
+             "v_cmp_eq_u32_e64 s[92:93], 0, v203\n"
+             "v_cmp_gt_u32_e32 vcc, s53, v202\n"
+             "s_and_b64 s[92:93], s[92:93], vcc\n"
+             CC_ALLOK
+             "s_ashr_i32 s88, s94, 31\n"
+             "s_bitcmp1_b32 s49, 1\n"
+             "s_cselect_b32 s95, s88, s95\n"               // rv32: the link register holds the sign-extended 32-bit pc
+             "v_mov_b32 v200, s94\n" "v_mov_b32 v201, s95\n" CC_WR
+             "s_branch L_jalr_tail_%=\n"
+    CC_H(20) CC_BR_FWD("v_cmp_eq_u64_e32")  CC_H(21) CC_BR_FWD("v_cmp_ne_u64_e32")  CC_H(22) CC_BR_FWD("v_cmp_lt_i64_e32")
+    CC_H(23) CC_BR_FWD("v_cmp_ge_i64_e32")  CC_H(24) CC_BR_FWD("v_cmp_lt_u64_e32")  CC_H(25) CC_BR_FWD("v_cmp_ge_u64_e32")
+    CC_H(26) CC_BR_BACK("v_cmp_eq_u64_e32") CC_H(27) CC_BR_BACK("v_cmp_ne_u64_e32") CC_H(28) CC_BR_BACK("v_cmp_lt_i64_e32")
+    CC_H(29) CC_BR_BACK("v_cmp_ge_i64_e32") CC_H(30) CC_BR_BACK("v_cmp_lt_u64_e32") CC_H(31) CC_BR_BACK("v_cmp_ge_u64_e32")
+    CC_H(32) CC_BR_OUT("v_cmp_eq_u64_e32")  CC_H(33) CC_BR_OUT("v_cmp_ne_u64_e32")  CC_H(34) CC_BR_OUT("v_cmp_lt_i64_e32")
+    CC_H(35) CC_BR_OUT("v_cmp_ge_i64_e32")  CC_H(36) CC_BR_OUT("v_cmp_lt_u64_e32")  CC_H(37) CC_BR_OUT("v_cmp_ge_u64_e32")
+    CC_H(38) CC_LOAD("v[214:215]", "0", "global_load_sbyte v200,", "v_ashrrev_i32 v201, 31, v200\n")
+    CC_H(39) CC_LOAD("v[216:217]", "1", "global_load_sshort v200,", "v_ashrrev_i32 v201, 31, v200\n")
+    CC_H(40) CC_LOAD("v[218:219]", "3", "global_load_dword v200,", "v_ashrrev_i32 v201, 31, v200\n")
+    CC_H(41) CC_LOAD("v[220:221]", "7", "global_load_dwordx2 v[200:201],", "")
+    CC_H(42) CC_LOAD("v[214:215]", "0", "global_load_ubyte v200,", "v_mov_b32 v201, 0\n")
+    CC_H(43) CC_LOAD("v[216:217]", "1", "global_load_ushort v200,", "v_mov_b32 v201, 0\n")
+    CC_H(44) CC_LOAD("v[218:219]", "3", "global_load_dword v200,", "v_mov_b32 v201, 0\n")
+    CC_H(45) CC_STORE("v[214:215]", "1", "0", "global_store_byte v[206:207], v196, off")
+    CC_H(46) CC_STORE("v[216:217]", "2", "1", "global_store_short v[206:207], v196, off")
+    CC_H(47) CC_STORE("v[218:219]", "4", "3", "global_store_dword v[206:207], v196, off")
+    CC_H(48) CC_STORE("v[220:221]", "8", "7", "global_store_dwordx2 v[206:207], v[196:197], off")
+    CC_H(49) CC_RET                                                                                         // nop
+    CC_H(50) CC_FPON CC_ADDR("v[218:219]", "3") CC_ALLOK CC_LANEPTR                                         // flw
              "global_load_dword v200, v[206:207], off\n"
-             "s_lshl_b32 s55, s57, 2\n" "s_add_u32 s55, s55, s92\n" "v_add_u32 v202, s55, %[xb]\n"
-             "s_bitcmp1_b32 s90, 3\n" "s_cselect_b32 s56, -1, 0\n" "v_mov_b32 v201, s56\n"
-             CC_LANES_SEQ
+             CC_FADDR("v238")
+             "s_bitcmp1_b32 s49, 3\n" "s_cselect_b32 s88, -1, 0\n" "v_mov_b32 v201, s88\n"
              "s_waitcnt vmcnt(0)\n"
-             "ds_write_b64 v202, v[200:201]\n"
-             CC_NEXT_SEQ
-    CC_H(40) "s_bitcmp1_b32 s90, 2\n" "s_cbranch_scc0 L_bad_%=\n"                                           // fld
-             CC_ADDR("8", "7")
-             "s_xor_b64 s[68:69], s[68:69], exec\n" "s_cbranch_scc1 L_bad_%=\n"
-             CC_LANEPTR
+             "ds_write_b64 v238, v[200:201]\n"
+             CC_RET
+    CC_H(51) CC_FPON CC_ADDR("v[220:221]", "7") CC_ALLOK CC_LANEPTR                                         // fld
              "global_load_dwordx2 v[200:201], v[206:207], off\n"
-             "s_lshl_b32 s55, s57, 2\n" "s_add_u32 s55, s55, s92\n" "v_add_u32 v202, s55, %[xb]\n"
-             CC_LANES_SEQ
+             CC_FADDR("v238")
              "s_waitcnt vmcnt(0)\n"
-             "ds_write_b64 v202, v[200:201]\n"
-             CC_NEXT_SEQ
-    CC_H(41) "s_bitcmp1_b32 s90, 2\n" "s_cbranch_scc0 L_bad_%=\n"                                           // fsw
-             "s_lshr_b32 s55, s40, 15\n" "s_and_b32 s55, s55, 0xf8\n" "s_add_u32 s55, s55, s92\n" "v_add_u32 v209, s55, %[xb]\n"
-             "ds_read_b64 v[196:197], v209\n"
-             CC_ADDR("4", "3")
-             CC_STCHK("4")
-             "s_xor_b64 s[68:69], s[68:69], exec\n" "s_cbranch_scc1 L_bad_%=\n"
-             CC_LANEPTR
+             "ds_write_b64 v238, v[200:201]\n"
+             CC_RET
+    CC_H(52) CC_FPON CC_FADDR("v238")                                                                       // fsw
+             "ds_read_b64 v[196:197], v238\n"
+             CC_ADDR("v[218:219]", "3") CC_STCHK("4") CC_ALLOK CC_LANEPTR
              "s_waitcnt lgkmcnt(0)\n"
              "global_store_dword v[206:207], v196, off\n"
-             CC_LANES_SEQ CC_NEXT_SEQ
-    CC_H(42) "s_bitcmp1_b32 s90, 2\n" "s_cbranch_scc0 L_bad_%=\n"                                           // fsd
-             "s_lshr_b32 s55, s40, 15\n" "s_and_b32 s55, s55, 0xf8\n" "s_add_u32 s55, s55, s92\n" "v_add_u32 v209, s55, %[xb]\n"
-             "ds_read_b64 v[196:197], v209\n"
-             CC_ADDR("8", "7")
-             CC_STCHK("8")
-             "s_xor_b64 s[68:69], s[68:69], exec\n" "s_cbranch_scc1 L_bad_%=\n"
-             CC_LANEPTR
+             CC_RET
+    CC_H(53) CC_FPON CC_FADDR("v238")                                                                       // fsd
+             "ds_read_b64 v[196:197], v238\n"
+             CC_ADDR("v[220:221]", "7") CC_STCHK("8") CC_ALLOK CC_LANEPTR
              "s_waitcnt lgkmcnt(0)\n"
              "global_store_dwordx2 v[206:207], v[196:197], off\n"
-             CC_LANES_SEQ CC_NEXT_SEQ
-    CC_H(43)
+             CC_RET
+    CC_H(54) "v_mov_b32 v0, s39\n"                                                                          // mulh* div* rem* Zb*
+             "v_sub_u32 v1, v198, v196\n"
+             "v_mov_b32 v2, v194\n" "v_mov_b32 v3, v195\n" "v_mov_b32 v4, v196\n" "v_mov_b32 v5, v197\n" "v_mov_b32 v6, s52\n"
+             "s_waitcnt lgkmcnt(0)\n"                      // the successor's record must have landed: the callee may use those registers
+             CC_CALL("wsp_pure_int")
+             "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"
+    CC_H(55) CC_PURE_FP_CALL "ds_write_b64 v241, v[0:1]\n" "s_branch L_resume_%=\n"                         // F / D -> f[rd]
+    CC_H(56) CC_PURE_FP_CALL "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"  // F / D -> x[rd]
     // ------------------------------------------------------------------ exit: x file back to LDS
     "L_exit_%=:\n"
-    "s_mov_b64 exec, s[84:85]\n"                   // only lanes that took part own an x block (the others alias lane 0's / their owner's)
+    "s_mov_b64 exec, s[70:71]\n"                   // only lanes that took part own an x block (the others alias lane 0's / their owner's)
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-    "ds_write_b64 %[xb], v[130:131] offset:8\n"    "ds_write_b64 %[xb], v[132:133] offset:16\n"   "ds_write_b64 %[xb], v[134:135] offset:24\n"
-    "ds_write_b64 %[xb], v[136:137] offset:32\n"   "ds_write_b64 %[xb], v[138:139] offset:40\n"   "ds_write_b64 %[xb], v[140:141] offset:48\n"
-    "ds_write_b64 %[xb], v[142:143] offset:56\n"   "ds_write_b64 %[xb], v[144:145] offset:64\n"   "ds_write_b64 %[xb], v[146:147] offset:72\n"
-    "ds_write_b64 %[xb], v[148:149] offset:80\n"   "ds_write_b64 %[xb], v[150:151] offset:88\n"   "ds_write_b64 %[xb], v[152:153] offset:96\n"
-    "ds_write_b64 %[xb], v[154:155] offset:104\n"  "ds_write_b64 %[xb], v[156:157] offset:112\n"  "ds_write_b64 %[xb], v[158:159] offset:120\n"
-    "ds_write_b64 %[xb], v[160:161] offset:128\n"  "ds_write_b64 %[xb], v[162:163] offset:136\n"  "ds_write_b64 %[xb], v[164:165] offset:144\n"
-    "ds_write_b64 %[xb], v[166:167] offset:152\n"  "ds_write_b64 %[xb], v[168:169] offset:160\n"  "ds_write_b64 %[xb], v[170:171] offset:168\n"
-    "ds_write_b64 %[xb], v[172:173] offset:176\n"  "ds_write_b64 %[xb], v[174:175] offset:184\n"  "ds_write_b64 %[xb], v[176:177] offset:192\n"
-    "ds_write_b64 %[xb], v[178:179] offset:200\n"  "ds_write_b64 %[xb], v[180:181] offset:208\n"  "ds_write_b64 %[xb], v[182:183] offset:216\n"
-    "ds_write_b64 %[xb], v[184:185] offset:224\n"  "ds_write_b64 %[xb], v[186:187] offset:232\n"  "ds_write_b64 %[xb], v[188:189] offset:240\n"
-    "ds_write_b64 %[xb], v[190:191] offset:248\n"
-    "s_mov_b64 exec, s[72:73]\n"
+    "ds_write_b64 v229, v[130:131] offset:8\n"    "ds_write_b64 v229, v[132:133] offset:16\n"   "ds_write_b64 v229, v[134:135] offset:24\n"
+    "ds_write_b64 v229, v[136:137] offset:32\n"   "ds_write_b64 v229, v[138:139] offset:40\n"   "ds_write_b64 v229, v[140:141] offset:48\n"
+    "ds_write_b64 v229, v[142:143] offset:56\n"   "ds_write_b64 v229, v[144:145] offset:64\n"   "ds_write_b64 v229, v[146:147] offset:72\n"
+    "ds_write_b64 v229, v[148:149] offset:80\n"   "ds_write_b64 v229, v[150:151] offset:88\n"   "ds_write_b64 v229, v[152:153] offset:96\n"
+    "ds_write_b64 v229, v[154:155] offset:104\n"  "ds_write_b64 v229, v[156:157] offset:112\n"  "ds_write_b64 v229, v[158:159] offset:120\n"
+    "ds_write_b64 v229, v[160:161] offset:128\n"  "ds_write_b64 v229, v[162:163] offset:136\n"  "ds_write_b64 v229, v[164:165] offset:144\n"
+    "ds_write_b64 v229, v[166:167] offset:152\n"  "ds_write_b64 v229, v[168:169] offset:160\n"  "ds_write_b64 v229, v[170:171] offset:168\n"
+    "ds_write_b64 v229, v[172:173] offset:176\n"  "ds_write_b64 v229, v[174:175] offset:184\n"  "ds_write_b64 v229, v[176:177] offset:192\n"
+    "ds_write_b64 v229, v[178:179] offset:200\n"  "ds_write_b64 v229, v[180:181] offset:208\n"  "ds_write_b64 v229, v[182:183] offset:216\n"
+    "ds_write_b64 v229, v[184:185] offset:224\n"  "ds_write_b64 v229, v[186:187] offset:232\n"  "ds_write_b64 v229, v[188:189] offset:240\n"
+    "ds_write_b64 v229, v[190:191] offset:248\n"
+    "s_mov_b64 exec, s[68:69]\n"
+    "v_mov_b32 %[vpc], v234\n"  "v_mov_b32 %[vit], v235\n"  "v_mov_b32 %[ncv], v236\n"  "v_mov_b32 %[fcsr], v237\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [vpc] "+v"(vpc), [vit] "+v"(vit_), [ncv] "+v"(ncv_)
-    : [recs] "s"(recs), [nmbase] "s"(nmbase), [msize] "s"(msize), [tlo] "s"(tlo), [thi] "s"(thi), [ntlo] "s"(ntlo), [tlen] "s"(tlen_ct),
-      [amhi] "s"(amhi), [cfg] "s"(cfg), [lpwsh] "s"(lpw_shift), [foff] "s"(foff), [n] "s"(n), [xb] "v"(xb), [arena] "v"(arena), [tohost] "v"(tohost)
+    : [vpc] "+v"(vpc), [fcsr] "+v"(fcsr), [vit] "+v"(vit_), [ncv] "+v"(ncv_)
+    : [recs] "v"(hrecs), [mbase] "v"(mbase), [msize] "v"(msize), [tlo] "v"(tlo), [thi] "v"(thi), [tlen] "v"(tlen), [cfg] "v"(cfg),
+      [lpwsh] "v"(lpw_shift), [foff] "v"(foff), [n] "v"(n), [isa] "v"(isa), [xb] "v"(xb), [arena] "v"(arena), [tohost] "v"(tohost)
     : CC_CLOBBERS);
   vit = vit_; ncv = ncv_;
 }
@@ -437,7 +526,7 @@ __device__ __forceinline__ void conv_core(const void* recs, u64 nmbase, u64 msiz
 
 #else   // host pass of the same translation unit: the kernels' bodies are parsed but never run there
 namespace wsp {
-__device__ void conv_core(const void* recs, u64 nmbase, u64 msize, u64 tlo, u64 thi, u64 ntlo, u32 tlen_ct, u32 amhi, u32 cfg, u32 lpw_shift,
-                          u32 foff, u32 n, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& vit, u32& ncv);
+__device__ void conv_core(const void* hrecs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg, u32 lpw_shift, u32 foff, u32 n,
+                          u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr, u32& vit, u32& ncv);
 }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -37,7 +37,7 @@ using namespace wsp;
 enum { H64_PC, H64_MSTATUS, H64_CYCLE, H64_INSTRET, H64_EXEC, H64_RETIRED, H64_THASH, H64_LR_ADDR, H64_EXEC_LAST_ILL, H64_STOP_VALUE, H64_COUNT };
 enum { H32_FCSR, H32_PRIV, H32_STATUS, H32_CONSEC_ILL, H32_HTIF_DEV, H32_FLAGS, H32_COUNT };
 
-struct ProgDev { u64 text_lo, text_hi; const Rec* recs; };
+struct ProgDev { u64 text_lo, text_hi; const Rec* recs; const HRec* hrecs; };   // hrecs: hot records of the hand-written loop, or null
 
 struct DevState {
   u32 n_harts, n_waves, lpw, lpw_shift, S, isa, hart_id_base, tlb_n;
@@ -339,7 +339,7 @@ __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u3
 // Lanes are grouped by instruction word: each distinct word present is executed once, for the lanes that hold it, with the word
 // in scalar registers - the unit's decode and dispatch then run on the scalar unit (the sub-groups of a wave of replicas hold the
 // same word, and even a mixed wave pays no more than the divergent form would).
-struct VWarmArgs { const Rec* recs; u64 text_lo, text_hi, tohost; };
+struct VWarmArgs { const Rec* recs; u64 text_lo, text_hi, tohost, stop_pc; };
 #ifdef WSP_INSPECT
 __device__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags, u32 max_n);
 #else
@@ -469,9 +469,58 @@ __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64
   if (!L.fast_tr_allowed()) return r;
   Lane<DevMem>::FastTr t; L.fast_tr_begin(t);
   u32 n = 0;
-  while (n < max_n && L.template fast_step_translated<TRACE>(va.recs, t)) ++n;
+  // the stop address is a virtual one: the record patch of wsp_batch_set_stop sits at the physical slot of the same number, so
+  // with VA != PA only this compare ends the run there (Hart.cpp:6063 compares the pc)
+  while (n < max_n && L.h.pc != va.stop_pc && L.template fast_step_translated<TRACE>(va.recs, t)) ++n;
   r.pc = L.h.pc; r.thash = L.h.thash; r.n = n; r.fcsr = L.h.fcsr;
   return r;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------ compiled semantics called from the hand-written loop
+// Pure functions of their arguments (no hart state, no memory): the loop (wsp_conv_core.h) marshals operands into the argument
+// registers of the standard calling convention and calls them by name.  Every lane active at the call holds the same instruction,
+// so the record goes through scalar registers and the dispatch inside runs as scalar branches.  The register file of the f
+// operands is a three-entry stand-in (PureMem): exec_fp reads f[rs1] / f[rs2] / f[rs3] and writes one result.
+struct PureMem : DevMem {
+  u64 fv[3]; u32 fr[3]; u64 out;
+  __device__ __forceinline__ u64 rf(u32 r) const { return r == fr[0] ? fv[0] : r == fr[1] ? fv[1] : fv[2]; }
+  __device__ __forceinline__ void wf(u32, u64 v) { out = v; }
+  __device__ __forceinline__ void wx(u32, u64 v) { out = v; }
+};
+struct WspPureRet { u64 val; u32 fcsr, ok; };
+#ifdef WSP_INSPECT
+extern "C" __device__ WspPureRet wsp_pure_fp(u32 w0, i32 imm, u64 xa, u64 f1, u64 f2, u64 f3, u32 fcsr, u32 isa);
+extern "C" __device__ u64 wsp_pure_int(u32 w0, i32 imm, u64 a, u64 b, u32 isa);
+#else
+extern "C" __device__ __noinline__ __attribute__((used)) WspPureRet wsp_pure_fp(u32 w0, i32 imm, u64 xa, u64 f1, u64 f2, u64 f3, u32 fcsr, u32 isa)
+{
+  w0 = wsp_uni32(w0); imm = (i32)wsp_uni32((u32)imm); isa = wsp_uni32(isa);
+  Lane<PureMem, true> L;
+  L.isa = isa; L.h.fcsr = fcsr; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.flags = HF_NOTRACE; L.h.status = ST_RUNNING; L.h.priv = PRV_M;
+  L.s.chg = 0;
+  Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = 0;
+  L.m.fr[0] = rec_rs1(rec); L.m.fr[1] = rec_rs2(rec); L.m.fr[2] = rec_rs3(rec); L.m.fv[0] = f1; L.m.fv[1] = f2; L.m.fv[2] = f3; L.m.out = 0;
+  WspPureRet r; r.val = 0; r.fcsr = fcsr; r.ok = 0;
+  const u32 op = w0 & 0xff;
+  const bool uses_rm = (op >= OP_FADD && op <= OP_FMA) || op == OP_FCVT_F2I || op == OP_FCVT_I2F || op == OP_FCVT_FF;
+  int rm = 0;
+  if (uses_rm && !L.fp_rm((u32)imm & 7, rm)) return r;          // reserved rounding mode: the general path raises the trap
+  L.exec_fp(rec, xa, 0);
+  if (L.s.chg & CH_BAIL) return r;
+  r.val = L.m.out; r.fcsr = L.h.fcsr; r.ok = 1;
+  return r;
+}
+extern "C" __device__ __noinline__ __attribute__((used)) u64 wsp_pure_int(u32 w0, i32 imm, u64 a, u64 b, u32 isa)
+{
+  w0 = wsp_uni32(w0); imm = (i32)wsp_uni32((u32)imm); isa = wsp_uni32(isa);
+  Lane<PureMem, true> L; L.isa = isa;
+  Rec rec; rec.w0 = w0; rec.imm = imm; rec.pad = 0; rec.raw = 0;
+  const u32 op = w0 & 0xff;
+  u64 v;
+  if (op == OP_ZB) v = L.exec_zb(rec_rs3(rec), (w0 & F_IMM) ? 0 : imm, a, (w0 & F_IMM) ? (u64)(i64)imm : b);
+  else v = L.muldiv(op, a, b);
+  return (isa & ISA_RV32) ? (u64)(i64)(i32)v : v;                // Lane::wx: an RV32 hart's registers hold the value sign-extended
 }
 #endif
 
@@ -613,14 +662,15 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         u32 vpc = can ? (u32)off64 : 0xffffffffu;          // lanes that take no part never match a scheduled pc
         u32 vit = 0, ncv = 0, left_it = n;
 #if WSP_CONV_ASM
-        // untraced: the hand-written loop (wsp_conv_core.h), same contract; its record offsets are 32-bit (text below 512 MiB)
-        const bool use_asm = !(TRACE && tr) && tlen <= (1u << 29);
+        // untraced: the hand-written loop (wsp_conv_core.h), same contract; it reads the program's hot records
+        const u64 hrecs_a = (u64)(size_t)pd.hrecs;
+        const bool use_asm = !(TRACE && tr) && hrecs_a != 0;
         if (use_asm) {
           const bool fsd_all = FP && __all(!can || fsd);
-          const u32 cfg = (u32)__builtin_amdgcn_readfirstlane((int)((rv32 ? 2u : 0u) | (fsd_all ? 4u : 0u) | (boxd ? 8u : 0u)));
-          const u32 amhi = (u32)__builtin_amdgcn_readfirstlane((int)(rv32 ? 0u : 0xffffffffu));
-          const u32 tlen_ct = (u32)__builtin_amdgcn_readfirstlane((int)(zca ? tlen : 0u));
-          conv_core(recs_u, 0 - mbase, msize, tlo, thi, 0 - tlo, tlen_ct, amhi, cfg, d.lpw_shift, foff, n, xb, L.m.arena, tohost, vpc, vit, ncv);
+          const u32 cfg = (rv32 ? 2u : 0u) | (fsd_all ? 4u : 0u) | (boxd ? 8u : 0u);
+          u32 vfcsr = L.h.fcsr;
+          conv_core((const void*)(size_t)hrecs_a, mbase, msize, tlo, thi, tlen, cfg, d.lpw_shift, foff, n, d.isa, xb, L.m.arena, tohost, vpc, vfcsr, vit, ncv);
+          if (can) L.h.fcsr = vfcsr;
         } else {
 #endif
         u32 upc = wave_min_dpp(vpc);
@@ -964,7 +1014,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     if (swarm_can && swarm_skip) --swarm_skip;
     else if (swarm_can) {
       // S / U-mode code under Sv39: the translated warm path (wsp_swarm); a hart it does not take is back at once
-      VWarmArgs sa; sa.recs = recs; sa.text_lo = L.text_lo; sa.text_hi = L.text_hi; sa.tohost = L.tohost;
+      VWarmArgs sa; sa.recs = recs; sa.text_lo = L.text_lo; sa.text_hi = L.text_hi; sa.tohost = L.tohost; sa.stop_pc = L.stop_pc;
       const u64 left = stop_at - L.h.exec;
       const u32 smax = left > 1024 ? 1024u : (u32)left;
       const SWarmRet w = (TRACE && tr) ? wsp_swarm<true>(dp, sa, L.h.pc, L.h.thash, L.h.flags, L.h.fcsr, smax)
@@ -1000,7 +1050,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         if (cand || helper) {
           // one call site for the hart's lane and its helpers: they execute the call together.  (A helper lane was set up with
           // its hart's slot: program image, text bounds and tohost are the owner's.)
-          VWarmArgs va; va.recs = recs; va.text_lo = L.text_lo; va.text_hi = L.text_hi; va.tohost = L.tohost;
+          VWarmArgs va; va.recs = recs; va.text_lo = L.text_lo; va.text_hi = L.text_hi; va.tohost = L.tohost; va.stop_pc = ~0ULL;
           const unsigned long long pv0 = WSP_PROF_T();
           const WarmRet w = wsp_vwarm(dp, va, vw0, vimm, vraw, vpc, vth, vfcsr, vfl, vmax);
           WSP_PROF_ADD(10, WSP_PROF_T() - pv0); WSP_PROF_ADD(9, 1); WSP_PROF_ADD(11, __popcll(__ballot(cand && w.handled)));
@@ -1058,6 +1108,15 @@ __global__ void wsp_predecode_kernel(const u8* img, u64 n_bytes, u32 isa, Rec* o
   else { r = mk(OP_SLOWFETCH, 0, 0, 0, 0); r.raw = lo; }   // upper half lies outside the decoded range
   finish_rec(r);
   out[i] = r;
+}
+
+// Hot records of one program image from its pre-decoded records (two sentinels included: class 0 = not inline).
+__global__ void wsp_hrec_kernel(const Rec* recs, u64 nslots, u32 isa, u64 text_lo, u32 text_len, HRec* out)
+{
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nslots + 2) return;
+  if (i >= nslots) { HRec h; for (u32 k = 0; k < 8; ++k) h.w[k] = 0; h.w[1] = 2; h.w[4] = 64; h.w[5] = 64; out[i] = h; return; }
+  out[i] = mk_hrec(recs[i], isa, text_lo, text_len, (u32)(i * 2));
 }
 
 __global__ void wsp_decode_words_kernel(const u32* words, u64 n, u32 isa, Rec* out)
@@ -1269,6 +1328,7 @@ static int scratch_of(int dev, u64** out)
 struct Program {
   u64 text_lo = 0, text_hi = 0;
   Rec* d_recs = nullptr;
+  HRec* d_hrecs = nullptr;             // hot records (wsp_conv_core.h); null for single-hart programs loaded in bulk
   bool pooled = false;                 // d_recs points into one of the batch's rec_pools (wsp_batch_load_elf_many)
   std::map<std::string, u64> symbols;
 };
@@ -1307,7 +1367,7 @@ static void snap_parts(wsp_batch* b, SnapPart out[WSP_SNAP_PARTS])
 static int upload_progs(wsp_batch* b)
 {
   std::vector<ProgDev> v(b->progs.size());
-  for (size_t i = 0; i < v.size(); ++i) { v[i].text_lo = b->progs[i].text_lo; v[i].text_hi = b->progs[i].text_hi; v[i].recs = b->progs[i].d_recs; }
+  for (size_t i = 0; i < v.size(); ++i) { v[i].text_lo = b->progs[i].text_lo; v[i].text_hi = b->progs[i].text_hi; v[i].recs = b->progs[i].d_recs; v[i].hrecs = b->progs[i].d_hrecs; }
   if (v.size() > b->d_progs_cap) {
     if (b->d_progs) HIPOK(hipFree(b->d_progs));
     b->d_progs_cap = std::max<size_t>(16, v.size() * 2);
@@ -1348,7 +1408,7 @@ extern "C" void wsp_batch_destroy(wsp_batch* b)
 {
   if (!b) return;
   hipSetDevice(b->device);
-  for (auto& p : b->progs) if (p.d_recs && !p.pooled) hipFree(p.d_recs);
+  for (auto& p : b->progs) { if (p.d_recs && !p.pooled) hipFree(p.d_recs); if (p.d_hrecs) hipFree(p.d_hrecs); }
   for (Rec* p : b->rec_pools) hipFree(p);
   void* ptrs[] = { b->d.x, b->d.f, b->d.hot64, b->d.hot32, b->d.cold, b->d.tlb, b->d.vreg, b->d.tohost, b->d.max_exec, b->d.prog, b->d.arena, b->d.running, b->d_progs, b->d_memhash, b->d_results, b->d_state, b->d.ring, b->d.ring_pos, b->d.max_ret, b->d.stop_pc };
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1554,6 +1614,22 @@ static int set_u32_slots(wsp_batch* b, u32* base, u32 lo, u32 hi, u32 val)
   return WSP_OK;
 }
 
+// Hot records for a program whose harts may share waves (the hand-written converged loop reads them).
+static int build_hrecs(wsp_batch* b, Program& p)
+{
+  if (!p.d_recs || p.d_hrecs) return WSP_OK;
+  const u64 nslots = (p.text_hi - p.text_lo) / 2;
+  if (nslots >= (1u << 27)) return WSP_OK;             // the loop's record offsets are 32-bit: larger images run the C++ loop
+  HRec* h = nullptr;
+  HIPOK(hipMalloc(&h, (nslots + 2) * sizeof(HRec)));
+  hipLaunchKernelGGL(wsp_hrec_kernel, dim3((unsigned)((nslots + 2 + 255) / 256)), dim3(256), 0, b->stream, (const Rec*)p.d_recs, nslots, b->d.isa,
+                     p.text_lo, (u32)(p.text_hi - p.text_lo), h);
+  hipError_t e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e != hipSuccess) { hipFree(h); return fail(WSP_EHIP, std::string("hot records: ") + hipGetErrorString(e)); }
+  p.d_hrecs = h;
+  return WSP_OK;
+}
+
 // Turn the pre-decoded record at `stop_pc` of program `pg` into OP_STOPCHK (see wsp_batch_set_stop).
 static int patch_stop(wsp_batch* b, u32 pg, u64 stop_pc)
 {
@@ -1564,11 +1640,8 @@ static int patch_stop(wsp_batch* b, u32 pg, u64 stop_pc)
   if ((w0 & 0xff) == OP_SLOWFETCH || (w0 & 0xff) == OP_STOPCHK) return WSP_OK;
   w0 = (w0 & ~0xffu) | OP_STOPCHK;
   HIPOK(hipMemcpy(w0p, &w0, 4, hipMemcpyHostToDevice));
-  // ... and out of the hand-written loop's inline subset too (its dispatch goes by the handler class in Rec.pad)
-  u32* padp = &p.d_recs[(stop_pc - p.text_lo) / 2].pad; u32 pad = 0;
-  HIPOK(hipMemcpy(&pad, padp, 4, hipMemcpyDeviceToHost));
-  pad &= ~0xfe00u;
-  HIPOK(hipMemcpy(padp, &pad, 4, hipMemcpyHostToDevice));
+  // ... and out of the hand-written loop's inline subset too (handler offset 0 = not inline)
+  if (p.d_hrecs) { const u32 zero = 0; HIPOK(hipMemcpy(&p.d_hrecs[(stop_pc - p.text_lo) / 2].w[0], &zero, 4, hipMemcpyHostToDevice)); }
   return WSP_OK;
 }
 
@@ -1590,6 +1663,7 @@ static int add_program(wsp_batch* b, u32 lo, u32 hi, u64 text_lo, const std::vec
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(b->stream));
     p.d_recs = recs.as<Rec>(); recs.p = nullptr;       // owned by the batch from here on
+    if (hi - lo > 1) { int rc = build_hrecs(b, p); if (rc) return rc; }
   }
   b->progs.push_back(p);
   u32 id = (u32)b->progs.size() - 1;
@@ -1852,6 +1926,7 @@ extern "C" int wsp_batch_load_elf_many(wsp_batch* b, uint32_t hart_lo, uint32_t 
   for (u32 i = 0; i < count; ++i) {
     Program p; p.symbols = std::move(pes[i].syms);
     if (mps[i].n_bytes) { p.text_lo = pes[i].text_lo; p.text_hi = p.text_lo + mps[i].n_bytes; p.d_recs = recs_base + mps[i].rec_off; p.pooled = true; }
+    if (harts_per_elf > 1) { rc = build_hrecs(b, p); if (rc) return rc; }
     b->progs.push_back(std::move(p));
   }
   rc = upload_progs(b); if (rc) return rc;
