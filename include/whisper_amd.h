@@ -193,7 +193,9 @@ int  wsp_decode_words_host(const char* isa, const uint32_t* words, size_t n, wsp
 /* Run the device build of the softfloat (the arithmetic behind float.cpp / float-util.hpp:230-930, which the reference gets from
  * third_party/softfloat) over n operand triples on the GPU: out[i], flags[i] = op(a[i], b[i], c[i]) under rounding mode rm (0..4,
  * RISC-V order).  op & 0x100 selects double precision; low byte: 0 add 1 sub 2 mul 3 div 4 sqrt 5 fused multiply-add,
- * 6..9 float -> integer (bit 0 signed, bit 1 64-bit), 10..13 integer c -> float (same bits), 14 convert to the other format. */
+ * 6..9 float -> integer (bit 0 signed, bit 1 64-bit), 10..13 integer c -> float (same bits), 14 convert to the other format.
+ * op & 0x200: evaluate the way the step kernel does for double precision under round-to-nearest-even - on the FP unit with
+ * exact flags where the operands allow (flags[i] bit 31 set then), the integer routine otherwise. */
 int  wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n, uint64_t* out, uint32_t* flags);
 /* Parse an ISA string into the internal option bit set (tests). */
 uint32_t wsp_isa_flags(const char* isa);

@@ -73,11 +73,31 @@ template <class F> static void one(const char* tag, u64 a, u64 b, u64 c)
       T2(sg ? (w ? "from_i64" : "from_i32") : (w ? "from_u64" : "from_u32"), int_to_f<F>(c, sg, w, rm, f), Ref<F>::fromi(c, sg, w)); }
   }
 }
+// The FP-unit paths (hw_* in the header: round to nearest even, ordinary operands) against the real library, wherever they apply.
+static long hw_hits = 0;
+static void one_hw(u64 a, u64 b, u64 c)
+{
+  softfloat_roundingMode = softfloat_round_near_even; unsigned f; u64 g, e;
+#define TH(NAME, CALL, REF) f = 0; g = 0; if (CALL) { ++hw_hits; softfloat_exceptionFlags = 0; e = REF; chk("hw." NAME, 0, a, b, c, g, f, e, softfloat_exceptionFlags); }
+  TH("add", hw_add64(a, b, g, f), Ref<F64>::add(a, b));
+  TH("sub", hw_add64(a, b ^ F64::SIGN, g, f), Ref<F64>::sub(a, b));
+  TH("mul", hw_mul64(a, b, g, f), Ref<F64>::mul(a, b));
+  TH("div", hw_div64(a, b, g, f), Ref<F64>::div(a, b));
+  TH("fma", hw_fma64(a, b, c, g, f), Ref<F64>::fma(a, b, c));
+  for (int k = 0; k < 4; ++k) { bool sg = k & 1, w = k & 2; u64 v = c >> (rnd() % 64); if (rnd() & 1) v = (u64)0 - v;
+    f = 0; g = hw_int_to_f64(v, sg, w, f); softfloat_exceptionFlags = 0; e = Ref<F64>::fromi(v, sg, w); chk("hw.fromi", 0, v, 0, 0, g, f, e, softfloat_exceptionFlags); }
+}
+// operands the way programs have them: moderate exponents, few significant bits, exact quotients and products
+static u64 rand64o() { u64 r = rnd(); u64 e = (u64)(1023 + (int)(rnd() % 40) - 20) << 52; u64 m = r & 0xfffffffffffffULL;
+  switch (rnd() % 4) { case 0: m &= ~((1ULL << (rnd() % 53)) - 1); break; case 1: m = 0; break; default: break; }
+  return (r & 0x8000000000000000ULL) | e | m; }
+
 int main(int argc, char** argv)
 {
   long n = argc > 1 ? atol(argv[1]) : 200000;
   auto s64 = specials64(); auto s32 = specials32();
   for (u64 a : s64) for (u64 b : s64) { one<F64>("f64", a, b, s64[rnd() % s64.size()]); }
+  for (u64 a : s64) for (u64 b : s64) { one_hw(a, b, s64[rnd() % s64.size()]); }
   for (u64 a : s32) for (u64 b : s32) { one<F32>("f32", a, b, s32[rnd() % s32.size()]); }
   for (u64 a : s64) for (u64 b : s64) for (int k = 0; k < 4; ++k) one<F64>("f64", a, b, s64[rnd() % s64.size()]);
   for (long i = 0; i < n; ++i) {
@@ -86,6 +106,9 @@ int main(int argc, char** argv)
       softfloat_roundingMode = 0; c = f64_mul({a}, {b}).v ^ 0x8000000000000000ULL; if (rnd() & 1) c += (rnd() % 5) - 2; }
     if (rnd() % 8 == 0) b = a ^ (rnd() % 2 ? 0x8000000000000000ULL : 0) ^ (rnd() % 4);
     one<F64>("f64", a, b, c);
+    one_hw(a, b, c);
+    { u64 p = rand64o(), q = rand64o(), w = rand64o(); one_hw(p, q, w);
+      softfloat_roundingMode = 0; one_hw(f64_mul({p}, {q}).v, q, f64_mul({p}, {q}).v ^ 0x8000000000000000ULL); }   // often an exact quotient; fma cancels
     u64 x = rand32f(), y = rand32f(), z = rand32f();
     if (rnd() % 4 == 0) { softfloat_roundingMode = 0; z = f32_mul({(u32)x}, {(u32)y}).v ^ 0x80000000u; if (rnd() & 1) z = (u32)(z + (rnd() % 5) - 2); }
     if (rnd() % 8 == 0) y = (x ^ (rnd() % 2 ? 0x80000000u : 0) ^ (rnd() % 4)) & 0xffffffffu;
@@ -96,6 +119,6 @@ int main(int argc, char** argv)
   }
   for (u64 a : s64) for (int rm = 0; rm < 5; ++rm) { softfloat_roundingMode = rm_sf[rm]; unsigned f = 0; u64 g = f64_to_f32(a, rm, f); softfloat_exceptionFlags = 0; u64 e = f64_to_f32({a}).v; chk("f64_to_f32", rm, a, 0, 0, g, f, e, softfloat_exceptionFlags); }
   for (u64 x : s32) { unsigned f = 0; u64 g = f32_to_f64(x, f); softfloat_exceptionFlags = 0; u64 e = ::f32_to_f64({(u32)x}).v; chk("f32_to_f64", 0, x, 0, 0, g, f, e, softfloat_exceptionFlags); }
-  printf("checked %ld cases, %ld mismatches\n", total, bad);
+  printf("checked %ld cases (%ld on the FP-unit paths), %ld mismatches\n", total, hw_hits, bad);
   return bad > 255 ? 255 : (int)bad;
 }

@@ -108,3 +108,45 @@ def test_device_softfloat_matches_reference_library(dbl):
                     bad.append((op, rm, hex(a[i]), hex(b[i]), hex(cc[i]), hex(got[i]), gfl[i], hex(exp[i]), efl[i]))
     assert not bad, f"{len(bad)} of {total} cases differ; first: {bad[:5]}"
     print(f"{'f64' if dbl else 'f32'}: {total} device softfloat cases bit-exact against the reference library")
+
+
+def _rand64_ordinary(rng):
+    """Operands the way programs have them: moderate exponents, often few significant bits."""
+    r = rng.getrandbits(64); e = (1023 + rng.randrange(40) - 20) << 52; m = r & 0xfffffffffffff
+    k = rng.randrange(4)
+    if k == 0: m &= ~((1 << rng.randrange(53)) - 1)
+    elif k == 1: m = 0
+    return (r & (1 << 63)) | e | m
+
+
+def test_device_fp_unit_paths_match_reference_library():
+    """The step kernel's double-precision add / sub / mul / div / fused multiply-add / integer -> double under round-to-nearest-even
+    (hw_* in wsp_softfloat.h: the FP unit's result plus an error-free transformation for the inexact flag, the integer routine
+    outside their domain), gfx950 build, against the reference's SoftFloat: results and flags, and the share the FP unit took."""
+    if not rvoracle.has_softfloat():
+        pytest.skip("oracle/_ref/libsoftfloat_ref.so not built")
+    a, b, c = _operands(True, 60000, 17)
+    rng = random.Random(5)
+    for _ in range(120000):
+        x, y, z = _rand64_ordinary(rng), _rand64_ordinary(rng), _rand64_ordinary(rng)
+        a.append(x); b.append(y); c.append(z)
+    prod, _ = _ref(0x100 | 2, 0, a, b, c)
+    sign = 1 << 63
+    # exact quotients (a := a * b when that product was exact-ish) and cancelling fused multiply-adds
+    cfma = [((p ^ sign) + rng.randrange(5) - 2) & M64 if i % 3 == 0 else z for i, (p, z) in enumerate(zip(prod, c))]
+    adiv = [p if i % 2 else x for i, (p, x) in enumerate(zip(prod, a))]
+    ints = [rng.getrandbits(64) >> rng.randrange(64) if i % 2 else (-(rng.getrandbits(63) >> rng.randrange(63))) & M64 for i in range(len(a))]
+    bad, total, hw = [], 0, 0
+    for op in (0, 1, 2, 3, 5, 10, 11, 12, 13):
+        aa = adiv if op == 3 else a
+        cc = cfma if op == 5 else ints if op >= 10 else c
+        got, gfl = W.sf_eval(0x300 | op, 0, aa, b, cc)
+        exp, efl = _ref(0x100 | op, 0, aa, b, cc)
+        total += len(a)
+        for i in range(len(a)):
+            hw += gfl[i] >> 31
+            if got[i] != exp[i] or (gfl[i] & 0x7fffffff) != efl[i]:
+                bad.append((op, hex(aa[i]), hex(b[i]), hex(cc[i]), hex(got[i]), hex(gfl[i]), hex(exp[i]), efl[i]))
+    assert not bad, f"{len(bad)} of {total} cases differ; first: {bad[:5]}"
+    assert hw > total // 2, (hw, total)
+    print(f"{total} cases bit-exact, {hw} on the FP unit")

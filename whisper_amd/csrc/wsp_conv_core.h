@@ -28,6 +28,13 @@
 //    outside the inline subset, a reserved rounding mode) changes nothing for ANY lane of the group and ends the loop with ncv = 1
 //    on those lanes: the general path executes that instruction (same contract as the C++ loop, coarser grain: rare events only).
 //
+//  * measured on gfx950 (tools/lab/valu_rate.hip): a wave that has its SIMD to itself issues a vector ALU instruction every
+//    ~1.9 ns with 15 or more lanes enabled in exec, but only every ~8.6 ns with 4 or fewer - and a 4096-hart batch puts 4 harts in
+//    a wave.  So the vector ALU always runs with EVERY lane of the wave enabled (lanes without a hart, and lanes outside the group
+//    in diverged mode, compute on garbage); results are committed with v_cndmask under the mask of the lanes that execute
+//    (s[84:85]: every hart's lane in converged mode, the group in diverged mode), exec is narrowed to that mask only around
+//    memory and LDS instructions, and checks (`all lanes fine`, `who takes the branch`) are and-ed with it;
+//
 // gfx940-family wait states observed by hand (nothing inside an asm statement is padded by the compiler): VALU write of an
 // SGPR / VCC -> VALU read of it: 2; VALU write of a VGPR -> v_readlane / v_readfirstlane / DPP read: 1 / 1 / 2.
 #pragma once
@@ -41,8 +48,8 @@
 //  callee-saved: s34 upc  s35 spc  s36 steps left - 1  s37 its value when converged mode was entered  s38 record word 6  s39 word 7
 //                s48 mode (0 converged, 1 diverged)  s49 cfg (bit 1 rv32, bit 2 FS dirty, bit 3 D)  s50 lpw shift  s51 f block offset
 //                s52 isa  s53 text length  s[54:55] return address of the step  s[64:65] handler table
-//                s[66:67] exec before the membership test (diverged mode)  s[68:69] exec at entry  s[70:71] eligible lanes
-//                s[80:81] hot records  s[82:83] text_lo
+//                s[68:69] exec at entry (= while the loop runs)  s[70:71] eligible lanes
+//                s[80:81] hot records  s[82:83] text_lo  s[84:85] the lanes that execute the current instruction
 //  clobbered by calls: s[40:47] record buffer A  s[56:63] buffer B  s[72:79] buffer T (branch / jump target)
 //                s88 s89 scratch  s[90:91] dispatch target  s[92:93] s[94:95] scratch pairs
 //  v[128:193] x file  v[194:195] a  v[196:197] b  v[198:199] b + imm  v[200:201] result  v[202:209] scratch  v[210:211] tohost + 4
@@ -96,12 +103,9 @@
 // diverged mode: the group = lanes whose pc is the scheduled one; they retire and move on in the epilogue
 #define CC_DSTEP(Q0, Q1, Q23, Q4, Q5, Q6, Q7, QN)                                       \
   CC_FETCH(Q1, QN)                                                                      \
-  "v_cmp_eq_u32_e32 vcc, s34, v234\n"                                                   \
-  "s_and_saveexec_b64 s[66:67], vcc\n"                                                  \
+  "v_cmp_eq_u32_e64 s[84:85], s34, v234\n"                                              \
   CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                                     \
-  "v_mov_b32 v234, s35\n"                                                               \
-  "v_add_u32 v235, 1, v235\n"                                                           \
-  "s_mov_b64 exec, s[66:67]\n"                                                          \
+  CC_ADVANCE("s35")                                                                     \
   "s_waitcnt lgkmcnt(0)\n"                                                              \
   "s_mov_b32 s34, s35\n"                                                                \
   "s_sub_u32 s36, s36, 1\n"                                                             \
@@ -114,10 +118,15 @@
 
 // x[rd] = v[200:201] for the lanes of the group; back to the step's epilogue
 #define CC_WR                                                                           \
-  "s_set_gpr_idx_on s38, gpr_idx(DST)\n"                                                \
-  "v_mov_b32 v128, v200\n"                                                              \
-  "v_mov_b32 v129, v201\n"                                                              \
+  "s_set_gpr_idx_on s38, gpr_idx(SRC0,DST)\n"                                           \
+  "v_cndmask_b32_e64 v128, v128, v200, s[84:85]\n"                                      \
+  "v_cndmask_b32_e64 v129, v129, v201, s[84:85]\n"                                      \
   "s_set_gpr_idx_off\n"
+// the lanes that execute move to pc NPC (an SGPR) and retire one instruction
+#define CC_ADVANCE(NPC)                                                                 \
+  "v_mov_b32 v202, " NPC "\n"                                                           \
+  "v_addc_co_u32_e64 v235, s[92:93], 0, v235, s[84:85]\n"                               \
+  "v_cndmask_b32_e64 v234, v234, v202, s[84:85]\n"
 #define CC_RET "s_setpc_b64 s[54:55]\n"
 #define CC_WR_RET CC_WR CC_RET
 #define CC_H(k) ".org L_htab_%= + 512 * " #k "\n"
@@ -139,8 +148,10 @@
   "s_and_b64 s[92:93], s[92:93], s[94:95]\n"                                            \
   "s_and_b64 s[92:93], s[92:93], vcc\n"
 #define CC_ALLOK                                                                        \
-  "s_xor_b64 s[92:93], s[92:93], exec\n"                                                \
+  "s_andn2_b64 s[92:93], s[84:85], s[92:93]\n"                                          \
   "s_cbranch_scc1 L_bad_%=\n"
+#define CC_MEMEXEC "s_mov_b64 exec, s[84:85]\n"      /* side effects (memory, LDS, pc) only for the lanes that execute */
+#define CC_ALUEXEC "s_mov_b64 exec, s[68:69]\n"
 // lane address of arena offset v[204:205] -> v[206:207] (8-byte interleave across the wave's harts, DevMem::p)
 #define CC_LANEPTR                                                                      \
   "v_and_b32 v206, -8, v204\n"                                                          \
@@ -150,7 +161,7 @@
   "v_lshl_add_u64 v[206:207], v[206:207], 0, v[230:231]\n"
 #define CC_LOAD(LIM, SZM1, LDOP, EXT)                                                   \
   CC_ADDR(LIM, SZM1) CC_ALLOK CC_LANEPTR                                                \
-  LDOP " v[206:207], off\n"                                                             \
+  CC_MEMEXEC LDOP " v[206:207], off\n" CC_ALUEXEC                                       \
   "s_waitcnt vmcnt(0)\n"                                                                \
   EXT CC_WR_RET
 // stores: the data register's index is record word 6; also not tohost + 4 and not into the text
@@ -169,7 +180,7 @@
   "s_andn2_b64 s[92:93], s[92:93], s[88:89]\n"
 #define CC_STORE(LIM, SZ, SZM1, STOP)                                                   \
   CC_STDATA CC_ADDR(LIM, SZM1) CC_STCHK(SZ) CC_ALLOK CC_LANEPTR                         \
-  STOP "\n" CC_RET
+  CC_MEMEXEC STOP "\n" CC_ALUEXEC CC_RET
 #define CC_FADDR(dst) "s_add_u32 s88, s38, s51\n" "v_add_u32 " dst ", s88, v229\n"      /* LDS address of the f register of word 6 */
 #define CC_FPON "s_bitcmp1_b32 s49, 2\n" "s_cbranch_scc0 L_bad_%=\n"
 
@@ -186,17 +197,18 @@
   "s_cbranch_scc1 L_exit_conv_%=\n"                                                     \
   "s_branch L_CT_T_%=\n"
 #define CC_BR_FWD(CMP)                                                                  \
-  CMP " vcc, v[194:195], v[196:197]\n" CC_BR_HEAD                                       \
+  CMP " vcc, v[194:195], v[196:197]\n" "s_and_b64 vcc, vcc, s[84:85]\n" CC_BR_HEAD                                       \
   "s_cmp_lg_u64 vcc, 0\n"                                                               \
   "s_cbranch_scc1 L_br_some_%=\n"                                                       \
   CC_RET
 #define CC_BR_BACK(CMP)                                                                 \
-  CMP " vcc, v[194:195], v[196:197]\n" CC_BR_HEAD                                       \
+  CMP " vcc, v[194:195], v[196:197]\n" "s_and_b64 vcc, vcc, s[84:85]\n" CC_BR_HEAD                                       \
   "s_cmp_eq_u64 vcc, s[70:71]\n"                                                        \
   "s_cbranch_scc0 L_br_notall_%=\n"                                                     \
   CC_TAKEN_ALL
 #define CC_BR_OUT(CMP)                                                                  \
   CMP " vcc, v[194:195], v[196:197]\n"                                                  \
+  "s_and_b64 vcc, vcc, s[84:85]\n"                                                      \
   "s_cmp_lg_u64 vcc, 0\n"                                                               \
   "s_cbranch_scc1 L_bad_%=\n"                                                           \
   CC_RET
@@ -229,9 +241,9 @@
   "s_waitcnt lgkmcnt(0)\n"                                                              \
   CC_CALL("wsp_pure_fp")                                                                \
   "v_cmp_ne_u32_e32 vcc, 0, v3\n"                                                       \
-  "s_xor_b64 s[92:93], vcc, exec\n"                                                     \
+  "s_andn2_b64 s[92:93], s[84:85], vcc\n"                                               \
   "s_cbranch_scc1 L_bad_%=\n"                                                           \
-  "v_mov_b32 v237, v2\n"
+  "v_cndmask_b32_e64 v237, v237, v2, s[84:85]\n"
 
 #define CC_CLOBBERS \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
@@ -251,12 +263,12 @@
   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", \
   "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", \
   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", \
-  "s94", "s95", "m0", "vcc", "scc", "memory"
+  "s94", "s95", "vcc", "scc", "memory"
 
 namespace wsp {
 
 // One run of the converged loop.  Arguments that are the same for the whole wave may sit in any lane's registers (they are read
-// with v_readfirstlane).  hrecs: hot-record image of the wave's program; cfg: bit 1 rv32, bit 2 mstatus.FS dirty in every lane that
+// with v_readfirstlane).  hrecs: hot-record image of the wave's program; cfg: bit 1 rv32, bit 16 never enter converged mode (tests of the diverged steps), bit 2 mstatus.FS dirty in every lane that
 // takes part (flw / fld / fsw / fsd and F / D arithmetic inline), bit 3 D extension (flw boxes); xb: LDS byte offset of the lane's x
 // block; arena: the lane's arena base (DevMem::arena); vpc: the lane's pc as a text offset, 0xffffffff for lanes that take no part;
 // fcsr: the lane's fcsr; n: iterations (>= 1).  Out: vit = instructions retired by the lane, ncv != 0 = the lane stands at an
@@ -308,41 +320,67 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_add_u32 s64, s64, L_htab_%=-L_anchor_%=\n"
     "s_addc_u32 s65, s65, 0\n"
     "v_cmp_ne_u32_e64 s[70:71], -1, v234\n"
-    // ------------------------------------------------------------------ schedule: the minimum pc over all lanes; converged if all agree
+    "s_branch L_sched_%=\n"
+    // ------------------------------------------------------------------ a control transfer in diverged mode (or one that splits the
+    // wave), then the schedule: the minimum pc over all lanes; converged if all agree.  Laid out so that the diverged path falls
+    // through from here into its steps: with one wave on the SIMD every taken branch is ~11 ns of instruction refetch.
+    "L_br_mixed_%=:\n"                             // the wave diverges here
+    CC_FLUSH
+    "L_br_div_%=:\n"                               // the lanes that execute go their ways (vcc: those that take the branch)
+    "v_mov_b32 v202, s35\n"
+    "v_mov_b32 v203, s39\n"
+    "v_addc_co_u32_e64 v235, s[92:93], 0, v235, s[84:85]\n"
+    "v_cndmask_b32_e32 v202, v202, v203, vcc\n"
+    "v_cndmask_b32_e64 v234, v234, v202, s[84:85]\n"
+    "L_sched_count_%=:\n"
+    "s_sub_u32 s36, s36, 1\n"
+    "s_cbranch_scc1 L_exit_%=\n"
     "L_sched_%=:\n"
-    "s_mov_b64 exec, s[68:69]\n"
-    CC_DPPMIN("v234", "s34")
+    "s_cmp_gt_u32 s50, 2\n"                       // up to 4 harts per wave (lanes 0..3; the others hold -1): four lane reads, else
+    "s_cbranch_scc1 L_sched_dpp_%=\n"             // the six-step DPP reduction
+    "v_readlane_b32 s34, v234, 0\n"
+    "v_readlane_b32 s88, v234, 1\n"
+    "v_readlane_b32 s89, v234, 2\n"
+    "v_readlane_b32 s92, v234, 3\n"
+    "s_min_u32 s34, s34, s88\n"
+    "s_min_u32 s89, s89, s92\n"
+    "s_min_u32 s34, s34, s89\n"
+    "L_sched_have_%=:\n"
     "s_lshl_b32 s88, s34, 4\n"
     "s_waitcnt lgkmcnt(0)\n"                      // a successor record may still be on its way into buffer A: scalar loads land in any order
     "s_load_dwordx8 s[40:47], s[80:81], s88\n"
-    "v_cmp_eq_u32_e32 vcc, s34, v234\n"
-    "s_mov_b64 exec, s[70:71]\n"                  // from here on only lanes that take part are ever active
-    "s_cmp_eq_u64 vcc, s[70:71]\n"
+    "v_cmp_eq_u32_e64 s[84:85], s34, v234\n"      // the lanes that stand there (lanes without a hart hold -1)
+    "s_cmp_eq_u64 s[84:85], s[70:71]\n"
     "s_waitcnt lgkmcnt(0)\n"
-    "s_cbranch_scc0 L_go_div_%=\n"
+    "s_cbranch_scc1 L_go_conv_%=\n"
+    "L_go_div_%=:\n"
+    "s_mov_b32 s48, 1\n"
+    // ------------------------------------------------------------------ the steps, diverged mode
+    "L_DT_A_%=:\n" CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB) CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB)
+    "s_branch L_DT_A_%=\n"
+    "L_go_conv_%=:\n"
+    "s_bitcmp1_b32 s49, 16\n"                     // test hook: never enter converged mode
+    "s_cbranch_scc1 L_go_div_%=\n"
     "s_mov_b32 s48, 0\n"
     "s_mov_b32 s37, s36\n"
     "s_branch L_CT_A_%=\n"
-    "L_go_div_%=:\n"
-    "s_mov_b32 s48, 1\n"
-    "s_branch L_DT_A_%=\n"
+    "L_sched_dpp_%=:\n"
+    CC_DPPMIN("v234", "s34")
+    "s_branch L_sched_have_%=\n"
     // ------------------------------------------------------------------ the steps, converged mode
     "L_CT_T_%=:\n" CC_CSTEP_(CC_QT)
     "L_CT_A_%=:\n" CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB) CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB)
     "s_branch L_CT_A_%=\n"
-    // ------------------------------------------------------------------ the steps, diverged mode
-    "L_DT_A_%=:\n" CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB) CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB)
-    "s_branch L_DT_A_%=\n"
     // ------------------------------------------------------------------ shared pieces
     "L_bad_%=:\n"                                  // nobody of the group executes: general path
-    "v_mov_b32 v236, 1\n"
+    "v_cndmask_b32_e64 v236, v236, 1, s[84:85]\n"
     "s_cmp_eq_u32 s48, 0\n"
     "s_cbranch_scc1 L_exit_conv_%=\n"
-    "s_mov_b64 exec, s[66:67]\n"
     "s_branch L_exit_%=\n"
     "L_exit_conv_%=:\n"                            // converged mode ends: pc and retire count of every lane from the scalar state
     CC_FLUSH
-    "v_mov_b32 v234, s34\n"
+    "v_mov_b32 v202, s34\n"
+    "v_cndmask_b32_e64 v234, v234, v202, s[70:71]\n"
     "s_branch L_exit_%=\n"
     "L_br_some_%=:\n"                              // converged, forward branch, somebody takes it
     "s_cmp_eq_u64 vcc, s[70:71]\n"
@@ -352,29 +390,10 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_cmp_eq_u64 vcc, 0\n"
     "s_cbranch_scc0 L_br_mixed_%=\n"
     CC_RET
-    "L_br_mixed_%=:\n"                             // the wave diverges here
-    "v_mov_b32 v202, s35\n"
-    "v_mov_b32 v203, s39\n"
-    CC_FLUSH
-    "v_add_u32 v235, 1, v235\n"
-    "v_cndmask_b32_e32 v234, v202, v203, vcc\n"
-    "s_branch L_sched_count_%=\n"
-    "L_br_div_%=:\n"                               // diverged mode: the group's lanes go their ways
-    "v_mov_b32 v202, s35\n"
-    "v_mov_b32 v203, s39\n"
-    "v_add_u32 v235, 1, v235\n"
-    "v_cndmask_b32_e32 v234, v202, v203, vcc\n"
-    "s_mov_b64 exec, s[66:67]\n"
-    "L_sched_count_%=:\n"
-    "s_sub_u32 s36, s36, 1\n"
-    "s_cbranch_scc0 L_sched_%=\n"
-    "s_branch L_exit_%=\n"
     "L_resume_%=:\n"                               // after a call: the step's epilogue by hand, then the next record again
     "s_cmp_lg_u32 s48, 0\n"
     "s_cbranch_scc0 L_resume2_%=\n"
-    "v_mov_b32 v234, s35\n"
-    "v_add_u32 v235, 1, v235\n"
-    "s_mov_b64 exec, s[66:67]\n"
+    CC_ADVANCE("s35")
     "L_resume2_%=:\n"
     "s_mov_b32 s34, s35\n"
     "s_lshl_b32 s88, s34, 4\n"
@@ -390,19 +409,14 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_cbranch_scc1 L_exit_%=\n"
     "s_branch L_exit_conv_%=\n"
     "L_jal_div_%=:\n"
-    "v_mov_b32 v234, s39\n"
-    "v_add_u32 v235, 1, v235\n"
-    "s_mov_b64 exec, s[66:67]\n"
+    CC_ADVANCE("s39")
     "s_branch L_sched_count_%=\n"
     "L_jalr_tail_%=:\n"                            // lanes' targets in v202, link written
-    "v_mov_b32 v234, v202\n"
-    "v_add_u32 v235, 1, v235\n"
+    "v_addc_co_u32_e64 v235, s[92:93], 0, v235, s[84:85]\n"
+    "v_cndmask_b32_e64 v234, v234, v202, s[84:85]\n"
     "s_cmp_lg_u32 s48, 0\n"
-    "s_cbranch_scc1 L_jalr_div_%=\n"
+    "s_cbranch_scc1 L_sched_count_%=\n"
     CC_FLUSH
-    "s_branch L_sched_count_%=\n"
-    "L_jalr_div_%=:\n"
-    "s_mov_b64 exec, s[66:67]\n"
     "s_branch L_sched_count_%=\n"
     // ------------------------------------------------------------------ handlers, 512 bytes apart (class order: HC_* in wsp_core.h)
     ".p2align 9\n"
@@ -465,29 +479,31 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     CC_H(48) CC_STORE("v[220:221]", "8", "7", "global_store_dwordx2 v[206:207], v[196:197], off")
     CC_H(49) CC_RET                                                                                         // nop
     CC_H(50) CC_FPON CC_ADDR("v[218:219]", "3") CC_ALLOK CC_LANEPTR                                         // flw
-             "global_load_dword v200, v[206:207], off\n"
              CC_FADDR("v238")
              "s_bitcmp1_b32 s49, 3\n" "s_cselect_b32 s88, -1, 0\n" "v_mov_b32 v201, s88\n"
+             CC_MEMEXEC
+             "global_load_dword v200, v[206:207], off\n"
              "s_waitcnt vmcnt(0)\n"
              "ds_write_b64 v238, v[200:201]\n"
-             CC_RET
+             CC_ALUEXEC CC_RET
     CC_H(51) CC_FPON CC_ADDR("v[220:221]", "7") CC_ALLOK CC_LANEPTR                                         // fld
-             "global_load_dwordx2 v[200:201], v[206:207], off\n"
              CC_FADDR("v238")
+             CC_MEMEXEC
+             "global_load_dwordx2 v[200:201], v[206:207], off\n"
              "s_waitcnt vmcnt(0)\n"
              "ds_write_b64 v238, v[200:201]\n"
-             CC_RET
+             CC_ALUEXEC CC_RET
     CC_H(52) CC_FPON CC_FADDR("v238")                                                                       // fsw
              "ds_read_b64 v[196:197], v238\n"
              CC_ADDR("v[218:219]", "3") CC_STCHK("4") CC_ALLOK CC_LANEPTR
              "s_waitcnt lgkmcnt(0)\n"
-             "global_store_dword v[206:207], v196, off\n"
+             CC_MEMEXEC "global_store_dword v[206:207], v196, off\n" CC_ALUEXEC
              CC_RET
     CC_H(53) CC_FPON CC_FADDR("v238")                                                                       // fsd
              "ds_read_b64 v[196:197], v238\n"
              CC_ADDR("v[220:221]", "7") CC_STCHK("8") CC_ALLOK CC_LANEPTR
              "s_waitcnt lgkmcnt(0)\n"
-             "global_store_dwordx2 v[206:207], v[196:197], off\n"
+             CC_MEMEXEC "global_store_dwordx2 v[206:207], v[196:197], off\n" CC_ALUEXEC
              CC_RET
     CC_H(54) "v_mov_b32 v0, s39\n"                                                                          // mulh* div* rem* Zb*
              "v_sub_u32 v1, v198, v196\n"
@@ -495,7 +511,7 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
              "s_waitcnt lgkmcnt(0)\n"                      // the successor's record must have landed: the callee may use those registers
              CC_CALL("wsp_pure_int")
              "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"
-    CC_H(55) CC_PURE_FP_CALL "ds_write_b64 v241, v[0:1]\n" "s_branch L_resume_%=\n"                         // F / D -> f[rd]
+    CC_H(55) CC_PURE_FP_CALL CC_MEMEXEC "ds_write_b64 v241, v[0:1]\n" CC_ALUEXEC "s_branch L_resume_%=\n"                         // F / D -> f[rd]
     CC_H(56) CC_PURE_FP_CALL "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"  // F / D -> x[rd]
     // ------------------------------------------------------------------ exit: x file back to LDS
     "L_exit_%=:\n"

@@ -1331,9 +1331,13 @@ template <class MEM, bool DRY = false> struct Lane {
       case OP_FADD: case OP_FSUB: case OP_FMUL: case OP_FDIV: case OP_FSQRT: {
         if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
         if (dbl) {
-          u64 x = m.rf(rs1), y = m.rf(rs2);
-          u64 z = op == OP_FADD ? f_add<F64>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F64>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F64>(x, y, rm, fl)
-                : op == OP_FDIV ? f_div<F64>(x, y, rm, fl) : f_sqrt<F64>(x, rm, fl);
+          u64 x = m.rf(rs1), y = m.rf(rs2), z = 0;
+          // round to nearest even, ordinary operands: the FP unit's own result with the exact inexact flag (wsp_softfloat.h)
+          const bool hw = rm == RM_RNE && (op == OP_FADD ? hw_add64(x, y, z, fl) : op == OP_FSUB ? hw_add64(x, y ^ F64::SIGN, z, fl)
+                                           : op == OP_FMUL ? hw_mul64(x, y, z, fl) : op == OP_FDIV ? hw_div64(x, y, z, fl) : false);
+          if (!hw)
+            z = op == OP_FADD ? f_add<F64>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F64>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F64>(x, y, rm, fl)
+              : op == OP_FDIV ? f_div<F64>(x, y, rm, fl) : f_sqrt<F64>(x, rm, fl);
           wf(rd, z);
         } else {
           u64 x = rf_s(rs1), y = rf_s(rs2);
@@ -1347,6 +1351,8 @@ template <class MEM, bool DRY = false> struct Lane {
         u32 k = ((u32)r.imm >> 3) & 3, rs3 = rec_rs3(r);
         if (dbl) {
           u64 x = m.rf(rs1), y = m.rf(rs2), z = m.rf(rs3);
+          u64 hz = 0;
+          if (rm == RM_RNE && hw_fma64((k == 2 || k == 3) ? x ^ F64::SIGN : x, y, (k == 1 || k == 3) ? z ^ F64::SIGN : z, hz, fl)) { wf(rd, hz); or_fflags(fl); mark_fs_dirty(); return; }
           if (k == 1 || k == 3) z = fneg<F64>(z, fl);
           if (k == 2 || k == 3) x = fneg<F64>(x, fl);
           wf(rd, f_fma<F64>(x, y, z, rm, fl));
@@ -1401,7 +1407,7 @@ template <class MEM, bool DRY = false> struct Lane {
       case OP_FCVT_I2F: {
         if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }
         bool sg = !(rs2 & 1), w = (rs2 & 2) != 0;
-        if (dbl) wf(rd, int_to_f<F64>(a, sg, w, rm, fl)); else wf_s(rd, (u32)int_to_f<F32>(a, sg, w, rm, fl));
+        if (dbl) wf(rd, rm == RM_RNE ? hw_int_to_f64(a, sg, w, fl) : int_to_f<F64>(a, sg, w, rm, fl)); else wf_s(rd, (u32)int_to_f<F32>(a, sg, w, rm, fl));
         or_fflags(fl); mark_fs_dirty(); return; }
       case OP_FCVT_FF: {
         if (!fp_rm((u32)r.imm & 7, rm)) { illegal(r, cur_pc); return; }

@@ -1240,6 +1240,20 @@ __global__ void wsp_sf_eval_kernel(u32 op, int rm, const u64* a, const u64* b, c
   const bool dbl = (op & 0x100) != 0; const u32 k = op & 0xff;
   const u64 x = a[i], y = b[i], z = c[i];
   unsigned fl = 0; u64 r = 0;
+  if ((op & 0x200) && dbl && rm == RM_RNE) {
+    // the FP unit's paths (hw_* in wsp_softfloat.h) where they apply; flags bit 31 tells the caller that one did
+    bool hw = false;
+    switch (k) {
+      case 0: hw = hw_add64(x, y, r, fl); break;
+      case 1: hw = hw_add64(x, y ^ F64::SIGN, r, fl); break;
+      case 2: hw = hw_mul64(x, y, r, fl); break;
+      case 3: hw = hw_div64(x, y, r, fl); break;
+      case 5: hw = hw_fma64(x, y, z, r, fl); break;
+      case 10: case 11: case 12: case 13: r = hw_int_to_f64(z, (k - 10) & 1, ((k - 10) & 2) != 0, fl); hw = true; break;
+      default: break;
+    }
+    if (hw) { out[i] = r; flags[i] = fl | 0x80000000u; return; }
+  }
   switch (k) {
     case 0: r = dbl ? f_add<F64>(x, y, rm, fl) : f_add<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
     case 1: r = dbl ? f_sub<F64>(x, y, rm, fl) : f_sub<F32>(x & 0xffffffffULL, y & 0xffffffffULL, rm, fl); break;
@@ -1463,7 +1477,7 @@ extern "C" int wsp_batch_create(const wsp_batch_desc* desc, wsp_batch** out)
     // still give every SIMD one - 1024 - is the fastest layout measured (profiles/r02/: 4096 harts lpw 1/2/4/8 -> 9.5 / 11.9 /
     // 13.5 / 13.7 GIPS, 16384 harts lpw 4/16/64 -> 36 / 55 / 57, 65536 harts lpw 16/64 -> 140 / 207).
     lpw = 1;
-    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 1024) lpw <<= 1;
+    while (lpw < 64 && (desc->n_harts + lpw - 1) / lpw > 1024u * WSP_WAVES_PER_EU) lpw <<= 1;
     // V batches keep lanes free for the vector unit's element loops (the hart's sub-group, wsp_vwarm): at least 8 lanes per hart at
     // VLEN 512 and above, 4 below (measured at 16384 harts, one wave per SIMD: vector kernels at VLEN 512 0.42 / 0.63 / 0.43 GIPS
     // with 4 / 8 / 16 harts per wave, at VLEN 256 0.69 / 1.07 / 1.46 / 0.91 with 4 / 8 / 16 / 32)
@@ -2472,7 +2486,7 @@ extern "C" int wsp_decode_words(const char* isa, const uint32_t* words, size_t n
 extern "C" int wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t n, uint64_t* out, uint32_t* flags)
 {
   if (!a || !b || !c || !out || !flags) return fail(WSP_EINVAL, "null argument");
-  if (rm > 4 || (op & 0xff) > 14 || (op & ~0x1ffu)) return fail(WSP_EINVAL, "wsp_sf_eval: bad op or rounding mode");
+  if (rm > 4 || (op & 0xff) > 14 || (op & ~0x3ffu)) return fail(WSP_EINVAL, "wsp_sf_eval: bad op or rounding mode");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WSP_ENODEV, "no HIP device");
   if (n == 0) return WSP_OK;

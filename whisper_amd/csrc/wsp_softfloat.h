@@ -414,4 +414,96 @@ template <class F> WSP_HD unsigned fclass(u64 a)
   return s ? 2u : 0x40u;
 }
 
+// ---- binary64 on the machine's own FP unit, with the exact flags ----------------------------------------------------------
+// add / sub / mul / fma / div / int -> double for round-to-nearest-even when every operand is zero or a normal number and the
+// exact result stays well inside the normal range: there the machine's correctly rounded IEEE result IS the SoftFloat result,
+// the only flag that can be raised is inexact, and inexact is decided by an error-free transformation (2Sum for sums, the fma
+// residual for products and quotients, Boldo & Muller's ErrFma for fused multiply-add: each yields the exact rounding error as
+// floating-point numbers, which is non-zero exactly when the operation was inexact).  Every function returns false without
+// touching its outputs when the operands are outside that domain (NaN, infinity, subnormal, results near overflow or
+// underflow, a zero divisor): the caller then runs the integer routine above, which handles everything.  Contraction of a
+// product into a following sum must stay off in here (the device compiler's default fuses u1 + a1 below into an fma and the
+// transformation is no longer error-free: measured, spurious inexact flags): WSP_FP_STRICT at the top of each body.
+// Checked against the integer routines on directed and random operands: oracle/sf_check.cpp (host), tests/test_gpu_softfloat.py
+// (gfx950, through wsp_sf_eval).
+#if defined(__clang__)
+#  define WSP_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#  define WSP_FP_STRICT
+#  if defined(__FMA__)
+#    pragma GCC optimize("fp-contract=off")
+#  endif
+#endif
+WSP_HD double hw_f64(u64 v) { double d; __builtin_memcpy(&d, &v, 8); return d; }
+WSP_HD u64 hw_bits(double d) { u64 v; __builtin_memcpy(&v, &d, 8); return v; }
+WSP_HD bool hw_zero(u64 a) { return !(a << 1); }
+WSP_HD int hw_exp(u64 a) { return (int)((a >> 52) & 0x7ff); }
+WSP_HD bool hw_normal(u64 a) { const int e = hw_exp(a); return e >= 1 && e <= 0x7fe; }
+enum { HW_ELO = 0x080, HW_EHI = 0x77e };                 // biased exponents of the "well inside" range: 2^-895 .. 2^+895
+
+WSP_HD bool hw_add64(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!((hw_zero(a) || hw_normal(a)) && (hw_zero(b) || hw_normal(b)))) return false;
+  const double x = hw_f64(a), y = hw_f64(b), s = x + y;
+  const u64 r = hw_bits(s);
+  if (hw_exp(r) == 0x7ff) return false;                  // overflow
+  const double bv = s - x, av = s - bv, e = (x - av) + (y - bv);      // 2Sum: x + y = s + e exactly
+  z = r; if (e != 0.0) fl |= FL_NX;
+  return true;
+}
+
+// the product a * b has its exponent well inside the range (or is an exact zero)
+WSP_HD bool hw_prod_ok(u64 a, u64 b)
+{
+  const bool za = hw_zero(a), zb = hw_zero(b);
+  if (!((za || hw_normal(a)) && (zb || hw_normal(b)))) return false;
+  const int e = hw_exp(a) + hw_exp(b) - 1023;
+  return za || zb || (e >= HW_ELO && e <= HW_EHI);
+}
+
+WSP_HD bool hw_mul64(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!hw_prod_ok(a, b)) return false;
+  const double x = hw_f64(a), y = hw_f64(b), p = x * y;
+  z = hw_bits(p); if (__builtin_fma(x, y, -p) != 0.0) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD bool hw_fma64(u64 a, u64 b, u64 c, u64& z, unsigned& fl)      // a * b + c
+{
+  WSP_FP_STRICT
+  if (!hw_prod_ok(a, b) || !(hw_zero(c) || (hw_exp(c) >= HW_ELO && hw_exp(c) <= HW_EHI))) return false;
+  const double x = hw_f64(a), y = hw_f64(b), w = hw_f64(c);
+  const double r1 = __builtin_fma(x, y, w);
+  const double u1 = x * y, u2 = __builtin_fma(x, y, -u1);             // x * y = u1 + u2
+  const double a1 = w + u2, t1 = a1 - w, a2 = (w - (a1 - t1)) + (u2 - t1);      // w + u2 = a1 + a2
+  const double b1 = u1 + a1, t2 = b1 - u1, b2 = (u1 - (b1 - t2)) + (a1 - t2);   // u1 + a1 = b1 + b2
+  const double g = (b1 - r1) + b2;                                    // x * y + w = r1 + g + a2, both terms exact
+  z = hw_bits(r1); if (g + a2 != 0.0) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD bool hw_div64(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!hw_normal(b) || !(hw_zero(a) || hw_normal(a))) return false;
+  if (!hw_zero(a)) {
+    const int e = hw_exp(a) - hw_exp(b) + 1023;
+    if (e < HW_ELO || e > HW_EHI || hw_exp(a) < HW_ELO) return false; // the residual a - q * b must be a normal number or zero
+  }
+  const double x = hw_f64(a), y = hw_f64(b), q = x / y;
+  z = hw_bits(q); if (__builtin_fma(-q, y, x) != 0.0) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD u64 hw_int_to_f64(u64 v, bool is_signed, bool is64, unsigned& fl)         // always in the domain
+{
+  if (!is64) return hw_bits(is_signed ? (double)(i32)v : (double)(u32)v);       // 32 bits fit the significand
+  const u64 mag = (is_signed && (i64)v < 0) ? (u64)0 - v : v;
+  if (mag && ((mag << clz64(mag)) << 53)) fl |= FL_NX;                          // more than 53 significant bits
+  return hw_bits(is_signed ? (double)(i64)v : (double)v);
+}
+
 }  // namespace wsf
