@@ -5,7 +5,7 @@
 # (FETCH_SIZE and WRITE_SIZE need separate runs: 3 + 2 TCC counters), 5. SQ instruction mix.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=${1:-r03_a}; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03_b}; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-traced-leg"
 timeout -k 10 300 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/kt.json 2> $O/kt.err
