@@ -144,7 +144,7 @@ def test_hostsim_readme_program():
 
 
 def test_hostsim_archtest_suite_signatures():
-    for p in WL.archtest_suite():
+    for p in WL.archtest_suite(4):
         r = _same(p)
         assert r["status"] == rvoracle.STOP_TOHOST, p.name
 
@@ -208,6 +208,8 @@ def test_hostsim_sv39_programs():
                     ok_su += 1
         else:
             _same(p)
+        if s < 48:
+            _same(WL.sv39_program(s, high=True, exec_body=bool(s & 1)))      # the upper half of the address space, non-canonical addresses
     assert pf > 1500 and ok_su > 10000
 
 

@@ -60,7 +60,10 @@ def test_readme_single_and_replicated():
 
 
 def test_archtest_suite_signatures():
-    progs = WL.archtest_suite()
+    """BASELINE configs[1]'s shape: the whole suite (364 programs: every RV64 I / M / C mnemonic x 4 operand / register parts) as ONE
+    batch, one hart per test; state, memory and commit digests and the signature region of every hart against the oracle."""
+    progs = WL.archtest_suite(4)
+    assert len(progs) >= 300
     b, left, res = _run_batch(progs)
     try:
         assert left == 0
@@ -160,6 +163,23 @@ def test_sv39_programs():
         assert left == 0
         _check(progs, res)
     assert sum(r["status"] == W.ST_STOP_TOHOST for r in res) > 90
+
+
+def test_sv39_upper_half_addresses():
+    """Sv39's upper half (bits 63:39 all ones, root entry 511): loads, stores, AMOs, FP accesses, jumps and MPRV service calls
+    through the high aliases of the code and data pages, and non-canonical addresses on both sides of the hole; bodies as data
+    (general path) and pre-decoded (translated warm path), traced and untraced."""
+    progs = [WL.sv39_program(s, high=True, exec_body=bool(s & 1)) for s in range(96)]
+    high_pcs = 0
+    for p in progs[:16]:
+        _, _, log = S.run_oracle(p, log_cap=p.max_inst)
+        high_pcs += sum(1 for c in log if c.pc >> 63)
+    assert high_pcs > 50                                      # instructions were executed AT upper-half pcs
+    for lanes, trace in ((0, True), (16, True), (8, False)):
+        b, left, res = _run_batch(progs, lanes=lanes, trace=trace)
+        b.close()
+        assert left == 0
+        _check(progs, res, trace=trace)
 
 
 @pytest.mark.parametrize("kind,lanes", [("sv39", 64), ("sv39", 2), ("pmp", 16), ("fuzz", 64)])

@@ -10,8 +10,8 @@ wl, n, lanes = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 if wl == "rvvk":
     k = 1; reps = n; progs = [WL.rvv_kernel(1024, 2)]
 else:
-    gen = {"sv39": WL.sv39_program, "rvv": WL.rvv_program, "fuzz": lambda s: WL.fuzz_program(s, 400)}[wl]
-    k = min(n, 256); reps = n // k; n = k * reps
+    gen = {"sv39": WL.sv39_program, "sv39v": lambda s: WL.variant(WL.sv39_program(s // 50), s % 50), "rvv": WL.rvv_program, "fuzz": lambda s: WL.fuzz_program(s, 400)}[wl]
+    k = min(n, 256 if wl != 'sv39v' else n); reps = n // k; n = k * reps
     progs = [gen(s) for s in range(k)]
 p0 = progs[0]
 b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0), vlen_bytes=p0.meta.get("vlenb", 0))
@@ -25,7 +25,7 @@ b.run()
 ks, _ = b.run_stats()
 W.lib().wsp_debug_prof(out, 1)
 insts = sum(r.exec_count for r in b.results())
-names = ["kernel_wave_cycles", "cold_calls", "cold_cycles", "cold_loop_cycles", "vec_calls", "vec_cycles", "cold_steps", "vls_calls", "vls_cycles", "vwarm_calls", "vwarm_cycles", "vwarm_handled"]
+names = ["kernel_wave_cycles", "cold_calls", "cold_cycles", "cold_loop_cycles", "vec_calls", "vec_cycles", "cold_steps", "vls_calls", "vls_cycles", "vwarm_calls", "vwarm_cycles", "vwarm_handled", "swarm_cycles", "x13", "warm_cycles", "hot_cycles"]
 d = {nm: out[i] for i, nm in enumerate(names)}
 d.update(workload=wl, harts=n, lanes=lanes, instructions=insts, kernel_ms=ks * 1e3, gips=insts / ks / 1e9)
 print(json.dumps(d))

@@ -630,6 +630,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     const bool can = run && (L.h.flags & HF_HOT) && off64 < (u64)text_len;
     bool need_cold = run && !can;
 
+    const unsigned long long ph0 = WSP_PROF_T();
     if (!__any(need_cold)) {
       const u64 left = stop_at - L.h.exec;
       const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu));
@@ -989,6 +990,8 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         wtake = take;
       }
     }
+    WSP_PROF_ADD(15, WSP_PROF_T() - ph0);     // hot loops + warm-path candidate scan
+    const unsigned long long pw0 = WSP_PROF_T();
     // one call per distinct instruction among the lanes that take the warm path (a converged wave: one call for all of them)
     if (__any(wtake)) {
       unsigned long long pend = __ballot(wtake);
@@ -1009,6 +1012,8 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         pend &= ~__ballot(mine);
       }
     }
+    WSP_PROF_ADD(14, WSP_PROF_T() - pw0);     // warm path
+    const unsigned long long ps0 = WSP_PROF_T();
     const bool swarm_can = WSP_SWARM && need_cold && active && d.tlb_n && recs &&
                            !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc;
     if (swarm_can && swarm_skip) --swarm_skip;
@@ -1028,6 +1033,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
       } else if (swarm_credit) --swarm_credit;
       else { swarm_backoff = swarm_backoff < 15 ? 2 * swarm_backoff + 1 : 15u; swarm_skip = swarm_backoff; }   // not its kind of code: try again later
     } else if (need_cold) swarm_credit = 0;
+    WSP_PROF_ADD(12, WSP_PROF_T() - ps0);     // translated warm path
     if (d.vreg) {
       // Vector warm path (wsp_vwarm): hot harts with VS Dirty at a vector instruction; the idle lanes l + lpw, l + 2 lpw, ... join
       // hart l as its sub-group and get the instruction and the hart's live registers from its lane.

@@ -92,9 +92,10 @@ def _fnv(s: str) -> int:
     return h
 
 
-def _archtest_operands(mn: str, n_rand=6):
-    rng = random.Random(_fnv(mn))
-    ops = [(x, y) for x in _CORNERS[:10] for y in _CORNERS[:10]]
+def _archtest_operands(mn: str, n_rand=6, part=0):
+    rng = random.Random(_fnv(mn) ^ (part * 0x9E3779B97F4A7C15 & MASK64))
+    cs = _CORNERS[5 * part % len(_CORNERS):] + _CORNERS[:5 * part % len(_CORNERS)]      # later parts: the other corner values first
+    ops = [(x, y) for x in cs[:10] for y in cs[:10]]
     for i in range(64):
         ops.append((1 << i, rng.getrandbits(64)))
     for _ in range(n_rand * 8):
@@ -112,10 +113,11 @@ _ST = [("sb", 1), ("sh", 2), ("sw", 4), ("sd", 8)]
 _CRR = ["c_sub", "c_xor", "c_or", "c_and", "c_subw", "c_addw", "c_mv", "c_add"]
 
 
-def archtest_program(mn: str) -> Program:
+def archtest_program(mn: str, part: int = 0) -> Program:
     """One arch-test style program: exercise `mn` over corner + seeded random operands, store every
     result into begin_signature..end_signature (model_test.h:33-41 conventions), then halt through
-    tohost (RVMODEL_HALT, model_test.h:23-27)."""
+    tohost (RVMODEL_HALT, model_test.h:23-27).  `part` (the suite's <mnemonic>-01, -02, ... files): other operand values,
+    immediates and offsets, and other registers."""
     data_base = BASE + 0x4000
     a = Asm(BASE)
     d = Asm(data_base)
@@ -128,10 +130,13 @@ def archtest_program(mn: str) -> Program:
     d.label("begin_signature")
     sig_words = 0
     a.label("_start")
-    SIG, T0, T1, T2 = 31, 5, 6, 7
+    SIG = 31
+    T0, T1, T2 = [(5, 6, 7), (28, 29, 30), (10, 11, 12), (18, 19, 20)][part % 4]
+    CA, CB = [(8, 9), (10, 11), (12, 13), (14, 15)][part % 4]                  # the compressed forms' register window
     sig_cap = 0x2000
     a.li(SIG, data_base + 0x200)      # patched below once begin_signature is known: same address by construction
-    rng = random.Random(_fnv(mn) ^ 0x5EED)
+    rng = random.Random(_fnv(mn) ^ 0x5EED ^ (part * 0x2545F4914F6CDD1D & MASK64))
+    _ops = lambda m: _archtest_operands(m, part=part)
 
     def emit_store(reg):
         nonlocal sig_words
@@ -140,23 +145,23 @@ def archtest_program(mn: str) -> Program:
         sig_words += 2
 
     if mn in _RR:
-        for x, y in _archtest_operands(mn):
+        for x, y in _ops(mn):
             a.li(T0, x); a.li(T1, y)
             getattr(a, mn)(T2, T0, T1)
             emit_store(T2)
     elif mn in _RI:
-        for x, _ in _archtest_operands(mn)[:120]:
+        for x, _ in _ops(mn)[:120]:
             a.li(T0, x)
             getattr(a, mn)(T2, T0, rng.randint(-2048, 2047))
             emit_store(T2)
     elif mn in dict(_SH):
         lim = dict(_SH)[mn]
-        for x, _ in _archtest_operands(mn)[:120]:
+        for x, _ in _ops(mn)[:120]:
             a.li(T0, x)
             getattr(a, mn)(T2, T0, rng.randrange(lim))
             emit_store(T2)
     elif mn in _BR:
-        for i, (x, y) in enumerate(_archtest_operands(mn)[:120]):
+        for i, (x, y) in enumerate(_ops(mn)[:120]):
             a.li(T0, x); a.li(T1, y); a.li(T2, 0)
             lbl = f"bt{i}"
             getattr(a, mn)(T0, T1, lbl)
@@ -203,42 +208,42 @@ def archtest_program(mn: str) -> Program:
             a.auipc(T1, 0); a.sub(T2, T2, T1)
             emit_store(T2)
     elif mn in _CRR:
-        for x, y in _archtest_operands(mn)[:100]:
-            a.li(8, x); a.li(9, y)
-            getattr(a, mn)(8, 9)
-            emit_store(8)
+        for x, y in _ops(mn)[:100]:
+            a.li(CA, x); a.li(CB, y)
+            getattr(a, mn)(CA, CB)
+            emit_store(CA)
     elif mn in ("c_addi", "c_addiw", "c_li", "c_andi", "c_slli", "c_srli", "c_srai", "c_lui"):
-        for x, _ in _archtest_operands(mn)[:100]:
-            a.li(8, x)
+        for x, _ in _ops(mn)[:100]:
+            a.li(CA, x)
             if mn in ("c_slli", "c_srli", "c_srai"):
-                getattr(a, mn)(8, rng.randrange(1, 64))
+                getattr(a, mn)(CA, rng.randrange(1, 64))
             elif mn == "c_lui":
-                v = rng.choice([i for i in range(-32, 32) if i != 0]); a.c_lui(8, v)
+                v = rng.choice([i for i in range(-32, 32) if i != 0]); a.c_lui(CA, v)
             else:
-                getattr(a, mn)(8, rng.randrange(-32, 32))
-            emit_store(8)
+                getattr(a, mn)(CA, rng.randrange(-32, 32))
+            emit_store(CA)
     elif mn in ("c_lw", "c_ld", "c_sw", "c_sd", "c_lwsp", "c_ldsp", "c_swsp", "c_sdsp"):
-        a.li(9, data_base + 0x10); a.li(2, data_base + 0x10)
+        a.li(CB, data_base + 0x10); a.li(2, data_base + 0x10)
         for i in range(32):
-            a.li(8, rng.getrandbits(64))
-            if mn == "c_lw": a.c_lw(8, 9, 4 * rng.randrange(32))
-            elif mn == "c_ld": a.c_ld(8, 9, 8 * rng.randrange(30))
-            elif mn == "c_sw": o = 4 * rng.randrange(32); a.c_sw(8, 9, o); a.ld(8, (o // 8) * 8, 9)
-            elif mn == "c_sd": o = 8 * rng.randrange(30); a.c_sd(8, 9, o); a.ld(8, o, 9)
-            elif mn == "c_lwsp": a.c_lwsp(8, 4 * rng.randrange(60))
-            elif mn == "c_ldsp": a.c_ldsp(8, 8 * rng.randrange(30))
-            elif mn == "c_swsp": o = 4 * rng.randrange(60); a.c_swsp(8, o); a.ld(8, (o // 8) * 8, 2)
-            else: o = 8 * rng.randrange(30); a.c_sdsp(8, o); a.ld(8, o, 2)
-            emit_store(8)
+            a.li(CA, rng.getrandbits(64))
+            if mn == "c_lw": a.c_lw(CA, CB, 4 * rng.randrange(32))
+            elif mn == "c_ld": a.c_ld(CA, CB, 8 * rng.randrange(30))
+            elif mn == "c_sw": o = 4 * rng.randrange(32); a.c_sw(CA, CB, o); a.ld(CA, (o // 8) * 8, CB)
+            elif mn == "c_sd": o = 8 * rng.randrange(30); a.c_sd(CA, CB, o); a.ld(CA, o, CB)
+            elif mn == "c_lwsp": a.c_lwsp(CA, 4 * rng.randrange(60))
+            elif mn == "c_ldsp": a.c_ldsp(CA, 8 * rng.randrange(30))
+            elif mn == "c_swsp": o = 4 * rng.randrange(60); a.c_swsp(CA, o); a.ld(CA, (o // 8) * 8, 2)
+            else: o = 8 * rng.randrange(30); a.c_sdsp(CA, o); a.ld(CA, o, 2)
+            emit_store(CA)
     elif mn in ("c_j", "c_beqz", "c_bnez", "c_jr", "c_jalr"):
         for i in range(32):
             lbl = f"ct{i}"
-            a.li(8, rng.choice([0, 1, rng.getrandbits(64)])); a.li(T2, 0)
+            a.li(CA, rng.choice([0, 1, rng.getrandbits(64)])); a.li(T2, 0)
             if mn == "c_j": a.c_j(lbl)
-            elif mn == "c_beqz": a.c_beqz(8, lbl)
-            elif mn == "c_bnez": a.c_bnez(8, lbl)
-            elif mn == "c_jr": a.la(9, lbl); a.c_jr(9)
-            else: a.la(9, lbl); a.c_jalr(9)
+            elif mn == "c_beqz": a.c_beqz(CA, lbl)
+            elif mn == "c_bnez": a.c_bnez(CA, lbl)
+            elif mn == "c_jr": a.la(CB, lbl); a.c_jr(CB)
+            else: a.la(CB, lbl); a.c_jalr(CB)
             a.li(T2, 1)
             a.label(lbl)
             emit_store(T2)
@@ -253,7 +258,7 @@ def archtest_program(mn: str) -> Program:
     d.symbols["begin_signature"] = data_base + 0x200
     d.zeros(sig_words * 4)
     d.label("end_signature")
-    return _finish(a, f"arch-{mn}", "rv64imc_zicsr", d, mem_size=1 << 16, max_inst=200000, meta=dict(mnemonic=mn))
+    return _finish(a, f"arch-{mn}" + (f"-{part + 1:02d}" if part else ""), "rv64imc_zicsr", d, mem_size=1 << 16, max_inst=200000, meta=dict(mnemonic=mn, part=part))
 
 
 def archtest_mnemonics():
@@ -262,8 +267,9 @@ def archtest_mnemonics():
                     "c_sd", "c_lwsp", "c_ldsp", "c_swsp", "c_sdsp", "c_j", "c_beqz", "c_bnez", "c_jr", "c_jalr"])
 
 
-def archtest_suite():
-    return [archtest_program(m) for m in archtest_mnemonics()]
+def archtest_suite(parts: int = 1):
+    """parts = 1: one program per mnemonic (91); parts = 4: 364 programs, the size of the RV64 I / M / C arch-test suite."""
+    return [archtest_program(m, k) for k in range(parts) for m in archtest_mnemonics()]
 
 
 # ------------------------------------------------------------------------------------------ config 2
@@ -833,7 +839,7 @@ def pmp_program(seed: int, n: int = 300) -> Program:
 _PTE_V, _PTE_R, _PTE_W, _PTE_X, _PTE_U, _PTE_G, _PTE_A, _PTE_D = 1, 2, 4, 8, 16, 32, 64, 128
 
 
-def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
+def sv39_program(seed: int, n: int = 300, exec_body: bool = False, high: bool = False) -> Program:
     """Sv39 paging: M mode opens PMP, builds a three-level page table (4 KiB pages with mixed
     R/W/X/U/A/D bits, a 2 MiB window over the whole arena, a misaligned superpage, malformed PTEs), and drops to S (odd
     seeds) or U (even seeds) at a virtual address that is not the physical one.  The body mixes loads, stores, AMOs, LR/SC
@@ -843,6 +849,9 @@ def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
     sstatus.SUM / MXR toggles and satp rewrites (new ASID).  `ecall` services run in M mode: MPRV loads and stores (translated
     with the caller's privilege) and satp switches.  Every trap goes to one M handler that steps over the faulting
     instruction (fetch faults resume at ra).  Run with a small `tlb_entries` so the replacement policy matters.
+    high: root entry 511 maps the code and data pages a second time in the UPPER half of the Sv39 address space
+    (0xFFFFFFFFC0000000 + ...: bits 63:39 all ones), and accesses, jumps and service calls go there as well as to non-canonical
+    addresses on either side of the hole (VirtMem.cpp: bits 63:39 must equal bit 38).
     exec_body: mark the body's segment executable in the ELF, so that the loader pre-decodes it too (the image then spans
     boot code .. body, about 80 KiB) and S / U-mode steps can take the TLB-hit fast path."""
     rng = random.Random(0x5339 ^ seed)
@@ -864,6 +873,9 @@ def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
     pt[PT_ROOT + 8 * 1] = pte(PT_L1 + 0x800, _PTE_V)      # second half of the L1 page serves root[1]
     pt[PT_ROOT + 8 * 2] = pte(BASE + 0x1000, FULL | U)    # misaligned 1 GiB leaf
     pt[PT_ROOT + 8 * 3] = pte(PT_L1, _PTE_V | _PTE_A)     # non-leaf with A set
+    HI = 0xFFFFFFFFC0000000
+    if high:
+        pt[PT_ROOT + 8 * 511] = pte(PT_L1, _PTE_V)        # the lower GiB's tables again, for VA 0xFFFF_FFFF_C000_0000 ..
     pt[PT_L1 + 8 * 0] = pte(PT_L0A, _PTE_V)               # VA 0x0000_0000 .. : code pages
     pt[PT_L1 + 8 * 2] = pte(PT_L0B, _PTE_V)               # VA 0x0040_0000 .. : data pages
     pt[PT_L1 + 8 * 3] = pte(BASE + 0x1000, FULL | U)      # misaligned 2 MiB leaf
@@ -961,6 +973,11 @@ def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
     regs = [r for r in range(2, 27) if r not in (P, 10, 11, 17)]
 
     def pick_va():
+        if high and rng.random() < 0.35:
+            return rng.choice([HI + VA_DATA + rng.randrange(16) * 0x1000 + rng.choice([rng.randrange(0x1000), 0xFF8 + rng.randrange(12)]),
+                               HI + VA_DATA + rng.randrange(16) * 0x1000 + 8 * rng.randrange(512), HI + VA_CODE + rng.randrange(0x4000),
+                               (HI + VA_DATA + rng.randrange(0x10000)) ^ (1 << (39 + rng.randrange(25))),      # one upper bit wrong: not canonical
+                               (1 << 38) + VA_DATA + rng.randrange(0x1000), 0xFFFFFFBFFFFFF000 + rng.randrange(0x1000)])
         r = rng.random()
         if r < 0.6:
             return VA_DATA + rng.randrange(16) * 0x1000 + rng.choice([rng.randrange(0x1000), 0xFF8 + rng.randrange(12), rng.randrange(16)])
@@ -1003,7 +1020,9 @@ def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
             rng.choice([b.flw, b.fld, b.fsw, b.fsd])(rng.randrange(32), 0, P)
         elif k < 0.64:                                                   # jumps: islands at the end of code page 2 / in page 3, data pages, unmapped
             t = rng.choice([VA_CODE + 0x2FF0, VA_CODE + 0x2FFA, VA_CODE + 0x3000, VA_CODE + 0x3010, VA_DATA + 0x1000 * rng.randrange(16), 0x800000, 0xC0000000])
-            b.li(P, t); b.jalr(1, P, 0)
+            if high and rng.random() < 0.5:                              # the islands through their upper-half addresses (the pc itself is up there)
+                t = rng.choice([HI + VA_CODE + 0x2FF0, HI + VA_CODE + 0x3010, HI + VA_CODE + 0x2FFA, (HI + VA_CODE + 0x3010) ^ (1 << 45)])
+            b.li(P, t & MASK64); b.jalr(1, P, 0)
         elif k < 0.74:                                                   # page-table edit through the window, no sfence
             ix = rng.randrange(16)
             f = rng.choice([data_flags[ix], FULL | U, _PTE_V | _PTE_R | _PTE_A | U, _PTE_V | _PTE_R | _PTE_W | _PTE_A | U, 0, rng.randrange(256)])
@@ -1044,7 +1063,7 @@ def sv39_program(seed: int, n: int = 300, exec_body: bool = False) -> Program:
     segs = [(a.base, text, PF_R | PF_X), (d.base, d.assemble(), PF_R | PF_W), (PA_CODE, code, PF_R | (PF_X if exec_body else 0))]   # code lands inside the data image's span: last
     syms = dict(a.symbols); syms.update(d.symbols)
     elf = write_elf(segs, syms["_start"], syms)
-    return Program(f"sv39-{seed}", "rv64imafdcsu_zicsr", elf, syms["_start"], segs, syms, BASE, MEM, 60000, dict(seed=seed, tlb_entries=8))
+    return Program(f"sv39{'hi' if high else ''}-{seed}", "rv64imafdcsu_zicsr", elf, syms["_start"], segs, syms, BASE, MEM, 60000, dict(seed=seed, tlb_entries=8))
 
 
 # ------------------------------------------------------------------------------------------ RVV (config 3)
