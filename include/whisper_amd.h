@@ -143,8 +143,9 @@ int  wsp_batch_last_run_stats(wsp_batch* b, double* kernel_seconds, uint32_t* la
 
 /* Fill out[0 .. n_harts) (computes the state and memory digests on the device). */
 int  wsp_batch_results(wsp_batch* b, wsp_result* out);
-/* wsp_batch_results for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  No counterpart in the reference.  Calls no hipMalloc / hipFree or allocating library routine: the
+/* wsp_batch_results for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that runs
+ * while another stream is being captured into a HIP graph).  It waits for the batch's stream before it returns, so the call
+ * itself cannot be part of a capture.  No counterpart in the reference.  Calls no hipMalloc / hipFree or allocating library routine: the
  * digest's partial sums live in a static device array of the library (8 MiB per GPU, held until the process ends) and the
  * n_harts records are written into d_out, which is DEVICE memory supplied by the caller.  Limit: n_waves * 64 <= 1048576
  * hart slots, else WSP_ERANGE.  All calls on one GPU share that array: calls that overlap on one GPU race. */

@@ -504,4 +504,14 @@ def test_cli_and_riscof_batch(tmp_path):
     ro32, _, olog32 = S.run_oracle(r32, log_cap=1000)
     lines32 = log32.read_text().splitlines()
     assert len([ln for ln in lines32 if not ln.endswith("+")]) == len(olog32) == ro32["exec"]
+    # --harts N: one log, the second column numbers the harts; a ring too small for the run is reported, not silently cut
+    logn = tmp_path / "rn.log"
+    assert cli.main(["--isa", rp.isa, "--target", str(e), "--harts", "3", "--logfile", str(logn), "--quiet"]) == 0
+    cols = [ln.split()[1] for ln in logn.read_text().splitlines() if ln.startswith("#")]
+    assert sorted(set(cols)) == ["0", "1", "2"] and cols == sorted(cols)
+    import contextlib, io
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        assert cli.main(["--isa", progs[3].isa, "--target", tests[3][0], "--logfile", str(log), "--logsize", "64", "--quiet"]) == 0
+    assert "the log ends early" in err.getvalue()
     assert all(re.match(r"#\d+ 0  M [0-9a-f]{8} ", ln) for ln in lines32)                     # RV32 layout: 8-digit pc column

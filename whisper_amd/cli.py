@@ -38,6 +38,7 @@ def build_parser():
     ap.add_argument("--setreg", action="append", default=[], help="x<n>=<value>, repeatable")
     ap.add_argument("--memorysize", type=_num, default=0)
     ap.add_argument("--logfile", "-f", default=None)
+    ap.add_argument("--logsize", type=_num, default=1 << 20, help="commit-ring words per hart behind --logfile (a record takes 5 .. 40)")
     ap.add_argument("--testsignature", default=None)
     ap.add_argument("--harts", type=int, default=1)
     ap.add_argument("--failoninstlimit", action="store_true")
@@ -72,8 +73,23 @@ def write_signature(path, words):
             f.write(f"{w:08x}\n")
 
 
+def _with_hart_column(text, hart):
+    """The log's second column is the hart's index in its system (printTrace.cpp:71: `#tag hart`); the library formats every hart
+    as hart 0 of a system of its own, --harts N makes them hart 0 .. N-1 of one target."""
+    if hart == 0:
+        return text
+    out = []
+    for line in text.splitlines(True):
+        if line.startswith("#"):
+            tag, _, rest = line.partition(" ")
+            rest = rest.partition(" ")[2]
+            line = f"{tag} {hart} {rest}"
+        out.append(line)
+    return "".join(out)
+
+
 def run_entries(entries, isa=None, config=None, xlen=0, tohost=None, maxinst=None, maxret=None, startpc=None, endpc=None, setreg=(),
-                memorysize=0, harts_per_entry=1, tlbsize=0, device=-1, fail_on_limit=False, quiet=False, disasm=None):
+                memorysize=0, harts_per_entry=1, tlbsize=0, device=-1, fail_on_limit=False, quiet=False, disasm=None, logsize=1 << 20):
     """entries: [(elf_path, signature_path | None, log_path | None)].  Runs them all in one batch; returns [ok per entry]."""
     elfs = [open(e[0], "rb").read() for e in entries]
     base, size = arena_for(elfs, memorysize)
@@ -94,7 +110,7 @@ def run_entries(entries, isa=None, config=None, xlen=0, tohost=None, maxinst=Non
         b.set_stop(tohost=tohost, max_inst=W.NO_LIMIT if maxinst is None else maxinst, max_ret=W.NO_LIMIT if maxret is None else maxret,
                    stop_pc=endpc)
         if want_log:
-            b.trace_ring(1 << 20)
+            b.trace_ring(logsize)
         left = b.run(trace_hash=want_log)
         res = b.results()
         oks = []
@@ -116,7 +132,13 @@ def run_entries(entries, isa=None, config=None, xlen=0, tohost=None, maxinst=Non
             if log:
                 with open(log, "w") as f:
                     for k in range(harts_per_entry):           # the reference's --logfile text (wsp_batch_trace_text)
-                        f.write(b.trace_text(i * harts_per_entry + k))
+                        h = i * harts_per_entry + k
+                        text = b.trace_text(h)
+                        got = sum(1 for ln in text.splitlines() if ln.startswith("#") and not ln.rstrip().endswith("+"))
+                        if got < res[h].exec_count:
+                            print(f"Warning: {log}: hart {h}: the commit ring held {got} of {res[h].exec_count} instructions "
+                                  f"(--logsize {logsize} words per hart): the log ends early", file=sys.stderr)
+                        f.write(_with_hart_column(text, k))
             oks.append(ok)
         return oks
     finally:
@@ -139,7 +161,7 @@ def main(argv=None):
         a.isa = "rv64imafdc_zicsr" if a.xlen != 32 else "rv32imac_zicsr"
     try:
         oks = run_entries(entries, isa=a.isa, config=config, xlen=a.xlen, tohost=a.tohost, maxinst=a.maxinst, maxret=a.maxretinst,
-                          startpc=a.startpc, endpc=a.endpc, setreg=a.setreg, memorysize=a.memorysize, harts_per_entry=a.harts,
+                          startpc=a.startpc, endpc=a.endpc, setreg=a.setreg, memorysize=a.memorysize, harts_per_entry=a.harts, logsize=a.logsize,
                           tlbsize=a.tlbsize, device=a.device, fail_on_limit=a.failoninstlimit, quiet=a.quiet)
     except W.WspError as e:
         print(f"Error: {e}", file=sys.stderr)

@@ -3421,8 +3421,8 @@ template <class MEM, bool DRY = false> struct Lane {
   // VirtMem.cpp:261-310; Tlb::findEntryUpdateTime, Tlb.hpp:91-100; the fetch and load / store glue of Hart.cpp:3052-3206, 1988-2154).
   // One instruction of the inline subset (exec_fast's register / branch / jump forms, aligned loads and stores) whose fetch and
   // data translations both HIT the TLB with permission, whose pages lie whole inside one PMP region that allows the access,
-  // inside the arena, away from tohost and (stores) from the code image, and whose record comes from the pre-decoded image
-  // by PHYSICAL address.  Everything is checked before anything is changed: on `false` nothing has happened and the general
+  // inside the arena, away from tohost and (stores) from the code image; the record comes from the pre-decoded image by PHYSICAL
+  // address, or is decoded from RAM when the code lies outside the image.  Everything is checked before anything is changed: on `false` nothing has happened and the general
   // step executes the instruction (misses and walks, faults, CSRs, traps, misaligned or page-crossing accesses, a straddling
   // fetch ...).  On `true` the side effects are exactly the general path's: the replacement counters of the TLB entries used
   // (fetch first, then data), the register / memory write, the pc.  The caller advances the four counters by one, as for a hot
@@ -3503,12 +3503,26 @@ template <class MEM, bool DRY = false> struct Lane {
       t.fok = 1; t.fvpn = vpn; t.fpa = pap; t.fix = ix; t.fe0 = e0; t.fe1 = e1;
       if (t.dok && t.dix == ix) t.dok = 0;             // (one copy per TLB entry: the fetch side owns this one now)
     }
-    const u64 idx = (t.fpa | (pc & 0xfff)) - text_lo, text_len = text_hi - text_lo;
-    if (idx >= text_len) return false;
-    const Rec rec = (t.nok && t.nidx == idx) ? t.nrec : fast_rec_load(recs, idx);
+    const u64 fpa = t.fpa | (pc & 0xfff), idx = fpa - text_lo, text_len = text_hi - text_lo;
+    Rec rec;
+    if (idx < text_len) {
+      rec = (t.nok && t.nidx == idx) ? t.nrec : fast_rec_load(recs, idx);
+      const u32 sz0 = (rec.w0 & F_SIZE4) ? 4 : 2;
+      // the sequential successor's record, requested now so that it arrives while this instruction's data access is under way
+      if ((pc & 0xfff) + sz0 < 0x1000 && idx + sz0 < text_len) { t.nidx = idx + sz0; t.nrec = fast_rec_load(recs, t.nidx); t.nok = 1; } else t.nok = 0;
+    } else {
+      // code outside the pre-decoded image (a segment the ELF does not mark executable, code the program wrote): fetched from RAM
+      // and decoded at every step, as fetch_slow does (the page lies inside the arena: checked with the TLB entry above)
+      const u64 o = fpa - mem_base;
+      u32 inst = m.ld16(o);
+      if ((inst & 3) == 3) {
+        if ((pc & 0xfff) == 0xffe) return false;
+        inst |= (u32)m.ld16(o + 2) << 16;
+      }
+      rec = decode(inst, isa);
+      t.nok = 0;
+    }
     const u32 op = rec.w0 & 0xff, size = (rec.w0 & F_SIZE4) ? 4 : 2;
-    // the sequential successor's record, requested now so that it arrives while this instruction's data access is under way
-    if ((pc & 0xfff) + size < 0x1000 && idx + size < text_len) { t.nidx = idx + size; t.nrec = fast_rec_load(recs, t.nidx); t.nok = 1; } else t.nok = 0;
     if (size == 4 && (pc & 0xfff) == 0xffe) return false;                              // second half on the next page (Hart.cpp:3144-3156)
     // ... and the reference translates the second half of a 4-byte instruction at a 2-byte-aligned pc AGAIN whenever the page
     // number of the virtual pc + 2 differs from the first half's PHYSICAL page number (i.e. whenever VA != PA): one more hit

@@ -16,6 +16,7 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <mutex>
 // -DWSP_PROF: cycle accounting of the step kernel's paths (tuning builds only; read back with wsp_debug_prof)
 #ifdef WSP_PROF
 __device__ unsigned long long wsp_prof[16];
@@ -125,8 +126,21 @@ struct DevMem {
 #define WSP_CONV_ASM 1                                   // 0: untraced converged waves run the C++ loop too (A/B measurements)
 #endif
 
+// Mirror lanes.  Measured on gfx950 (tools/lab/valu_rate.hip): a wave that has its SIMD to itself issues a vector ALU instruction
+// every ~1.9 ns with 15 or more lanes enabled in exec, but only every ~8.6 ns with 4 or fewer - and small batches put 1 .. 8 harts
+// in a wave.  So in batches without V (whose idle lanes serve as vector sub-groups) with up to 8 harts per wave, lanes lpw .. 15
+// run COPIES of the harts of lanes 0 .. lpw - 1 (lane l copies hart l mod lpw): same state loaded, same instructions executed in
+// lock step, the same values stored to the same addresses at the same time (LDS register files, arena, HBM state rows, TLB, commit
+// ring: every store of a copy is the owner's store again; nothing on these paths is an atomic), results of the copies ignored.
+#define WSP_MIRROR_LANES 16u
+__device__ __forceinline__ bool wsp_mirrors(const DevState& d) { return !d.vreg && d.lpw <= 8; }
 __device__ __forceinline__ u32 ln_of(const DevState& d)
-{ const u32 lane = threadIdx.x; return (lane < d.lpw && blockIdx.x * d.lpw + lane < d.n_harts) ? lane : 0; }
+{
+  const u32 lane = threadIdx.x;
+  if (lane < d.lpw) return blockIdx.x * d.lpw + lane < d.n_harts ? lane : 0;
+  const u32 own = lane & (d.lpw - 1);
+  return (wsp_mirrors(d) && lane < WSP_MIRROR_LANES && blockIdx.x * d.lpw + own < d.n_harts) ? own : 0;
+}
 
 template <class LaneT> __device__ __forceinline__ void wsp_lane_setup(LaneT& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
 {
@@ -267,10 +281,9 @@ template <bool TRACE>
 __device__ __noinline__ WarmRet wsp_warm(const DevState* dp, u32 w0, i32 imm, u32 raw, u64 pc, u64 thash, u32 fcsr, u32 flags)
 {
   const DevState& d = *dp;
-  // Every lane active at the call holds the SAME instruction (the call site groups lanes by instruction): the record goes into
-  // scalar registers, and with it the whole dispatch below - which operation, which format, which rounding mode - runs as scalar
-  // branches instead of exec-masked regions every lane walks through (measured: 3.3 us -> see profiles/r03_ubench_*.jsonl).
-  w0 = wsp_uni32(w0); imm = (i32)wsp_uni32((u32)imm); raw = wsp_uni32(raw);
+  // Every lane brings its own instruction: a wave of 64 different fuzz programs stands at up to 64 different csrr / csrw / mret /
+  // mul words at once, and one call per distinct word (tried in round 3 for the scalar dispatch it allows) made the warm path 26 %
+  // of that workload's wave cycles (-DWSP_PROF); the paths through this function are few, the words many.
   const u32 ln = ln_of(d), slot = blockIdx.x * 64 + ln, isa = wsp_uni32(d.isa);
   const size_t S = wsp_uni32(d.S);
   Lane<DevMem> L;
@@ -448,7 +461,7 @@ __device__ __noinline__ SWarmRet wsp_swarm(const DevState* dp, VWarmArgs va, u64
 {
   const DevState& d = *dp;
   const u32 lpw = wsp_uni32(d.lpw), lpw_shift = wsp_uni32(d.lpw_shift), S = wsp_uni32(d.S), tlb_n = wsp_uni32(d.tlb_n);
-  const u32 wave = blockIdx.x, ln = threadIdx.x, slot = wave * 64 + ln;
+  const u32 wave = blockIdx.x, ln = ln_of(d), slot = wave * 64 + ln;
   Lane<DevMem> L;
   L.m.xs = wsp_lds + ln * WSP_XSLOTS;
   L.m.fs = wsp_lds + (lpw + ln) * WSP_XSLOTS;
@@ -564,14 +577,16 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   const bool active = lane < d.lpw && hart < d.n_harts;
   // a lane without a hart looks at hart 0's slot; in a V batch at the slot of the hart whose sub-group it belongs to (wsp_vwarm)
   const u32 own = lane & (d.lpw - 1);
-  const u32 ln = active ? lane : (d.vreg && wave * d.lpw + own < d.n_harts) ? own : 0;
+  const bool mirror = wsp_mirrors(d) && lane >= d.lpw && lane < WSP_MIRROR_LANES && wave * d.lpw + own < d.n_harts;   // see ln_of
+  const bool live = active || mirror;
+  const u32 ln = live ? own : (d.vreg && wave * d.lpw + own < d.n_harts) ? own : 0;
   const u32 slot = wave * 64 + ln;
   const u32 S = d.S;
 
   Lane<DevMem> L; const Rec* recs;
   wsp_lane_setup(L, d, wave, ln, slot, recs);
   L.h.pc = d.hot64[H64_PC * S + slot]; L.h.exec = d.hot64[H64_EXEC * S + slot]; L.h.thash = d.hot64[H64_THASH * S + slot];
-  L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = active ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
+  L.h.flags = d.hot32[H32_FLAGS * S + slot]; L.h.status = live ? d.hot32[H32_STATUS * S + slot] : (u32)ST_STOP_LIMIT;
   L.h.priv = d.hot32[H32_PRIV * S + slot]; L.h.mstatus = d.hot64[H64_MSTATUS * S + slot]; L.h.fcsr = d.hot32[H32_FCSR * S + slot];
   L.update_pmp_flags();                                  // host pokes may have changed priv / mstatus / mip / mie / pmpcfg / flags
   L.h.flags = d.ring ? (L.h.flags | HF_RING) : (L.h.flags & ~(u32)HF_RING);
@@ -992,29 +1007,17 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     }
     WSP_PROF_ADD(15, WSP_PROF_T() - ph0);     // hot loops + warm-path candidate scan
     const unsigned long long pw0 = WSP_PROF_T();
-    // one call per distinct instruction among the lanes that take the warm path (a converged wave: one call for all of them)
-    if (__any(wtake)) {
-      unsigned long long pend = __ballot(wtake);
-      while (pend) {
-        const int leader = __ffsll((long long)pend) - 1;
-        const u32 uw0 = (u32)__builtin_amdgcn_readlane((int)wrec.w0, leader), uraw = (u32)__builtin_amdgcn_readlane((int)wrec.raw, leader);
-        const u32 uimm = (u32)__builtin_amdgcn_readlane((int)wrec.imm, leader);
-        const bool mine = wtake && wrec.w0 == uw0 && wrec.raw == uraw && (u32)wrec.imm == uimm;
-        if (mine) {
-          const WarmRet w = (TRACE && tr) ? wsp_warm<true>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags)
-                                          : wsp_warm<false>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags);
-          if (w.handled) {
-            L.h.pc = w.pc; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; L.h.flags = w.flags;
-            need_cold = false;
-          }
-          wtake = false;
-        }
-        pend &= ~__ballot(mine);
+    if (wtake) {
+      const WarmRet w = (TRACE && tr) ? wsp_warm<true>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags)
+                                      : wsp_warm<false>(dp, wrec.w0, wrec.imm, wrec.raw, L.h.pc, L.h.thash, L.h.fcsr, L.h.flags);
+      if (w.handled) {
+        L.h.pc = w.pc; L.h.exec++; L.h.thash = w.thash; L.h.fcsr = w.fcsr; L.h.flags = w.flags;
+        need_cold = false;
       }
     }
     WSP_PROF_ADD(14, WSP_PROF_T() - pw0);     // warm path
     const unsigned long long ps0 = WSP_PROF_T();
-    const bool swarm_can = WSP_SWARM && need_cold && active && d.tlb_n && recs &&
+    const bool swarm_can = WSP_SWARM && need_cold && live && d.tlb_n && recs &&
                            !(L.h.flags & (HF_HOT | HF_RING | HF_CODE_DIRTY | HF_INH_CY | HF_INH_IR)) && L.h.pc != L.stop_pc;
     if (swarm_can && swarm_skip) --swarm_skip;
     else if (swarm_can) {
@@ -1332,9 +1335,11 @@ extern "C" uint32_t wsp_isa_flags(const char* isa) { u32 f = 0; std::string w; i
 
 // Device address of wsp_scratch on each GPU, looked up with that GPU current (each GPU holds its own copy at its own address).
 static u64* g_scratch_ptr[64];
+static std::mutex g_scratch_mu;                        // batches may be created from several host threads
 static int scratch_of(int dev, u64** out)
 {
   if (dev < 0 || dev >= 64) return fail(WSP_ENODEV, "device ordinal out of range for the static scratch table");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!g_scratch_ptr[dev]) {
     void* p = nullptr;
     HIPOK(hipSetDevice(dev));
@@ -1361,6 +1366,7 @@ struct wsp_batch {
   std::vector<Program> progs;
   std::vector<u32> hart_prog;          // host copy, index = hart
   std::vector<u64> hart_stop_pc;       // host copy of the stop addresses (~0: none)
+  std::vector<u32> snap_hart_prog; std::vector<u64> snap_hart_stop_pc;   // the two host copies as of wsp_batch_snapshot
   std::vector<Rec*> rec_pools;         // record allocations shared by many programs
   ProgDev* d_progs = nullptr; size_t d_progs_cap = 0;
   DevState* d_state = nullptr;
@@ -2292,7 +2298,8 @@ extern "C" int wsp_batch_results(wsp_batch* b, wsp_result* out)
   return WSP_OK;
 }
 
-// The variant of wsp_batch_results that allocates nothing (for callers that cannot: HIP graph capture, tight serving loops).
+// The variant of wsp_batch_results that allocates nothing (for callers that cannot: tight serving loops, harnesses that forbid
+// hipMalloc, code around a graph capture - the call itself waits for the batch's stream, so it cannot sit INSIDE a capture).
 // Same two kernels; the digest's partial sums live in the static device array wsp_scratch instead of a buffer of the batch,
 // and the records are written straight into the caller's device buffer.  Every call on a GPU shares that GPU's array: the
 // part used is cleared at the start of each call, and calls that overlap on one GPU race.
@@ -2452,6 +2459,7 @@ extern "C" int wsp_batch_snapshot(wsp_batch* b)
     HIPOK(hipMemcpyAsync(b->snap[i], parts[i].live, parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   }
   HIPOK(hipStreamSynchronize(b->stream));
+  b->snap_hart_prog = b->hart_prog; b->snap_hart_stop_pc = b->hart_stop_pc;      // the host's view of prog / stop_pc rows goes with them
   return WSP_OK;
 }
 
@@ -2463,6 +2471,7 @@ extern "C" int wsp_batch_restore(wsp_batch* b)
   SnapPart parts[WSP_SNAP_PARTS]; snap_parts(b, parts);
   for (int i = 0; i < WSP_SNAP_PARTS; ++i) if (parts[i].bytes) HIPOK(hipMemcpyAsync(parts[i].live, b->snap[i], parts[i].bytes, hipMemcpyDeviceToDevice, b->stream));
   HIPOK(hipStreamSynchronize(b->stream));
+  b->hart_prog = b->snap_hart_prog; b->hart_stop_pc = b->snap_hart_stop_pc;
   return WSP_OK;
 }
 
