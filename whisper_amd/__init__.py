@@ -57,7 +57,7 @@ class Decoded(C.Structure):
 
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_conv_core.h"), os.path.join(HERE, "csrc", "wsp_softfloat.h"), os.path.join(HERE, "csrc", "wsp_config.h"),
+    deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_conv_core.h"), os.path.join(HERE, "csrc", "wsp_conv_handlers.inc"), os.path.join(HERE, "csrc", "wsp_softfloat.h"), os.path.join(HERE, "csrc", "wsp_config.h"),
             os.path.join(HERE, "csrc", "wsp_disasm.h"), os.path.join(HERE, "csrc", "wsp_disasm_tables.inc"), os.path.join(ROOT, "include", "whisper_amd.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH

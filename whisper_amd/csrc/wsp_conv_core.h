@@ -48,7 +48,7 @@
 //  callee-saved: s34 upc  s35 spc  s36 steps left - 1  s37 its value when converged mode was entered  s38 record word 6  s39 word 7
 //                s48 mode (0 converged, 1 diverged)  s49 cfg (bit 1 rv32, bit 2 FS dirty, bit 3 D)  s50 lpw shift  s51 f block offset
 //                s52 isa  s53 text length  s[54:55] return address of the step  s[64:65] handler table
-//                s[68:69] exec at entry (= while the loop runs)  s[70:71] eligible lanes
+//                s[66:67] s[86:87] the threaded copies A / B of the handler table  s[68:69] exec at entry (= while the loop runs)  s[70:71] eligible lanes
 //                s[80:81] hot records  s[82:83] text_lo  s[84:85] the lanes that execute the current instruction
 //  clobbered by calls: s[40:47] record buffer A  s[56:63] buffer B  s[72:79] buffer T (branch / jump target)
 //                s88 s89 scratch  s[90:91] dispatch target  s[92:93] s[94:95] scratch pairs
@@ -79,7 +79,8 @@
   "s_add_u32 s35, s34, " Q1 "\n"                                                        \
   "s_lshl_b32 s88, s35, 4\n"                                                            \
   "s_load_dwordx8 " QN ", s[80:81], s88\n"
-#define CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                               \
+#define CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7) CC_ISSUE_B(Q0, Q23, Q4, Q5, Q6, Q7, "s64", "s65")
+#define CC_ISSUE_B(Q0, Q23, Q4, Q5, Q6, Q7, BLO, BHI)                                   \
   "s_set_gpr_idx_on " Q4 ", gpr_idx(SRC0)\n"                                            \
   "v_mov_b32 v194, v128\n"                                                              \
   "v_mov_b32 v195, v129\n"                                                              \
@@ -89,8 +90,8 @@
   "s_set_gpr_idx_off\n"                                                                 \
   "s_mov_b32 s38, " Q6 "\n"                                                             \
   "s_mov_b32 s39, " Q7 "\n"                                                             \
-  "s_add_u32 s90, s64, " Q0 "\n"                                                        \
-  "s_addc_u32 s91, s65, 0\n"                                                            \
+  "s_add_u32 s90, " BLO ", " Q0 "\n"                                                    \
+  "s_addc_u32 s91, " BHI ", 0\n"                                                        \
   "v_lshl_add_u64 v[198:199], v[196:197], 0, " Q23 "\n"                                 \
   "s_swappc_b64 s[54:55], s[90:91]\n"
 // converged mode: every eligible lane is in; the epilogue only moves the scalar state on
@@ -110,6 +111,21 @@
   "s_mov_b32 s34, s35\n"                                                                \
   "s_sub_u32 s36, s36, 1\n"                                                             \
   "s_cbranch_scc1 L_exit_%=\n"
+// Converged mode runs THREADED: two more copies of the handler table (A: the record sits in buffer A, B: in buffer B) whose handlers
+// end with the next step's front end and dispatch straight into the other copy - one taken branch per simulated instruction instead
+// of two (each ~11 ns with one wave on the SIMD).  A handler that leaves through shared code and returns with s[54:55] lands behind
+// the dispatch that called it, which branches to a stand-alone copy of the tail.
+#define CC_TSTEP(Q0, Q1, Q23, Q4, Q5, Q6, Q7, QN, BLO, BHI, NEXT)                       \
+  CC_FETCH(Q1, QN) CC_ISSUE_B(Q0, Q23, Q4, Q5, Q6, Q7, BLO, BHI)                        \
+  "s_branch " NEXT "\n"
+#define CC_TSTEP_(...) CC_TSTEP(__VA_ARGS__)
+#define CC_TEPI                                                                         \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  "s_mov_b32 s34, s35\n"                                                                \
+  "s_sub_u32 s36, s36, 1\n"                                                             \
+  "s_cbranch_scc1 L_exit_conv_%=\n"
+#define CC_TAIL_A CC_TEPI CC_TSTEP_(CC_QB, "s86", "s87", "L_tail_B_%=")     /* record A done: the one in B next, through table B */
+#define CC_TAIL_B CC_TEPI CC_TSTEP_(CC_QA, "s66", "s67", "L_tail_A_%=")
 #define CC_QA "s40", "s41", "s[42:43]", "s44", "s45", "s46", "s47", "s[56:63]"
 #define CC_QB "s56", "s57", "s[58:59]", "s60", "s61", "s62", "s63", "s[40:47]"
 #define CC_QT "s72", "s73", "s[74:75]", "s76", "s77", "s78", "s79", "s[40:47]"
@@ -127,9 +143,9 @@
   "v_mov_b32 v202, " NPC "\n"                                                           \
   "v_addc_co_u32_e64 v235, s[92:93], 0, v235, s[84:85]\n"                               \
   "v_cndmask_b32_e64 v234, v234, v202, s[84:85]\n"
-#define CC_RET "s_setpc_b64 s[54:55]\n"
+#define CC_RET "s_setpc_b64 s[54:55]\n"             /* (redefined around the threaded copies of the handler table) */
 #define CC_WR_RET CC_WR CC_RET
-#define CC_H(k) ".org L_htab_%= + 512 * " #k "\n"
+#define CC_H(k) ".org " CC_HTAB " + 512 * " #k "\n"
 // leaving converged mode: the steps taken in it reach the lanes' retire counts
 #define CC_FLUSH                                                                        \
   "s_sub_u32 s88, s37, s36\n"                                                           \
@@ -319,6 +335,10 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "L_anchor_%=:\n"
     "s_add_u32 s64, s64, L_htab_%=-L_anchor_%=\n"
     "s_addc_u32 s65, s65, 0\n"
+    "s_add_u32 s66, s64, L_htabA_%=-L_htab_%=\n"
+    "s_addc_u32 s67, s65, 0\n"
+    "s_add_u32 s86, s64, L_htabB_%=-L_htab_%=\n"
+    "s_addc_u32 s87, s65, 0\n"
     "v_cmp_ne_u32_e64 s[70:71], -1, v234\n"
     "s_branch L_sched_%=\n"
     // ------------------------------------------------------------------ a control transfer in diverged mode (or one that splits the
@@ -368,9 +388,11 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     CC_DPPMIN("v234", "s34")
     "s_branch L_sched_have_%=\n"
     // ------------------------------------------------------------------ the steps, converged mode
-    "L_CT_T_%=:\n" CC_CSTEP_(CC_QT)
-    "L_CT_A_%=:\n" CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB) CC_CSTEP_(CC_QA) CC_CSTEP_(CC_QB)
-    "s_branch L_CT_A_%=\n"
+    "L_CT_T_%=:\n" CC_TSTEP_(CC_QT, "s86", "s87", "L_tail_B_%=")     // after a taken branch: the record in T, its successor into A = what
+                                                                        // table B's tails continue with
+    "L_CT_A_%=:\n" CC_TSTEP_(CC_QA, "s66", "s67", "L_tail_A_%=")
+    "L_tail_A_%=:\n" CC_TAIL_A
+    "L_tail_B_%=:\n" CC_TAIL_B
     // ------------------------------------------------------------------ shared pieces
     "L_bad_%=:\n"                                  // nobody of the group executes: general path
     "v_cndmask_b32_e64 v236, v236, 1, s[84:85]\n"
@@ -419,100 +441,22 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     CC_FLUSH
     "s_branch L_sched_count_%=\n"
     // ------------------------------------------------------------------ handlers, 512 bytes apart (class order: HC_* in wsp_core.h)
-    ".p2align 9\n"
-    "L_htab_%=:\n"
-    "s_branch L_bad_%=\n"                                                                                   // HC_BAD
-    CC_H(1)  "v_lshl_add_u64 v[200:201], v[194:195], 0, v[198:199]\n" CC_WR_RET                             // add
-    CC_H(2)  "v_sub_co_u32_e32 v200, vcc, v194, v198\n" "s_nop 1\n" "v_subb_co_u32_e32 v201, vcc, v195, v199, vcc\n" CC_WR_RET
-    CC_H(3)  "v_lshlrev_b64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // sll
-    CC_H(4)  "v_cmp_lt_i64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_WR_RET
-    CC_H(5)  "v_cmp_lt_u64_e32 vcc, v[194:195], v[198:199]\n" "v_mov_b32 v201, 0\n" "s_nop 0\n" "v_cndmask_b32_e64 v200, 0, 1, vcc\n" CC_WR_RET
-    CC_H(6)  "v_xor_b32 v200, v194, v198\n" "v_xor_b32 v201, v195, v199\n" CC_WR_RET
-    CC_H(7)  "v_lshrrev_b64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // srl
-    CC_H(8)  "v_ashrrev_i64 v[200:201], v198, v[194:195]\n" CC_WR_RET                                       // sra
-    CC_H(9)  "v_or_b32 v200, v194, v198\n" "v_or_b32 v201, v195, v199\n" CC_WR_RET
-    CC_H(10) "v_and_b32 v200, v194, v198\n" "v_and_b32 v201, v195, v199\n" CC_WR_RET
-    CC_H(11) "v_add_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                      // addw
-    CC_H(12) "v_sub_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                      // subw
-    CC_H(13) "v_lshlrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // sllw
-    CC_H(14) "v_lshrrev_b32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // srlw
-    CC_H(15) "v_ashrrev_i32 v200, v198, v194\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                  // sraw
-    CC_H(16) "v_mad_u64_u32 v[200:201], s[92:93], v194, v198, 0\n" "v_mul_lo_u32 v202, v195, v198\n" "v_mul_lo_u32 v203, v194, v199\n"
-             "v_add3_u32 v201, v201, v202, v203\n" CC_WR_RET                                                // mul
-    CC_H(17) "v_mul_lo_u32 v200, v194, v198\n" "v_ashrrev_i32 v201, 31, v200\n" CC_WR_RET                   // mulw
-    CC_H(18) "s_lshl_b32 s88, s39, 4\n"                                                                     // jal: link = the immediate
-             "s_load_dwordx8 s[72:79], s[80:81], s88\n"
-             "v_mov_b32 v200, v198\n" "v_mov_b32 v201, v199\n" CC_WR
-             "s_cmp_lg_u32 s48, 0\n"
-             "s_cbranch_scc1 L_jal_div_%=\n"
-             CC_TAKEN_ALL
-    CC_H(19) "v_lshl_add_u64 v[202:203], v[194:195], 0, v[198:199]\n"                                       // jalr
-             "v_and_b32 v203, v228, v203\n"
-             "v_and_b32 v202, -2, v202\n"
-             "v_lshl_add_u64 v[202:203], v[202:203], 0, v[226:227]\n"
-             "s_add_u32 s94, s82, s35\n" "s_addc_u32 s95, s83, 0\n"
-             "v_cmp_eq_u32_e64 s[92:93], 0, v203\n"
-             "v_cmp_gt_u32_e32 vcc, s53, v202\n"
-             "s_and_b64 s[92:93], s[92:93], vcc\n"
-             CC_ALLOK
-             "s_ashr_i32 s88, s94, 31\n"
-             "s_bitcmp1_b32 s49, 1\n"
-             "s_cselect_b32 s95, s88, s95\n"               // rv32: the link register holds the sign-extended 32-bit pc
-             "v_mov_b32 v200, s94\n" "v_mov_b32 v201, s95\n" CC_WR
-             "s_branch L_jalr_tail_%=\n"
-    CC_H(20) CC_BR_FWD("v_cmp_eq_u64_e32")  CC_H(21) CC_BR_FWD("v_cmp_ne_u64_e32")  CC_H(22) CC_BR_FWD("v_cmp_lt_i64_e32")
-    CC_H(23) CC_BR_FWD("v_cmp_ge_i64_e32")  CC_H(24) CC_BR_FWD("v_cmp_lt_u64_e32")  CC_H(25) CC_BR_FWD("v_cmp_ge_u64_e32")
-    CC_H(26) CC_BR_BACK("v_cmp_eq_u64_e32") CC_H(27) CC_BR_BACK("v_cmp_ne_u64_e32") CC_H(28) CC_BR_BACK("v_cmp_lt_i64_e32")
-    CC_H(29) CC_BR_BACK("v_cmp_ge_i64_e32") CC_H(30) CC_BR_BACK("v_cmp_lt_u64_e32") CC_H(31) CC_BR_BACK("v_cmp_ge_u64_e32")
-    CC_H(32) CC_BR_OUT("v_cmp_eq_u64_e32")  CC_H(33) CC_BR_OUT("v_cmp_ne_u64_e32")  CC_H(34) CC_BR_OUT("v_cmp_lt_i64_e32")
-    CC_H(35) CC_BR_OUT("v_cmp_ge_i64_e32")  CC_H(36) CC_BR_OUT("v_cmp_lt_u64_e32")  CC_H(37) CC_BR_OUT("v_cmp_ge_u64_e32")
-    CC_H(38) CC_LOAD("v[214:215]", "0", "global_load_sbyte v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(39) CC_LOAD("v[216:217]", "1", "global_load_sshort v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(40) CC_LOAD("v[218:219]", "3", "global_load_dword v200,", "v_ashrrev_i32 v201, 31, v200\n")
-    CC_H(41) CC_LOAD("v[220:221]", "7", "global_load_dwordx2 v[200:201],", "")
-    CC_H(42) CC_LOAD("v[214:215]", "0", "global_load_ubyte v200,", "v_mov_b32 v201, 0\n")
-    CC_H(43) CC_LOAD("v[216:217]", "1", "global_load_ushort v200,", "v_mov_b32 v201, 0\n")
-    CC_H(44) CC_LOAD("v[218:219]", "3", "global_load_dword v200,", "v_mov_b32 v201, 0\n")
-    CC_H(45) CC_STORE("v[214:215]", "1", "0", "global_store_byte v[206:207], v196, off")
-    CC_H(46) CC_STORE("v[216:217]", "2", "1", "global_store_short v[206:207], v196, off")
-    CC_H(47) CC_STORE("v[218:219]", "4", "3", "global_store_dword v[206:207], v196, off")
-    CC_H(48) CC_STORE("v[220:221]", "8", "7", "global_store_dwordx2 v[206:207], v[196:197], off")
-    CC_H(49) CC_RET                                                                                         // nop
-    CC_H(50) CC_FPON CC_ADDR("v[218:219]", "3") CC_ALLOK CC_LANEPTR                                         // flw
-             CC_FADDR("v238")
-             "s_bitcmp1_b32 s49, 3\n" "s_cselect_b32 s88, -1, 0\n" "v_mov_b32 v201, s88\n"
-             CC_MEMEXEC
-             "global_load_dword v200, v[206:207], off\n"
-             "s_waitcnt vmcnt(0)\n"
-             "ds_write_b64 v238, v[200:201]\n"
-             CC_ALUEXEC CC_RET
-    CC_H(51) CC_FPON CC_ADDR("v[220:221]", "7") CC_ALLOK CC_LANEPTR                                         // fld
-             CC_FADDR("v238")
-             CC_MEMEXEC
-             "global_load_dwordx2 v[200:201], v[206:207], off\n"
-             "s_waitcnt vmcnt(0)\n"
-             "ds_write_b64 v238, v[200:201]\n"
-             CC_ALUEXEC CC_RET
-    CC_H(52) CC_FPON CC_FADDR("v238")                                                                       // fsw
-             "ds_read_b64 v[196:197], v238\n"
-             CC_ADDR("v[218:219]", "3") CC_STCHK("4") CC_ALLOK CC_LANEPTR
-             "s_waitcnt lgkmcnt(0)\n"
-             CC_MEMEXEC "global_store_dword v[206:207], v196, off\n" CC_ALUEXEC
-             CC_RET
-    CC_H(53) CC_FPON CC_FADDR("v238")                                                                       // fsd
-             "ds_read_b64 v[196:197], v238\n"
-             CC_ADDR("v[220:221]", "7") CC_STCHK("8") CC_ALLOK CC_LANEPTR
-             "s_waitcnt lgkmcnt(0)\n"
-             CC_MEMEXEC "global_store_dwordx2 v[206:207], v[196:197], off\n" CC_ALUEXEC
-             CC_RET
-    CC_H(54) "v_mov_b32 v0, s39\n"                                                                          // mulh* div* rem* Zb*
-             "v_sub_u32 v1, v198, v196\n"
-             "v_mov_b32 v2, v194\n" "v_mov_b32 v3, v195\n" "v_mov_b32 v4, v196\n" "v_mov_b32 v5, v197\n" "v_mov_b32 v6, s52\n"
-             "s_waitcnt lgkmcnt(0)\n"                      // the successor's record must have landed: the callee may use those registers
-             CC_CALL("wsp_pure_int")
-             "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"
-    CC_H(55) CC_PURE_FP_CALL CC_MEMEXEC "ds_write_b64 v241, v[0:1]\n" CC_ALUEXEC "s_branch L_resume_%=\n"                         // F / D -> f[rd]
-    CC_H(56) CC_PURE_FP_CALL "v_mov_b32 v200, v0\n" "v_mov_b32 v201, v1\n" CC_WR "s_branch L_resume_%=\n"  // F / D -> x[rd]
+#define CC_HTAB "L_htab_%="
+#define CC_RET "s_setpc_b64 s[54:55]\n"
+#include "wsp_conv_handlers.inc"
+#undef CC_HTAB
+#undef CC_RET
+#define CC_HTAB "L_htabA_%="
+#define CC_RET CC_TAIL_A
+#include "wsp_conv_handlers.inc"
+#undef CC_HTAB
+#undef CC_RET
+#define CC_HTAB "L_htabB_%="
+#define CC_RET CC_TAIL_B
+#include "wsp_conv_handlers.inc"
+#undef CC_HTAB
+#undef CC_RET
+#define CC_RET "s_setpc_b64 s[54:55]\n"
     // ------------------------------------------------------------------ exit: x file back to LDS
     "L_exit_%=:\n"
     "s_mov_b64 exec, s[70:71]\n"                   // only lanes that took part own an x block (the others alias lane 0's / their owner's)

@@ -509,6 +509,26 @@ extern "C" __device__ u64 wsp_pure_int(u32 w0, i32 imm, u64 a, u64 b, u32 isa);
 extern "C" __device__ __noinline__ __attribute__((used)) WspPureRet wsp_pure_fp(u32 w0, i32 imm, u64 xa, u64 f1, u64 f2, u64 f3, u32 fcsr, u32 isa)
 {
   w0 = wsp_uni32(w0); imm = (i32)wsp_uni32((u32)imm); isa = wsp_uni32(isa);
+  {
+    // The common double-precision arithmetic first, without the hart object: round to nearest even and ordinary operands take
+    // the FP unit's paths (hw_* in wsp_softfloat.h: the machine result plus the exact inexact flag); a lane outside their domain,
+    // or under another rounding mode, goes on to the general routine below.
+    using namespace wsf;
+    const u32 op0 = w0 & 0xff;
+    if ((w0 & F_DBL) && (op0 == OP_FADD || op0 == OP_FSUB || op0 == OP_FMUL || op0 == OP_FDIV || op0 == OP_FMA || op0 == OP_FCVT_I2F)) {
+      u32 rm0 = (u32)imm & 7; if (rm0 == 7) rm0 = (fcsr >> 5) & 7;
+      u64 z = 0; unsigned fl = 0; bool hw = false;
+      if (rm0 == RM_RNE) {
+        if (op0 == OP_FADD) hw = hw_add64(f1, f2, z, fl);
+        else if (op0 == OP_FSUB) hw = hw_add64(f1, f2 ^ F64::SIGN, z, fl);
+        else if (op0 == OP_FMUL) hw = hw_mul64(f1, f2, z, fl);
+        else if (op0 == OP_FDIV) hw = hw_div64(f1, f2, z, fl);
+        else if (op0 == OP_FMA) { const u32 k = ((u32)imm >> 3) & 3; hw = hw_fma64((k == 2 || k == 3) ? f1 ^ F64::SIGN : f1, f2, (k == 1 || k == 3) ? f3 ^ F64::SIGN : f3, z, fl); }
+        else { const u32 rs2 = (w0 >> 18) & 31; z = hw_int_to_f64(xa, !(rs2 & 1), (rs2 & 2) != 0, fl); hw = true; }
+      }
+      if (hw) { WspPureRet q; q.val = z; q.fcsr = fcsr | fl; q.ok = 1; return q; }
+    }
+  }
   Lane<PureMem, true> L;
   L.isa = isa; L.h.fcsr = fcsr; L.h.mstatus = MSTATUS_RESET | (3ULL << MST_FS_SH) | MST_SD; L.h.flags = HF_NOTRACE; L.h.status = ST_RUNNING; L.h.priv = PRV_M;
   L.s.chg = 0;
