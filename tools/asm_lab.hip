@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(64, 1) lab_kernel(const HRec* hrecs, u64 mbase
   const u32 xb = own * 33 * 8, foff = lpw * 33 * 8;
   u8* arena = arena_all + (size_t)blockIdx.x * lpw * msize + (size_t)own * 8;
   u32 vpc = active ? 0u : 0xffffffffu, fcsr = 0, vit = 0, ncv = 0;
-  conv_core(hrecs, mbase, msize, tlo, tlo + tlen, tlen, cfg, lpw_shift, foff, n, isa, xb, arena, ~0ULL, vpc, fcsr, vit, ncv);
+  u64 th = 0;
+  conv_core(hrecs, hrecs, mbase, msize, tlo, tlo + tlen, tlen, cfg, lpw_shift, foff, n, isa, xb, arena, ~0ULL, vpc, fcsr, th, vit, ncv);
   __syncthreads();
   if (active) {
     out_vit[(blockIdx.x * lpw + lane) * 3 + 0] = vit; out_vit[(blockIdx.x * lpw + lane) * 3 + 1] = ncv; out_vit[(blockIdx.x * lpw + lane) * 3 + 2] = vpc;
@@ -120,7 +121,7 @@ int main(int argc, char** argv)
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(t0));
-      hipLaunchKernelGGL(lab_kernel, dim3(waves), dim3(64), 2 * lpw * 33 * 8, 0, dh, mbase, msize, mbase, tlen, lpw_shift, (u32)(steps + 100), isa, arena, iters, d_vit, d_x, 4u | 8u | (getenv("LAB_DIV") ? 0x10000u : 0u));
+      hipLaunchKernelGGL(lab_kernel, dim3(waves), dim3(64), 2 * lpw * 33 * 8, 0, dh, mbase, msize, mbase, tlen, lpw_shift, (u32)(steps + 100), isa, arena, iters, d_vit, d_x, 4u | 8u | (getenv("LAB_DIV") ? 0x10000u : 0u) | (getenv("LAB_TR") ? 0x20000u : 0u));
       CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
       float ms; CK(hipEventElapsedTime(&ms, t0, t1)); if (ms < best) best = ms;
     }

@@ -50,11 +50,13 @@
 //                s52 isa  s53 text length  s[54:55] return address of the step  s[64:65] handler table
 //                s[66:67] s[86:87] the threaded copies A / B of the handler table  s[68:69] exec at entry (= while the loop runs)  s[70:71] eligible lanes
 //                s[80:81] hot records  s[82:83] text_lo  s[84:85] the lanes that execute the current instruction
+//                traced runs: s[96:97] record image  s98 instruction bits  s99 size  (s[64:65]: the traced copy of the handler table)
 //  clobbered by calls: s[40:47] record buffer A  s[56:63] buffer B  s[72:79] buffer T (branch / jump target)
 //                s88 s89 scratch  s[90:91] dispatch target  s[92:93] s[94:95] scratch pairs
 //  v[128:193] x file  v[194:195] a  v[196:197] b  v[198:199] b + imm  v[200:201] result  v[202:209] scratch  v[210:211] tohost + 4
 //  v[212:213] -mem_base  v[214:221] mem_size - 1 / 2 / 4 / 8  v[222:223] text_lo  v[224:225] text_hi  v[226:227] -text_lo
 //  v228 high address mask  v229 xb  v[230:231] arena  v[232:233] tohost  v234 pc  v235 retired  v236 ncv  v237 fcsr  v[238:241] scratch
+//  traced runs: v[242:243] commit digest  v[244:245] v[246:247] the record's (key, value)  v[248:249] digest being folded
 
 #define CC_DPPMIN(src, dst_s)                                                           \
   "v_mov_b32 v202, " src "\n"                                                           \
@@ -137,7 +139,7 @@
   "s_set_gpr_idx_on s38, gpr_idx(SRC0,DST)\n"                                           \
   "v_cndmask_b32_e64 v128, v128, v200, s[84:85]\n"                                      \
   "v_cndmask_b32_e64 v129, v129, v201, s[84:85]\n"                                      \
-  "s_set_gpr_idx_off\n"
+  "s_set_gpr_idx_off\n" CC_TRH_REG
 // the lanes that execute move to pc NPC (an SGPR) and retire one instruction
 #define CC_ADVANCE(NPC)                                                                 \
   "v_mov_b32 v202, " NPC "\n"                                                           \
@@ -194,9 +196,9 @@
   "s_and_b64 s[92:93], s[92:93], s[94:95]\n"                                            \
   "s_and_b64 s[88:89], s[88:89], vcc\n"                                                 \
   "s_andn2_b64 s[92:93], s[92:93], s[88:89]\n"
-#define CC_STORE(LIM, SZ, SZM1, STOP)                                                   \
+#define CC_STORE(LIM, SZ, SZM1, STOP, TRH)                                              \
   CC_STDATA CC_ADDR(LIM, SZM1) CC_STCHK(SZ) CC_ALLOK CC_LANEPTR                         \
-  CC_MEMEXEC STOP "\n" CC_ALUEXEC CC_RET
+  CC_MEMEXEC STOP "\n" CC_ALUEXEC TRH CC_RET
 #define CC_FADDR(dst) "s_add_u32 s88, s38, s51\n" "v_add_u32 " dst ", s88, v229\n"      /* LDS address of the f register of word 6 */
 #define CC_FPON "s_bitcmp1_b32 s49, 2\n" "s_cbranch_scc0 L_bad_%=\n"
 
@@ -261,6 +263,72 @@
   "s_cbranch_scc1 L_bad_%=\n"                                                           \
   "v_cndmask_b32_e64 v237, v237, v2, s[84:85]\n"
 
+// ---- traced runs (cfg bit 17): the commit digest of every executed instruction, as the C++ loop folds it (wsp_lib.hip: pc, meta =
+// raw | M << 32 | size << 48, then one (key, value) pair: x register / f register / memory / none).  One more copy of the handler
+// table whose handlers leave the pair in v[244:245], v[246:247] (the CC_TRX_* hooks); the step folds the four words into the lane's
+// digest v[242:243] under the mask of the lanes that execute.  Traced runs use diverged-mode steps throughout (per-lane pc and
+// counters), call / return dispatch, and leave F / D arithmetic to the general path (its record can carry an fcsr pair too).
+#define CC_TRX_REG                                                                      \
+  "s_lshr_b32 s88, s38, 1\n" "s_cmp_lg_u32 s38, 0\n" "s_cselect_b32 s89, -1, 0\n"       \
+  "v_mov_b32 v244, s88\n" "v_mov_b32 v245, 0x10000000\n"                                \
+  "v_and_b32 v246, s89, v200\n" "v_and_b32 v247, v228, v201\n" "v_and_b32 v247, s89, v247\n"
+#define CC_TRX_STK "v_mov_b32 v244, v202\n" "v_xor_b32 v245, 0x40000000, v203\n"
+#define CC_TRX_ST1 CC_TRX_STK "v_and_b32 v246, 0xff, v196\n" "v_mov_b32 v247, 0\n"
+#define CC_TRX_ST2 CC_TRX_STK "v_and_b32 v246, 0xffff, v196\n" "v_mov_b32 v247, 0\n"
+#define CC_TRX_ST4 CC_TRX_STK "v_mov_b32 v246, v196\n" "v_mov_b32 v247, 0\n"
+#define CC_TRX_ST8 CC_TRX_STK "v_mov_b32 v246, v196\n" "v_mov_b32 v247, v197\n"
+#define CC_TRX_FLD "s_lshr_b32 s88, s38, 3\n" "v_mov_b32 v244, s88\n" "v_mov_b32 v245, 0x20000000\n" "v_mov_b32 v246, v200\n" "v_mov_b32 v247, v201\n"
+#define CC_TRX_NONE "v_mov_b32 v244, 0\n" "v_mov_b32 v245, 0x10000000\n" "v_mov_b32 v246, 0\n" "v_mov_b32 v247, 0\n"
+#define CC_BR_TR(CMP, OUT)                                                              \
+  CMP " vcc, v[194:195], v[196:197]\n" "s_and_b64 vcc, vcc, s[84:85]\n" OUT              \
+  "v_mov_b32 v202, s35\n" "v_mov_b32 v203, s39\n" CC_TRX_NONE                            \
+  "v_cndmask_b32_e32 v202, v202, v203, vcc\n" "s_branch L_tr_ctl_%=\n"
+// h = fold(h, w) on the working copy v[248:249]: h ^= w; h = rotl(h, 27); h = h * 5 + 0x52dce729 (wsp_core.h)
+#define CC_FOLD(WLO, WHI)                                                               \
+  "v_xor_b32 v238, " WLO ", v248\n" "v_xor_b32 v239, " WHI ", v249\n"                    \
+  "v_alignbit_b32 v240, v238, v239, 5\n" "v_alignbit_b32 v241, v239, v238, 5\n"         \
+  "v_lshl_add_u64 v[238:239], v[240:241], 2, v[240:241]\n"                              \
+  "v_add_co_u32_e32 v248, vcc, 0x52dce729, v238\n" "v_addc_co_u32_e32 v249, vcc, 0, v239, vcc\n"
+#define CC_FOLD4                                                                        \
+  "v_mov_b32 v248, v242\n" "v_mov_b32 v249, v243\n"                                     \
+  "s_add_u32 s92, s82, s34\n" "s_addc_u32 s93, s83, 0\n" CC_FOLD("s92", "s93")          \
+  "s_lshl_b32 s89, s99, 16\n" "s_or_b32 s89, s89, 3\n" CC_FOLD("s98", "s89")            \
+  CC_FOLD("v244", "v245") CC_FOLD("v246", "v247")                                       \
+  "v_cndmask_b32_e64 v242, v242, v248, s[84:85]\n" "v_cndmask_b32_e64 v243, v243, v249, s[84:85]\n"
+#define CC_RSTEP(Q0, Q1, Q23, Q4, Q5, Q6, Q7, QN)                                       \
+  CC_FETCH(Q1, QN)                                                                      \
+  "s_lshl_b32 s88, s34, 3\n" "s_add_u32 s88, s88, 12\n" "s_load_dword s98, s[96:97], s88\n"   \
+  "s_mov_b32 s99, " Q1 "\n"                                                             \
+  "v_cmp_eq_u32_e64 s[84:85], s34, v234\n"                                              \
+  CC_ISSUE(Q0, Q23, Q4, Q5, Q6, Q7)                                                     \
+  "s_waitcnt lgkmcnt(0)\n"                                                              \
+  CC_FOLD4                                                                              \
+  CC_ADVANCE("s35")                                                                     \
+  "s_mov_b32 s34, s35\n"                                                                \
+  "s_sub_u32 s36, s36, 1\n"                                                             \
+  "s_cbranch_scc1 L_exit_%=\n"
+#define CC_RSTEP_(...) CC_RSTEP(__VA_ARGS__)
+// hooks and endings of the untraced copies
+#define CC_TRH_REG
+#define CC_TRH_ST1
+#define CC_TRH_ST2
+#define CC_TRH_ST4
+#define CC_TRH_ST8
+#define CC_TRH_FLD
+#define CC_TRH_NONE
+#define CC_TRH_NOFP
+#define CC_JAL_END "s_cmp_lg_u32 s48, 0\n" "s_cbranch_scc1 L_jal_div_%=\n" CC_TAKEN_ALL
+#define CC_JALR_END "s_branch L_jalr_tail_%=\n"
+
+// The compiler prices an inline-asm block at 8 bytes per statement and does not see the 512-byte alignment of the handler slots, so it
+// would place short branches across this block (~122 KB of code from ~6500 statements) that cannot reach.  10240 re-definable local
+// labels emit nothing and bring its estimate above the real size, so that it relaxes those branches.
+#define CC_PAD4 "1:\n1:\n1:\n1:\n"
+#define CC_PAD32 CC_PAD4 CC_PAD4 CC_PAD4 CC_PAD4 CC_PAD4 CC_PAD4 CC_PAD4 CC_PAD4
+#define CC_PAD256 CC_PAD32 CC_PAD32 CC_PAD32 CC_PAD32 CC_PAD32 CC_PAD32 CC_PAD32 CC_PAD32
+#define CC_PAD2K CC_PAD256 CC_PAD256 CC_PAD256 CC_PAD256 CC_PAD256 CC_PAD256 CC_PAD256 CC_PAD256
+#define CC_SIZE_PAD CC_PAD2K CC_PAD2K CC_PAD2K CC_PAD2K CC_PAD2K
+
 #define CC_CLOBBERS \
   "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
   "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", \
@@ -273,24 +341,26 @@
   "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", \
   "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", \
   "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", \
-  "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+  "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", \
   "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", \
   "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s34", "s35", "s36", "s37", "s38", "s39", \
   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", \
   "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", \
   "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", \
-  "s94", "s95", "vcc", "scc", "memory"
+  "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "memory"
 
 namespace wsp {
 
 // One run of the converged loop.  Arguments that are the same for the whole wave may sit in any lane's registers (they are read
 // with v_readfirstlane).  hrecs: hot-record image of the wave's program; cfg: bit 1 rv32, bit 16 never enter converged mode (tests of the diverged steps), bit 2 mstatus.FS dirty in every lane that
-// takes part (flw / fld / fsw / fsd and F / D arithmetic inline), bit 3 D extension (flw boxes); xb: LDS byte offset of the lane's x
+// takes part (flw / fld / fsw / fsd and F / D arithmetic inline), bit 3 D extension (flw boxes), bit 17 traced run (thash: the lane's
+// commit digest, updated for every instruction it executes; recs: the program's 16-byte record image, for the instruction bits); xb: LDS byte offset of the lane's x
 // block; arena: the lane's arena base (DevMem::arena); vpc: the lane's pc as a text offset, 0xffffffff for lanes that take no part;
 // fcsr: the lane's fcsr; n: iterations (>= 1).  Out: vit = instructions retired by the lane, ncv != 0 = the lane stands at an
 // instruction for the general path.
-__device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg, u32 lpw_shift,
-                                          u32 foff, u32 n, u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr, u32& vit, u32& ncv)
+__device__ __forceinline__ void conv_core(const void* hrecs, const void* recs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg,
+                                          u32 lpw_shift, u32 foff, u32 n, u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr,
+                                          u64& thash, u32& vit, u32& ncv)
 {
   u32 vit_ = 0, ncv_ = 0;
   asm volatile(
@@ -302,6 +372,7 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "v_mov_b64 v[222:223], %[tlo]\n"   "v_mov_b64 v[224:225], %[thi]\n"
     "v_mov_b32 v208, %[cfg]\n"         "v_mov_b32 v209, %[lpwsh]\n"         "v_mov_b32 v238, %[foff]\n"         "v_mov_b32 v239, %[n]\n"
     "v_mov_b32 v240, %[isa]\n"         "v_mov_b32 v241, %[tlen]\n"
+    "v_mov_b64 v[242:243], %[thash]\n" "v_mov_b64 v[244:245], %[rimg]\n"
     "ds_read_b64 v[130:131], v229 offset:8\n"    "ds_read_b64 v[132:133], v229 offset:16\n"   "ds_read_b64 v[134:135], v229 offset:24\n"
     "ds_read_b64 v[136:137], v229 offset:32\n"   "ds_read_b64 v[138:139], v229 offset:40\n"   "ds_read_b64 v[140:141], v229 offset:48\n"
     "ds_read_b64 v[142:143], v229 offset:56\n"   "ds_read_b64 v[144:145], v229 offset:64\n"   "ds_read_b64 v[146:147], v229 offset:72\n"
@@ -316,7 +387,7 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "v_mov_b32 v192, 0\n"  "v_mov_b32 v193, 0\n"  "v_mov_b32 v128, 0\n"  "v_mov_b32 v129, 0\n"
     "v_readfirstlane_b32 s80, v202\n"  "v_readfirstlane_b32 s81, v203\n"  "v_readfirstlane_b32 s82, v222\n"  "v_readfirstlane_b32 s83, v223\n"
     "v_readfirstlane_b32 s49, v208\n"  "v_readfirstlane_b32 s50, v209\n"  "v_readfirstlane_b32 s51, v238\n"  "v_readfirstlane_b32 s36, v239\n"
-    "v_readfirstlane_b32 s52, v240\n"  "v_readfirstlane_b32 s53, v241\n"
+    "v_readfirstlane_b32 s52, v240\n"  "v_readfirstlane_b32 s53, v241\n"  "v_readfirstlane_b32 s96, v244\n"  "v_readfirstlane_b32 s97, v245\n"
     "v_sub_co_u32_e32 v212, vcc, 0, v204\n"
     "v_lshl_add_u64 v[214:215], v[206:207], 0, -1\n"
     "v_lshl_add_u64 v[216:217], v[206:207], 0, -2\n"
@@ -339,6 +410,11 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_addc_u32 s67, s65, 0\n"
     "s_add_u32 s86, s64, L_htabB_%=-L_htab_%=\n"
     "s_addc_u32 s87, s65, 0\n"
+    "s_bitcmp1_b32 s49, 17\n"                     // a traced run dispatches through the traced copy only: s[64:65] is that one then
+    "s_cbranch_scc0 L_untraced_%=\n"
+    "s_add_u32 s64, s64, L_htabR_%=-L_htab_%=\n"
+    "s_addc_u32 s65, s65, 0\n"
+    "L_untraced_%=:\n"
     "v_cmp_ne_u32_e64 s[70:71], -1, v234\n"
     "s_branch L_sched_%=\n"
     // ------------------------------------------------------------------ a control transfer in diverged mode (or one that splits the
@@ -375,11 +451,13 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_cbranch_scc1 L_go_conv_%=\n"
     "L_go_div_%=:\n"
     "s_mov_b32 s48, 1\n"
+    "s_bitcmp1_b32 s49, 17\n"
+    "s_cbranch_scc1 L_RT_A_%=\n"
     // ------------------------------------------------------------------ the steps, diverged mode
     "L_DT_A_%=:\n" CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB) CC_DSTEP_(CC_QA) CC_DSTEP_(CC_QB)
     "s_branch L_DT_A_%=\n"
     "L_go_conv_%=:\n"
-    "s_bitcmp1_b32 s49, 16\n"                     // test hook: never enter converged mode
+    "s_and_b32 s88, s49, 0x30000\n"               // never converged mode: test hook (bit 16), traced run (bit 17)
     "s_cbranch_scc1 L_go_div_%=\n"
     "s_mov_b32 s48, 0\n"
     "s_mov_b32 s37, s36\n"
@@ -387,6 +465,15 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "L_sched_dpp_%=:\n"
     CC_DPPMIN("v234", "s34")
     "s_branch L_sched_have_%=\n"
+    // ------------------------------------------------------------------ the steps of a traced run
+    "L_RT_A_%=:\n" CC_RSTEP_(CC_QA) CC_RSTEP_(CC_QB) CC_RSTEP_(CC_QA) CC_RSTEP_(CC_QB)
+    "s_branch L_RT_A_%=\n"
+    "L_tr_ctl_%=:\n"                               // traced control transfer: lanes' next pcs in v202, pair set
+    "s_waitcnt lgkmcnt(0)\n"
+    CC_FOLD4
+    "v_addc_co_u32_e64 v235, s[92:93], 0, v235, s[84:85]\n"
+    "v_cndmask_b32_e64 v234, v234, v202, s[84:85]\n"
+    "s_branch L_sched_count_%=\n"
     // ------------------------------------------------------------------ the steps, converged mode
     "L_CT_T_%=:\n" CC_TSTEP_(CC_QT, "s86", "s87", "L_tail_B_%=")     // after a taken branch: the record in T, its successor into A = what
                                                                         // table B's tails continue with
@@ -415,6 +502,10 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "L_resume_%=:\n"                               // after a call: the step's epilogue by hand, then the next record again
     "s_cmp_lg_u32 s48, 0\n"
     "s_cbranch_scc0 L_resume2_%=\n"
+    "s_bitcmp1_b32 s49, 17\n"
+    "s_cbranch_scc0 L_resume1_%=\n"
+    CC_FOLD4
+    "L_resume1_%=:\n"
     CC_ADVANCE("s35")
     "L_resume2_%=:\n"
     "s_mov_b32 s34, s35\n"
@@ -423,6 +514,8 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "s_sub_u32 s36, s36, 1\n"
     "s_cbranch_scc1 L_exit_any_%=\n"
     "s_waitcnt lgkmcnt(0)\n"
+    "s_bitcmp1_b32 s49, 17\n"
+    "s_cbranch_scc1 L_RT_A_%=\n"
     "s_cmp_lg_u32 s48, 0\n"
     "s_cbranch_scc1 L_DT_A_%=\n"
     "s_branch L_CT_A_%=\n"
@@ -457,6 +550,36 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
 #undef CC_HTAB
 #undef CC_RET
 #define CC_RET "s_setpc_b64 s[54:55]\n"
+    // the traced copy: call / return dispatch, hooks on, control transfers through L_tr_ctl
+#define CC_HTAB "L_htabR_%="
+#undef CC_TRH_REG
+#undef CC_TRH_ST1
+#undef CC_TRH_ST2
+#undef CC_TRH_ST4
+#undef CC_TRH_ST8
+#undef CC_TRH_FLD
+#undef CC_TRH_NONE
+#undef CC_TRH_NOFP
+#undef CC_JAL_END
+#undef CC_JALR_END
+#undef CC_BR_FWD
+#undef CC_BR_BACK
+#undef CC_BR_OUT
+#define CC_TRH_REG CC_TRX_REG
+#define CC_TRH_ST1 CC_TRX_ST1
+#define CC_TRH_ST2 CC_TRX_ST2
+#define CC_TRH_ST4 CC_TRX_ST4
+#define CC_TRH_ST8 CC_TRX_ST8
+#define CC_TRH_FLD CC_TRX_FLD
+#define CC_TRH_NONE CC_TRX_NONE
+#define CC_TRH_NOFP "s_branch L_bad_%=\n"
+#define CC_JAL_END "v_mov_b32 v202, s39\n" "s_branch L_tr_ctl_%=\n"
+#define CC_JALR_END "s_branch L_tr_ctl_%=\n"
+#define CC_BR_FWD(CMP) CC_BR_TR(CMP, "")
+#define CC_BR_BACK(CMP) CC_BR_TR(CMP, "")
+#define CC_BR_OUT(CMP) CC_BR_TR(CMP, "s_cmp_lg_u64 vcc, 0\n" "s_cbranch_scc1 L_bad_%=\n")
+#include "wsp_conv_handlers.inc"
+#undef CC_HTAB
     // ------------------------------------------------------------------ exit: x file back to LDS
     "L_exit_%=:\n"
     "s_mov_b64 exec, s[70:71]\n"                   // only lanes that took part own an x block (the others alias lane 0's / their owner's)
@@ -473,10 +596,11 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
     "ds_write_b64 v229, v[184:185] offset:224\n"  "ds_write_b64 v229, v[186:187] offset:232\n"  "ds_write_b64 v229, v[188:189] offset:240\n"
     "ds_write_b64 v229, v[190:191] offset:248\n"
     "s_mov_b64 exec, s[68:69]\n"
-    "v_mov_b32 %[vpc], v234\n"  "v_mov_b32 %[vit], v235\n"  "v_mov_b32 %[ncv], v236\n"  "v_mov_b32 %[fcsr], v237\n"
+    "v_mov_b32 %[vpc], v234\n"  "v_mov_b32 %[vit], v235\n"  "v_mov_b32 %[ncv], v236\n"  "v_mov_b32 %[fcsr], v237\n"  "v_mov_b64 %[thash], v[242:243]\n"
     "s_waitcnt lgkmcnt(0)\n"
-    : [vpc] "+v"(vpc), [fcsr] "+v"(fcsr), [vit] "+v"(vit_), [ncv] "+v"(ncv_)
-    : [recs] "v"(hrecs), [mbase] "v"(mbase), [msize] "v"(msize), [tlo] "v"(tlo), [thi] "v"(thi), [tlen] "v"(tlen), [cfg] "v"(cfg),
+    CC_SIZE_PAD
+    : [vpc] "+v"(vpc), [fcsr] "+v"(fcsr), [thash] "+v"(thash), [vit] "+v"(vit_), [ncv] "+v"(ncv_)
+    : [recs] "v"(hrecs), [rimg] "v"(recs), [mbase] "v"(mbase), [msize] "v"(msize), [tlo] "v"(tlo), [thi] "v"(thi), [tlen] "v"(tlen), [cfg] "v"(cfg),
       [lpwsh] "v"(lpw_shift), [foff] "v"(foff), [n] "v"(n), [isa] "v"(isa), [xb] "v"(xb), [arena] "v"(arena), [tohost] "v"(tohost)
     : CC_CLOBBERS);
   vit = vit_; ncv = ncv_;
@@ -486,7 +610,7 @@ __device__ __forceinline__ void conv_core(const void* hrecs, u64 mbase, u64 msiz
 
 #else   // host pass of the same translation unit: the kernels' bodies are parsed but never run there
 namespace wsp {
-__device__ void conv_core(const void* hrecs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg, u32 lpw_shift, u32 foff, u32 n,
-                          u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr, u32& vit, u32& ncv);
+__device__ void conv_core(const void* hrecs, const void* recs, u64 mbase, u64 msize, u64 tlo, u64 thi, u32 tlen, u32 cfg, u32 lpw_shift, u32 foff,
+                          u32 n, u32 isa, u32 xb, const void* arena, u64 tohost, u32& vpc, u32& fcsr, u64& thash, u32& vit, u32& ncv);
 }
 #endif  // __HIP_DEVICE_COMPILE__

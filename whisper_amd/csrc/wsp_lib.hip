@@ -698,15 +698,17 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         u32 vpc = can ? (u32)off64 : 0xffffffffu;          // lanes that take no part never match a scheduled pc
         u32 vit = 0, ncv = 0, left_it = n;
 #if WSP_CONV_ASM
-        // untraced: the hand-written loop (wsp_conv_core.h), same contract; it reads the program's hot records
+        // the hand-written loop (wsp_conv_core.h), same contract, traced or not; it reads the program's hot records (the C++ loop
+        // below remains for images too large for them)
         const u64 hrecs_a = (u64)(size_t)pd.hrecs;
-        const bool use_asm = !(TRACE && tr) && hrecs_a != 0;
+        const bool use_asm = hrecs_a != 0;
         if (use_asm) {
           const bool fsd_all = FP && __all(!can || fsd);
-          const u32 cfg = (rv32 ? 2u : 0u) | (fsd_all ? 4u : 0u) | (boxd ? 8u : 0u);
-          u32 vfcsr = L.h.fcsr;
-          conv_core((const void*)(size_t)hrecs_a, mbase, msize, tlo, thi, tlen, cfg, d.lpw_shift, foff, n, d.isa, xb, L.m.arena, tohost, vpc, vfcsr, vit, ncv);
-          if (can) L.h.fcsr = vfcsr;
+          const u32 cfg = (rv32 ? 2u : 0u) | (fsd_all ? 4u : 0u) | (boxd ? 8u : 0u) | ((TRACE && tr) ? (1u << 17) : 0u);
+          u32 vfcsr = L.h.fcsr; u64 vth = L.h.thash;
+          conv_core((const void*)(size_t)hrecs_a, (const void*)recs_u, mbase, msize, tlo, thi, tlen, cfg, d.lpw_shift, foff, n, d.isa, xb, L.m.arena, tohost, vpc,
+                    vfcsr, vth, vit, ncv);
+          if (can) { L.h.fcsr = vfcsr; L.h.thash = vth; }
         } else {
 #endif
         u32 upc = wave_min_dpp(vpc);
@@ -1119,6 +1121,24 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
 }
 
+// Split build (whisper_amd.build): the four instantiations of the step kernel dominate the device compile, so the file is
+// compiled five times in parallel - WSP_STEP_PART = 0..3 keeps the text up to here and instantiates one step kernel each;
+// WSP_STEP_PART = -1 is everything else and only declares them.  Without WSP_STEP_PART the file is one translation unit
+// (profiling and A/B builds).
+#define WSP_STEP_DECL(T, F) template __global__ void wsp_step_kernel<T, F>(DevState d, const DevState* dp, u64 max_steps, u32 notrace)
+#if defined(WSP_STEP_PART) && WSP_STEP_PART == 0
+WSP_STEP_DECL(false, false);
+#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 1
+WSP_STEP_DECL(false, true);
+#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 2
+WSP_STEP_DECL(true, false);
+#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 3
+WSP_STEP_DECL(true, true);
+#elif defined(WSP_STEP_PART)
+extern WSP_STEP_DECL(false, false); extern WSP_STEP_DECL(false, true); extern WSP_STEP_DECL(true, false); extern WSP_STEP_DECL(true, true);
+#endif
+
+#if !defined(WSP_STEP_PART) || WSP_STEP_PART < 0
 // ------------------------------------------------------------------------------------------ support kernels
 // Pre-decode one program image: thread i decodes the (up to) 4 bytes at byte offset 2*i.
 __global__ void wsp_predecode_kernel(const u8* img, u64 n_bytes, u32 isa, Rec* out)
@@ -2533,3 +2553,4 @@ extern "C" int wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const ui
   HIPOK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(flags, dfl.p, n * 4, hipMemcpyDeviceToHost));
   return WSP_OK;
 }
+#endif  // !WSP_STEP_PART || WSP_STEP_PART < 0
