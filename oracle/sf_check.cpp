@@ -87,6 +87,15 @@ static void one_hw(u64 a, u64 b, u64 c)
   for (int k = 0; k < 4; ++k) { bool sg = k & 1, w = k & 2; u64 v = c >> (rnd() % 64); if (rnd() & 1) v = (u64)0 - v;
     f = 0; g = hw_int_to_f64(v, sg, w, f); softfloat_exceptionFlags = 0; e = Ref<F64>::fromi(v, sg, w); chk("hw.fromi", 0, v, 0, 0, g, f, e, softfloat_exceptionFlags); }
 }
+static void one_hw32(u64 a, u64 b, u64 c)
+{
+  softfloat_roundingMode = softfloat_round_near_even; unsigned f; u64 g, e;
+  TH("add32", hw_add32(a, b, g, f), Ref<F32>::add(a, b));
+  TH("sub32", hw_add32(a, b ^ F32::SIGN, g, f), Ref<F32>::sub(a, b));
+  TH("mul32", hw_mul32(a, b, g, f), Ref<F32>::mul(a, b));
+  TH("div32", hw_div32(a, b, g, f), Ref<F32>::div(a, b));
+  TH("fma32", hw_fma32(a, b, c, g, f), Ref<F32>::fma(a, b, c));
+}
 // operands the way programs have them: moderate exponents, few significant bits, exact quotients and products
 static u64 rand64o() { u64 r = rnd(); u64 e = (u64)(1023 + (int)(rnd() % 40) - 20) << 52; u64 m = r & 0xfffffffffffffULL;
   switch (rnd() % 4) { case 0: m &= ~((1ULL << (rnd() % 53)) - 1); break; case 1: m = 0; break; default: break; }
@@ -99,6 +108,7 @@ int main(int argc, char** argv)
   for (u64 a : s64) for (u64 b : s64) { one<F64>("f64", a, b, s64[rnd() % s64.size()]); }
   for (u64 a : s64) for (u64 b : s64) { one_hw(a, b, s64[rnd() % s64.size()]); }
   for (u64 a : s32) for (u64 b : s32) { one<F32>("f32", a, b, s32[rnd() % s32.size()]); }
+  for (u64 a : s32) for (u64 b : s32) for (u64 c : s32) one_hw32(a, b, c);
   for (u64 a : s64) for (u64 b : s64) for (int k = 0; k < 4; ++k) one<F64>("f64", a, b, s64[rnd() % s64.size()]);
   for (long i = 0; i < n; ++i) {
     u64 a = rand64f(), b = rand64f(), c = rand64f();
@@ -113,6 +123,13 @@ int main(int argc, char** argv)
     if (rnd() % 4 == 0) { softfloat_roundingMode = 0; z = f32_mul({(u32)x}, {(u32)y}).v ^ 0x80000000u; if (rnd() & 1) z = (u32)(z + (rnd() % 5) - 2); }
     if (rnd() % 8 == 0) y = (x ^ (rnd() % 2 ? 0x80000000u : 0) ^ (rnd() % 4)) & 0xffffffffu;
     one<F32>("f32", x, y, z);
+    one_hw32(x, y, z);
+    { // few significant bits, moderate exponents: exact sums / products / quotients, fma ties
+      auto ro = [] { u64 r = rnd(); u64 m = r & 0x7fffff; switch (rnd() % 4) { case 0: m &= ~((1ULL << (rnd() % 24)) - 1); break; case 1: m = 0; break; default: break; }
+                     return ((r >> 32) & 0x80000000ULL) | ((u64)(127 + (int)(rnd() % 40) - 20) << 23) | m; };
+      u64 p = ro(), q = ro(), w = ro(); one_hw32(p, q, w);
+      softfloat_roundingMode = 0; const u64 pq = f32_mul({(u32)p}, {(u32)q}).v; one_hw32(pq, q, pq ^ 0x80000000u);
+      one_hw32(p, q, (u64)(u32)((pq ^ 0x80000000u) + (rnd() % 5) - 2)); }
     // conversions between formats
     for (int rm = 0; rm < 5; ++rm) { softfloat_roundingMode = rm_sf[rm]; unsigned f = 0; u64 g = f64_to_f32(a, rm, f); softfloat_exceptionFlags = 0; u64 e = f64_to_f32({a}).v; chk("f64_to_f32", rm, a, 0, 0, g, f, e, softfloat_exceptionFlags); }
     { unsigned f = 0; u64 g = f32_to_f64(x, f); softfloat_exceptionFlags = 0; u64 e = ::f32_to_f64({(u32)x}).v; chk("f32_to_f64", 0, x, 0, 0, g, f, e, softfloat_exceptionFlags); }

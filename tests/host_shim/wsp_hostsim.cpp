@@ -21,6 +21,7 @@ struct HostMem {
   u64& tlb(u32 i) { return tlb_[i]; }
   u32 xlane_or(u32 v) const { return v; }            // one lane per hart on the host
   u32 xlane_min(u32 v) const { return v; }
+  u64 xlane_xchg64(u64 v, u32) const { return v; }
   void xlane_fence() const {}
   u64 vld(u32 o, u32 esz) const { u64 v = 0; memcpy(&v, vreg_ + o, (size_t)1 << esz); return v; }
   void vst(u32 o, u32 esz, u64 v) { memcpy(vreg_ + o, &v, (size_t)1 << esz); }

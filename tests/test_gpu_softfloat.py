@@ -150,3 +150,43 @@ def test_device_fp_unit_paths_match_reference_library():
     assert not bad, f"{len(bad)} of {total} cases differ; first: {bad[:5]}"
     assert hw > total // 2, (hw, total)
     print(f"{total} cases bit-exact, {hw} on the FP unit")
+
+
+def _rand32_ordinary(rng):
+    r = rng.getrandbits(32); e = (127 + rng.randrange(40) - 20) << 23; m = r & 0x7fffff
+    k = rng.randrange(4)
+    if k == 0: m &= ~((1 << rng.randrange(24)) - 1)
+    elif k == 1: m = 0
+    return (r & (1 << 31)) | e | m
+
+
+def test_device_fp_unit_binary32_paths_match_reference_library():
+    """The binary32 add / sub / mul / div / fused multiply-add / int32 -> float paths of the FP unit (hw_*32 in wsp_softfloat.h: computed in
+    binary64 and rounded once more, which is innocuous for the four basic operations; the fma ties through the unit's own binary32
+    fma) that the scalar F instructions and the vector unit's SEW 32 loops use under round-to-nearest-even: gfx950 build against
+    the reference's SoftFloat, results and flags, and the share the FP unit took."""
+    if not rvoracle.has_softfloat():
+        pytest.skip("oracle/_ref/libsoftfloat_ref.so not built")
+    a, b, c = _operands(False, 60000, 27)
+    rng = random.Random(15)
+    for _ in range(120000):
+        a.append(_rand32_ordinary(rng)); b.append(_rand32_ordinary(rng)); c.append(_rand32_ordinary(rng))
+    prod, _ = _ref(2, 0, a, b, c)
+    sign = 1 << 31
+    cfma = [((p ^ sign) + rng.randrange(5) - 2) & 0xffffffff if i % 3 == 0 else z for i, (p, z) in enumerate(zip(prod, c))]
+    adiv = [p if i % 2 else x for i, (p, x) in enumerate(zip(prod, a))]
+    ints = [rng.getrandbits(32) >> rng.randrange(32) if i % 2 else (-(rng.getrandbits(31) >> rng.randrange(31))) & 0xffffffff for i in range(len(a))]
+    bad, total, hw = [], 0, 0
+    for op in (0, 1, 2, 3, 5, 10, 11):
+        aa = adiv if op == 3 else a
+        cc = cfma if op == 5 else ints if op >= 10 else c
+        got, gfl = W.sf_eval(0x200 | op, 0, aa, b, cc)
+        exp, efl = _ref(op, 0, aa, b, cc)
+        total += len(a)
+        for i in range(len(a)):
+            hw += gfl[i] >> 31
+            if got[i] != exp[i] or (gfl[i] & 0x7fffffff) != efl[i]:
+                bad.append((op, hex(aa[i]), hex(b[i]), hex(cc[i]), hex(got[i]), hex(gfl[i]), hex(exp[i]), efl[i]))
+    assert not bad, f"{len(bad)} of {total} cases differ; first: {bad[:5]}"
+    assert hw > total // 2, (hw, total)
+    print(f"{total} cases bit-exact, {hw} on the FP unit")

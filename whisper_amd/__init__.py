@@ -64,18 +64,10 @@ def build(force=False):
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     # -structurizecfg-skip-uniform-regions: the interpreter's dispatch is a tree of wave-uniform branches; left to the
     # structurizer every level of it costs three extra scalar instructions (measured: 10.6 -> 11.9 GIPS, profiles/README.md)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-structurizecfg-skip-uniform-regions"]
-    # five translation units compiled side by side (wsp_lib.hip, WSP_STEP_PART): the four step kernels and the rest
-    objdir = os.path.join(os.path.dirname(LIB_PATH), "obj")
-    os.makedirs(objdir, exist_ok=True)
-    procs = []
-    for part in (-1, 0, 1, 2, 3):
-        obj = os.path.join(objdir, f"wsp_part{part + 1}.o")
-        procs.append((obj, subprocess.Popen(["hipcc", *flags, f"-DWSP_STEP_PART={part}", "-c", "-o", obj, SRC])))
-    for obj, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, pr.args)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, *[o for o, _ in procs]])
+    # one translation unit: the out-of-line general path dominates the device compile (~6 min) and every step kernel calls it, so
+    # compiling the four kernels side by side repeats it four times (tried: no gain)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                           "-mllvm", "-structurizecfg-skip-uniform-regions", "-o", LIB_PATH, SRC])
     return LIB_PATH
 
 

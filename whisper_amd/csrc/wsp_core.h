@@ -1340,9 +1340,12 @@ template <class MEM, bool DRY = false> struct Lane {
               : op == OP_FDIV ? f_div<F64>(x, y, rm, fl) : f_sqrt<F64>(x, rm, fl);
           wf(rd, z);
         } else {
-          u64 x = rf_s(rs1), y = rf_s(rs2);
-          u64 z = op == OP_FADD ? f_add<F32>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F32>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F32>(x, y, rm, fl)
-                : op == OP_FDIV ? f_div<F32>(x, y, rm, fl) : f_sqrt<F32>(x, rm, fl);
+          u64 x = rf_s(rs1), y = rf_s(rs2), z = 0;
+          const bool hw = rm == RM_RNE && (op == OP_FADD ? hw_add32(x, y, z, fl) : op == OP_FSUB ? hw_add32(x, y ^ F32::SIGN, z, fl)
+                                           : op == OP_FMUL ? hw_mul32(x, y, z, fl) : op == OP_FDIV ? hw_div32(x, y, z, fl) : false);
+          if (!hw)
+            z = op == OP_FADD ? f_add<F32>(x, y, rm, fl) : op == OP_FSUB ? f_sub<F32>(x, y, rm, fl) : op == OP_FMUL ? f_mul<F32>(x, y, rm, fl)
+              : op == OP_FDIV ? f_div<F32>(x, y, rm, fl) : f_sqrt<F32>(x, rm, fl);
           wf_s(rd, (u32)z);
         }
         or_fflags(fl); mark_fs_dirty(); return; }
@@ -1513,6 +1516,44 @@ template <class MEM, bool DRY = false> struct Lane {
     if (masked && !v_mask_bit(ix)) { if (c.ma) val = ones_of(esz); return false; }
     return true;
   }
+  // Element loops with the element width (and where it pays the operation) as compile-time constants: the loop body is a
+  // handful of instructions instead of a switch per element (tools/vbench.py: a vadd.vv at e32 / LMUL 8 took 0.5 us per
+  // element of a sub-group lane).  esz_switch calls f with K<esz>; v_each is one pass over the destination elements of an
+  // elementwise instruction, split over the sub-group (lane vsub takes elements vsub, vsub + vgrp, ...): body(ix) is the value
+  // of an active element; tail and masked-off elements become all ones under the agnostic policies and otherwise stay as they
+  // are - isDestActive (VecRegs.hpp:738-757) followed by a write of the value it returned.
+  template <u32 V> struct K { static constexpr u32 v = V; };
+  template <class F> WSP_HD static void esz_switch(u32 esz, F&& f)
+  { switch (esz) { case 0: f(K<0>()); break; case 1: f(K<1>()); break; case 2: f(K<2>()); break; default: f(K<3>()); break; } }
+  template <u32 E> WSP_HD u64 vrd_c(u32 reg, u32 ix) { return m.vld(reg * vlenb + (ix << E), E); }
+  template <u32 E> WSP_HD void vst_c(u32 reg, u32 ix, u64 v) { m.vst(reg * vlenb + (ix << E), E, v); }
+  template <u32 E, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
+  {
+    const u64 on = ones_of(E);
+    const u32 vl = c.vl < c.elem_max ? c.vl : c.elem_max;
+    if (!masked) for (u32 ix = vsub; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
+    else
+      for (u32 ix = vsub; ix < vl; ix += vgrp) {
+        if (v_mask_bit(ix)) vst_c<E>(vd, ix, body(ix) & on);
+        else if (c.ma) vst_c<E>(vd, ix, on);
+      }
+    if (c.ta) for (u32 ix = vl + (vsub + vgrp - vl % vgrp) % vgrp; ix < c.elem_max; ix += vgrp) vst_c<E>(vd, ix, on);
+  }
+  // The split pass for loops whose destination elements are not SEW wide (widening / narrowing forms): dsz = log2 of the destination
+  // element's bytes, elems = the destination's element count.  A destination group that overlaps a source group of ANOTHER element
+  // width is legal in places (the serial loop reads an element before the writes so far can reach it; lanes writing apart would
+  // not): `apart` false runs the pass unsplit, every lane of the sub-group doing all of it alike.
+  WSP_HD static bool v_apart(u32 a, u32 ga8, u32 b, u32 gb8)
+  { const u32 ga = ga8 >= 8 ? ga8 / 8 : 1, gb = gb8 >= 8 ? gb8 / 8 : 1; return a + ga <= b || b + gb <= a; }
+  template <class F> WSP_HD void v_each_w(const VCfg& c, u32 vd, u32 dsz, u32 elems, bool masked, bool apart, F&& body)
+  {
+    VCfg c2 = c; c2.elem_max = elems;
+    const u32 vsub0 = vsub, vgrp0 = vgrp;
+    if (!apart) { vsub = 0; vgrp = 1; }
+    esz_switch(dsz, [&](auto e) { constexpr u32 E = decltype(e)::v; v_each<E>(c2, vd, masked, body); });
+    vsub = vsub0; vgrp = vgrp0;
+    sub_fence();
+  }
   WSP_HD void vec_fail(const Rec& r, u64 cur_pc) { illegal(r, cur_pc); if (s.vgroup) mark_vs_dirty(); }       // postVecFail (vector.cpp:672-680)
   WSP_HD void vec_success()                                                                                   // postVecSuccess (vector.cpp:637-669)
   {
@@ -1608,6 +1649,24 @@ template <class MEM, bool DRY = false> struct Lane {
   }
   // the address checks of a vector memory instruction have no side effects: bare translation (the TLB model is order dependent)
   WSP_HD bool v_ldst_pure() { return !(ext(ISA_S) && eff_priv() != PRV_M && (m.cold(CI_SATP) >> 60) != 0); }
+  // [lo, lo + n) is ordinary memory for a vector load (need 1) / store (need 2) of esz-byte elements: inside the arena, element
+  // aligned, no translation (the caller checked v_ldst_pure), one PMP verdict for every byte that allows the access, and - what
+  // the per-element loops treat apart - clear of tohost (a load of it reads 0; a store near it is a host call) and, for stores,
+  // of the code image (HF_CODE_DIRTY).  Then no element can fault and every element is a plain arena access.
+  WSP_HD bool v_plain_range(u64 lo, u64 n, u32 esz, u32 need, bool store)
+  {
+    if ((lo & (esz - 1)) || n == 0 || !in_mem(lo, n)) return false;
+    const u32 pm = eff_priv();
+    u32 perm;
+    if (!(h.flags & HF_PMP_ON) || (pm == PRV_M && !(h.flags & HF_PMP_MLOCK))) perm = pm == PRV_M ? 7u : 0u;
+    else if (h.flags & HF_PMP_E0ALL) { const u32 cfg = (u32)m.cold(CI_PMPCFG0) & 0xff; perm = (pm == PRV_M && !(cfg & 0x80)) ? 7u : (cfg & 7u); }
+    else return false;
+    if (!(perm & need)) return false;
+    const u64 hi = lo + n;                               // exclusive; no wrap: in_mem
+    if (tohost != ~0ULL && lo < tohost + 16 && tohost < hi + 8) return false;
+    if (store && lo < text_hi && text_lo < hi) return false;
+    return true;
+  }
   WSP_HD void v_load_unit(const Rec& r, u64 base, u64 stride_reg, u64 cur_pc, u32 eew, bool strided, bool mask_ls = false)
   {
     VCfg c = vcfg();
@@ -1626,6 +1685,22 @@ template <class MEM, bool DRY = false> struct Lane {
       // lanes.  Pass 1 finds the first element that faults (the checks have no side effect without paging), pass 2 loads the
       // elements before it, then every lane takes that element's trap: what the serial loop leaves behind.
       if (start < c.vl) {
+        if (!strided && v_plain_range(base + (u64)start * esz, (u64)(c.vl - start) * esz, esz, 1, false)) {
+          // every element lies in ordinary memory the hart may read, aligned: no element can fault, none is special
+          v_note_write(gx8);
+          const u64 off0 = base - mem_base;
+          auto run = [&](auto e) { constexpr u32 E = decltype(e)::v;
+            const u64 on = ones_of(E);
+            for (u32 ix = start + vsub; ix < elem_max; ix += vgrp) {
+              if (ix >= c.vl) { if (c.ta) vst_c<E>(vd, ix, on); }
+              else if (masked && !v_mask_bit(ix)) { if (c.ma) vst_c<E>(vd, ix, on); }
+              else vst_c<E>(vd, ix, mem_read(off0 + ((u64)ix << E), 1u << E));
+            } };
+          esz_switch(eew, run);
+          sub_fence();
+          vec_success();
+          return;
+        }
         u32 first = ~0u;
         for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
           if (masked && !v_mask_bit(ix)) continue;
@@ -1685,6 +1760,18 @@ template <class MEM, bool DRY = false> struct Lane {
     if ((vgrp > 1 || dry) && v_ldst_pure() && astride >= esz) {
       // lanes, as in v_load_unit; an element that lands in the code image or on tohost has side effects on hart state beyond
       // memory (v_store_elem): any such element sends the instruction through the serial loop below, on every lane alike.
+      if (!strided && start < c.vl && v_plain_range(base + (u64)start * esz, (u64)(c.vl - start) * esz, esz, 2, true)) {
+        const u64 off0 = base - mem_base;
+        auto run = [&](auto e) { constexpr u32 E = decltype(e)::v;
+          for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
+            if (masked && !v_mask_bit(ix)) continue;
+            mem_write(off0 + ((u64)ix << E), 1u << E, vrd_c<E>(vd, ix));
+          } };
+        esz_switch(eew, run);
+        sub_fence();
+        vec_success();
+        return;
+      }
       u32 first = ~0u, special = 0;
       for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
         if (masked && !v_mask_bit(ix)) continue;
@@ -1910,11 +1997,18 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
     if (0 < c.vl) {
       v_note_write(dg);
-      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = vi_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
-        vwr(vd, ix, c.esz, dg, d);
-      }
+      const bool vv = kind == 0;
+      esz_switch(c.esz, [&](auto e) {                                           // lanes
+        constexpr u32 E = decltype(e)::v;
+#define WSP_VI_CASE(OP) case OP: v_each<E>(c, vd, masked, [&](u32 ix) { return vi_op(OP, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
+        switch (DRY ? op : ~0u) {                                               // (the general path's copy keeps the one generic loop)
+          WSP_VI_CASE(VI_ADD) WSP_VI_CASE(VI_SUB) WSP_VI_CASE(VI_RSUB) WSP_VI_CASE(VI_AND) WSP_VI_CASE(VI_OR) WSP_VI_CASE(VI_XOR)
+          WSP_VI_CASE(VI_SLL) WSP_VI_CASE(VI_SRL) WSP_VI_CASE(VI_SRA) WSP_VI_CASE(VI_MINU) WSP_VI_CASE(VI_MIN) WSP_VI_CASE(VI_MAXU)
+          WSP_VI_CASE(VI_MAX) WSP_VI_CASE(VI_MUL)
+          default: v_each<E>(c, vd, masked, [&](u32 ix) { return vi_op(op, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
+        }
+#undef WSP_VI_CASE
+      });
       sub_fence();
     }
     vec_success();
@@ -1929,14 +2023,13 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
     if (0 < c.vl) {
       v_note_write(dg);
-      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
-          const u64 e1 = vx ? xs : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz), dd = vrd(vd, ix, c.esz);
-          d = (k == 0 ? e1 * e2 + dd : k == 1 ? dd - e1 * e2 : k == 2 ? e1 * dd + e2 : e2 - e1 * dd) & ones_of(c.esz);
-        }
-        vwr(vd, ix, c.esz, dg, d);
-      }
+      esz_switch(c.esz, [&](auto e) {                                           // lanes
+        constexpr u32 E = decltype(e)::v;
+        v_each<E>(c, vd, masked, [&](u32 ix) {
+          const u64 e1 = vx ? xs : vrd_c<E>(vs1, ix), e2 = vrd_c<E>(vs2, ix), dd = vrd_c<E>(vd, ix);
+          return k == 0 ? e1 * e2 + dd : k == 1 ? dd - e1 * e2 : k == 2 ? e1 * dd + e2 : e2 - e1 * dd;
+        });
+      });
       sub_fence();
     }
     vec_success();
@@ -1950,25 +2043,24 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
     if (vm) {
       if (!v_check_emul(r, cur_pc, dg, vd, kind == 0 ? vs1 : 0, 0)) return;
-      if (0 < c.vl)
-        for (u32 ix = 0; ix < c.elem_max; ++ix) {
-          u64 d;
-          if (v_dest_active(c, vd, ix, c.esz, false, d)) d = (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & ones_of(c.esz);
-          vwr(vd, ix, c.esz, dg, d);
-        }
+      if (0 < c.vl) {
+        v_note_write(dg);
+        esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v;       // lanes
+          v_each<E>(c, vd, false, [&](u32 ix) { return kind == 0 ? vrd_c<E>(vs1, ix) : scalar; }); });
+        sub_fence();
+      }
       if (s.vgroup == 0) { s.vgroup = dg / 8; s.chg |= CH_VREG; }               // touchReg (vector.cpp:8150)
       vec_success();
       return;
     }
     if (vd == 0 || vs2 == 0 || (kind == 0 && vs1 == 0)) { vec_fail(r, cur_pc); return; }
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, kind == 0 ? vs1 : 0)) return;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, false, d))
-          d = (v_mask_bit(ix) ? (kind == 0 ? vrd(vs1, ix, c.esz) : scalar) : vrd(vs2, ix, c.esz)) & ones_of(c.esz);
-        vwr(vd, ix, c.esz, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v;         // lanes (v0 is neither vd nor a source here)
+        v_each<E>(c, vd, false, [&](u32 ix) { return v_mask_bit(ix) ? (kind == 0 ? vrd_c<E>(vs1, ix) : scalar) : vrd_c<E>(vs2, ix); }); });
+      sub_fence();
+    }
     vec_success();
   }
   // reduction prologue shared by the integer and FP sums (checkRedOpVsEmul, vector.cpp:222-258)
@@ -1993,7 +2085,23 @@ template <class MEM, bool DRY = false> struct Lane {
     if (c.vl == 0) return;                                                      // no postVecSuccess (:3733-3734)
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     u64 res = vrd(vs1, 0, c.esz);
-    for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vi_op(op, res, vrd(vs2, ix, c.esz), c.esz); }
+    if (vgrp > 1) {
+      // lanes: sum / and / or / xor / min / max are associative and commutative on the wrapped element values, so every lane
+      // folds the elements it owns and the partial results meet in a butterfly over the sub-group (all lanes end with the total)
+      u64 part = 0; u32 have = 0;
+      for (u32 ix = vsub; ix < c.vl; ix += vgrp) {
+        if (masked && !v_mask_bit(ix)) continue;
+        const u64 x = vrd(vs2, ix, c.esz);
+        part = have ? vi_op(op, part, x, c.esz) : x; have = 1;
+      }
+      for (u32 st = 0; (vgrp >> st) > 1; ++st) {
+        const u64 op2 = m.xlane_xchg64(part, st); const u32 h2 = (u32)m.xlane_xchg64(have, st);
+        if (h2) { part = have ? vi_op(op, part, op2, c.esz) : op2; have = 1; }
+      }
+      if (have) res = vi_op(op, res, part, c.esz);
+      sub_fence();                                                              // every lane has read vs1 / vs2 before vd changes
+    } else
+      for (u32 ix = 0; ix < c.vl; ++ix) { if (masked && !v_mask_bit(ix)) continue; res = vi_op(op, res, vrd(vs2, ix, c.esz), c.esz); }
     v_red_finish(c, vd, res);
     vec_success();
   }
@@ -2041,17 +2149,16 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dsz = c.esz + 1, vlmax = c.gx8 * vlenb / (8u << c.esz), single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
     if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, vx ? 2 : 3, vd, true, vs2, wide_src, vs1, false, op == 3)) return;
     const u32 dg = wg < 8 ? 8 : wg, sh = 64 - (8u << c.esz);
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < elems; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, dsz, masked, d)) {
-          const u64 a = wide_src ? vrd(vs2, ix, dsz) : sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
-          const u64 braw = vx ? (xs & ones_of(c.esz)) : vrd(vs1, ix, c.esz);
-          const u64 b = sb ? (u64)((i64)(braw << sh) >> sh) : braw;
-          d = (op == 0 ? a + b : op == 1 ? a - b : op == 2 ? a * b : vrd(vd, ix, dsz) + a * b) & ones_of(dsz);   // op 3: vwmacc family (vector.cpp:5686-6170)
-        }
-        vwr(vd, ix, dsz, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      const bool apart = (wide_src || v_apart(vd, wg, vs2, c.gx8)) && (vx || v_apart(vd, wg, vs1, c.gx8));
+      v_each_w(c, vd, dsz, elems, masked, apart, [&](u32 ix) -> u64 {             // lanes
+        const u64 a = wide_src ? vrd(vs2, ix, dsz) : sa ? (u64)vrd_s(vs2, ix, c.esz) : vrd(vs2, ix, c.esz);
+        const u64 braw = vx ? (xs & ones_of(c.esz)) : vrd(vs1, ix, c.esz);
+        const u64 b = sb ? (u64)((i64)(braw << sh) >> sh) : braw;
+        return op == 0 ? a + b : op == 1 ? a - b : op == 2 ? a * b : vrd(vd, ix, dsz) + a * b;   // op 3: vwmacc family (vector.cpp:5686-6170)
+      });
+    }
     vec_success();
   }
   // narrowing shifts vnsrl / vnsra .wv / .wx / .wi (vector.cpp:3013-3300): vs2 is 2 * SEW wide, shift amount mod 2 * SEW
@@ -2063,15 +2170,13 @@ template <class MEM, bool DRY = false> struct Lane {
     if (c.gx8 * 2 > 64 || c.esz > 2) { vec_fail(r, cur_pc); return; }
     if (!v_check_ops_wide(r, cur_pc, c.gx8, c.esz, kind == 0 ? 3 : 2, vd, false, vs2, true, vs1, false)) return;
     const u32 dg = c.gx8 < 8 ? 8 : c.gx8, wbits = 16u << c.esz;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
-          const u32 amt = (u32)((kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & (wbits - 1));
-          d = (arith ? (u64)(vrd_s(vs2, ix, c.esz + 1) >> amt) : vrd(vs2, ix, c.esz + 1) >> amt) & ones_of(c.esz);
-        }
-        vwr(vd, ix, c.esz, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      v_each_w(c, vd, c.esz, c.elem_max, masked, v_apart(vd, c.gx8, vs2, c.gx8 * 2), [&](u32 ix) -> u64 {   // lanes
+        const u32 amt = (u32)((kind == 0 ? vrd(vs1, ix, c.esz) : scalar) & (wbits - 1));
+        return arith ? (u64)(vrd_s(vs2, ix, c.esz + 1) >> amt) : vrd(vs2, ix, c.esz + 1) >> amt;
+      });
+    }
     vec_success();
   }
   // ---- integer compares into a mask register (vector.cpp:1985-2800) and mask logicals (vector-mask.cpp:14-120)
@@ -2106,19 +2211,50 @@ template <class MEM, bool DRY = false> struct Lane {
     if (!ok) vec_fail(r, cur_pc);
     return ok;
   }
+  // The destination of a mask-producing compare, one BYTE (eight elements) at a time, the bytes split over the sub-group: lane
+  // vsub builds bytes vsub, vsub + vgrp, ... - no two lanes touch one byte.  flag(ix) is the compare of an active element;
+  // masked-off bits stay or become 1 (isMaskDestActive, VecRegs.hpp:762-780), bits from vl to the end of the register become 1
+  // (finishMaskDest, VecRegs.hpp:639-646).  Only for a destination that is not also a source (the serial loop reads an element
+  // before the bits written so far can reach it; lanes writing bytes of a source register would not).  vl > 0.
+  template <class F> WSP_HD void v_mask_dest_bytes(const VCfg& c, u32 vd, bool masked, F&& flag)
+  {
+    for (u32 j = vsub; j < vlenb; j += vgrp) {
+      const u32 o = vd * vlenb + j, i0 = 8 * j;
+      u32 byte = 0xff;
+      if (i0 < c.vl) {
+        byte = (u32)m.vld(o, 0);
+        const u32 mk = masked ? (u32)m.vld(j, 0) : 0xffu;                        // v0's bits for these elements
+        for (u32 b = 0; b < 8; ++b) {
+          const u32 ix = i0 + b, bit = 1u << b;
+          if (ix >= c.vl) byte |= bit;
+          else if (!(mk & bit)) { if (c.ma) byte |= bit; }
+          else byte = flag(ix) ? (byte | bit) : (byte & ~bit);
+        }
+      }
+      m.vst(o, 0, byte);
+    }
+    if (s.vgroup == 0) { s.vgroup = 1; s.chg |= CH_VREG; }
+    sub_fence();
+  }
   WSP_HD void v_int_compare(const Rec& r, u64 cur_pc, u32 op, u32 kind, u64 scalar)
   {
     const VCfg c = vcfg();
     if (!v_check_mask_inst(c, r, cur_pc, kind == 0)) return;
     const u32 inst = r.raw, vd = (inst >> 7) & 31, vs1 = (inst >> 15) & 31, vs2 = (inst >> 20) & 31; const bool masked = !((inst >> 25) & 1);
     if (0 < c.vl) {
-      for (u32 ix = 0; ix < c.vl; ++ix) {                                       // isMaskDestActive (VecRegs.hpp:762-780)
-        bool flag = v_rd_mask_bit(vd, ix);
-        if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
-        else flag = vc_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
-        v_wr_mask_bit(vd, ix, flag);
+      if (vd != vs2 && !(kind == 0 && vd == vs1)) {                             // lanes
+        const bool vv = kind == 0;
+        esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v;
+          v_mask_dest_bytes(c, vd, masked, [&](u32 ix) { return vc_op(op, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); });
+      } else {
+        for (u32 ix = 0; ix < c.vl; ++ix) {                                     // isMaskDestActive (VecRegs.hpp:762-780)
+          bool flag = v_rd_mask_bit(vd, ix);
+          if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
+          else flag = vc_op(op, vrd(vs2, ix, c.esz), kind == 0 ? vrd(vs1, ix, c.esz) : scalar, c.esz);
+          v_wr_mask_bit(vd, ix, flag);
+        }
+        for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);  // finishMaskDest (VecRegs.hpp:639-646)
       }
-      for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);    // finishMaskDest (VecRegs.hpp:639-646)
     }
     vec_success();
   }
@@ -2218,12 +2354,11 @@ template <class MEM, bool DRY = false> struct Lane {
     if (from == 0 || (vd % eg) || (eg > factor && (vs2 % (eg / factor))) || !v_overlap_ok(vd, 8u << c.esz, c.gx8, vs2, (8u << c.esz) / factor, from) ||
         c.esz < lf) { vec_fail(r, cur_pc); return; }
     const u32 ssz = c.esz - lf, dg = c.gx8 < 8 ? 8 : c.gx8;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) d = (sign ? (u64)vrd_s(vs2, ix, ssz) : vrd(vs2, ix, ssz)) & ones_of(c.esz);
-        vwr(vd, ix, c.esz, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      v_each_w(c, vd, c.esz, c.elem_max, masked, v_apart(vd, c.gx8, vs2, from), [&](u32 ix) -> u64 {       // lanes
+        return sign ? (u64)vrd_s(vs2, ix, ssz) : vrd(vs2, ix, ssz); });
+    }
     vec_success();
   }
   // ---- permutation: vrgather .vv / .vx / .vi (vector.cpp:3302-3507), vslideup / vslidedown .vx / .vi, vslide1up / vslide1down .vx (:3968-4310)
@@ -2476,6 +2611,12 @@ template <class MEM, bool DRY = false> struct Lane {
   {
     using namespace wsf;
     if (op == 4 || op == 5) { const u64 t = a; a = b; b = t; op = op == 4 ? 1 : 3; }
+    if (rm == RM_RNE) {                                  // ordinary operands: the FP unit's result with the exact inexact flag (wsp_softfloat.h)
+      u64 z = 0; bool hw;
+      if (esz == 2) hw = op == 0 ? hw_add32(a, b, z, fl) : op == 1 ? hw_add32(a, b ^ F32::SIGN, z, fl) : op == 2 ? hw_mul32(a, b, z, fl) : hw_div32(a, b, z, fl);
+      else hw = op == 0 ? hw_add64(a, b, z, fl) : op == 1 ? hw_add64(a, b ^ F64::SIGN, z, fl) : op == 2 ? hw_mul64(a, b, z, fl) : hw_div64(a, b, z, fl);
+      if (hw) return z;
+    }
     if (esz == 2) return op == 0 ? f_add<F32>(a, b, rm, fl) : op == 1 ? f_sub<F32>(a, b, rm, fl) : op == 2 ? f_mul<F32>(a, b, rm, fl) : f_div<F32>(a, b, rm, fl);
     return op == 0 ? f_add<F64>(a, b, rm, fl) : op == 1 ? f_sub<F64>(a, b, rm, fl) : op == 2 ? f_mul<F64>(a, b, rm, fl) : f_div<F64>(a, b, rm, fl);
   }
@@ -2507,28 +2648,33 @@ template <class MEM, bool DRY = false> struct Lane {
     unsigned fl = 0;
     if (0 < c.vl) {
       v_note_write(dg);
-      for (u32 ix = vsub; ix < c.elem_max; ix += vgrp) {                        // lanes
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
-          u64 e1 = vf ? sc : vrd(vs1, ix, c.esz), e2 = vrd(vs2, ix, c.esz);
-          if (op < 8) d = vf_op(op, e2, e1, c.esz, rm, fl);
-          else if (op < 16) {
+      auto run = [&](auto e) {                                                  // lanes
+        constexpr u32 E = decltype(e)::v; constexpr bool w = E == 2;
+        // a * b + c3 with one rounding: the FP unit where it applies (round to nearest even, ordinary operands)
+        auto fma = [&](u64 a, u64 b, u64 c3) -> u64 {
+          u64 z = 0;
+          if (rm == RM_RNE && (w ? hw_fma32(a, b, c3, z, fl) : hw_fma64(a, b, c3, z, fl))) return z;
+          return w ? f_fma<F32>(a, b, c3, rm, fl) : f_fma<F64>(a, b, c3, rm, fl);
+        };
+        v_each<E>(c, vd, masked, [&](u32 ix) -> u64 {
+          u64 e1 = vf ? sc : vrd_c<E>(vs1, ix), e2 = vrd_c<E>(vs2, ix);
+          if (op < 8) return vf_op(op, e2, e1, E, rm, fl);
+          if (op < 16) {
             const u32 k = op - 8;
-            u64 dd = vrd(vd, ix, c.esz);
+            u64 dd = vrd_c<E>(vd, ix);
             if (k & 1) e1 = w ? fneg<F32>(e1, fl) : fneg<F64>(e1, fl);
             if (k < 4) {                                                         // *madd / *msub: vd is a multiplicand, vs2 the addend
               if (k == 1 || k == 2) e2 = w ? fneg<F32>(e2, fl) : fneg<F64>(e2, fl);
-              d = w ? f_fma<F32>(e1, dd, e2, rm, fl) : f_fma<F64>(e1, dd, e2, rm, fl);
-            } else {                                                             // *macc / *msac: vd is the addend
-              if (k == 5 || k == 6) dd = w ? fneg<F32>(dd, fl) : fneg<F64>(dd, fl);
-              d = w ? f_fma<F32>(e1, e2, dd, rm, fl) : f_fma<F64>(e1, e2, dd, rm, fl);
+              return fma(e1, dd, e2);
             }
+            if (k == 5 || k == 6) dd = w ? fneg<F32>(dd, fl) : fneg<F64>(dd, fl);   // *macc / *msac: vd is the addend
+            return fma(e1, e2, dd);
           }
-          else if (op < 18) d = w ? vf_minmax<F32>(op == 17, e2, e1, fl) : vf_minmax<F64>(op == 17, e2, e1, fl);
-          else d = (e2 & ~sign) | ((op == 18 ? e1 : op == 19 ? ~e1 : e2 ^ e1) & sign);
-        }
-        vwr(vd, ix, c.esz, dg, d);
-      }
+          if (op < 18) return w ? vf_minmax<F32>(op == 17, e2, e1, fl) : vf_minmax<F64>(op == 17, e2, e1, fl);
+          return (e2 & ~sign) | ((op == 18 ? e1 : op == 19 ? ~e1 : e2 ^ e1) & sign);
+        });
+      };
+      if (w) run(K<2>()); else run(K<3>());
       sub_fence();
     }
     or_fflags(sub_or(fl));                                                      // updateAccruedFpBits: flags accumulate over all elements
@@ -2545,24 +2691,25 @@ template <class MEM, bool DRY = false> struct Lane {
     const u64 sc = vf ? vf_scalar(vs1, c.esz) : 0;
     const bool w = c.esz == 2;
     unsigned fl = 0;
+    auto cmp = [&](u32 ix) -> bool {
+      const u64 a = vrd(vs2, ix, c.esz), b = vf ? sc : vrd(vs1, ix, c.esz);
+      const bool nan = w ? (is_nan<F32>(a) || is_nan<F32>(b)) : (is_nan<F64>(a) || is_nan<F64>(b));
+      const bool sn = w ? (is_snan<F32>(a) || is_snan<F32>(b)) : (is_snan<F64>(a) || is_snan<F64>(b));
+      if (nan) { if (sn || (op != 0 && op != 3)) fl |= FL_NV; return op == 3; }
+      const bool lt = w ? lt_ord<F32>(a, b) : lt_ord<F64>(a, b), eq = w ? eq_ord<F32>(a, b) : eq_ord<F64>(a, b);
+      return op == 0 ? eq : op == 1 ? (lt || eq) : op == 2 ? lt : op == 3 ? !eq : op == 4 ? (!lt && !eq) : !lt;
+    };
     if (0 < c.vl) {
-      for (u32 ix = 0; ix < c.vl; ++ix) {
-        bool flag = v_rd_mask_bit(vd, ix);
-        if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
-        else {
-          const u64 a = vrd(vs2, ix, c.esz), b = vf ? sc : vrd(vs1, ix, c.esz);
-          const bool nan = w ? (is_nan<F32>(a) || is_nan<F32>(b)) : (is_nan<F64>(a) || is_nan<F64>(b));
-          const bool sn = w ? (is_snan<F32>(a) || is_snan<F32>(b)) : (is_snan<F64>(a) || is_snan<F64>(b));
-          flag = op == 3;
-          if (nan) { if (sn || (op != 0 && op != 3)) fl |= FL_NV; }
-          else {
-            const bool lt = w ? lt_ord<F32>(a, b) : lt_ord<F64>(a, b), eq = w ? eq_ord<F32>(a, b) : eq_ord<F64>(a, b);
-            flag = op == 0 ? eq : op == 1 ? (lt || eq) : op == 2 ? lt : op == 3 ? !eq : op == 4 ? (!lt && !eq) : !lt;
-          }
+      if (vd != vs2 && !(!vf && vd == vs1)) { v_mask_dest_bytes(c, vd, masked, cmp); fl = sub_or(fl); }   // lanes
+      else {
+        for (u32 ix = 0; ix < c.vl; ++ix) {
+          bool flag = v_rd_mask_bit(vd, ix);
+          if (masked && !v_mask_bit(ix)) { if (c.ma) flag = true; }
+          else flag = cmp(ix);
+          v_wr_mask_bit(vd, ix, flag);
         }
-        v_wr_mask_bit(vd, ix, flag);
+        for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);
       }
-      for (u32 ix = c.vl; ix < vlenb * 8; ++ix) v_wr_mask_bit(vd, ix, true);
     }
     or_fflags(fl);
     vec_success();
@@ -2607,19 +2754,26 @@ template <class MEM, bool DRY = false> struct Lane {
     const bool w = c.esz == 2;
     if (op == 5 || op == 6) rm = RM_RTZ;
     unsigned fl = 0;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, c.esz, masked, d)) {
-          const u64 a = vrd(vs2, ix, c.esz);
-          if (op >= 7) d = v_est7(op == 8, a, c.esz, (u32)rm, fl);                 // 7 vfrsqrt7.v, 8 vfrec7.v
-          else if (op == 0) d = w ? f_sqrt<F32>(a, rm, fl) : f_sqrt<F64>(a, rm, fl);
-          else if (op == 3 || op == 4) d = w ? int_to_f<F32>(a, op == 4, false, rm, fl) : int_to_f<F64>(a, op == 4, true, rm, fl);
-          else { const bool sg = op == 2 || op == 6; d = (w ? f_to_int<F32>(a, rm, sg, false, fl) : f_to_int<F64>(a, rm, sg, true, fl)) & ones_of(c.esz); }
-        }
-        vwr(vd, ix, c.esz, dg, d);
-      }
-    or_fflags(fl);
+    if (0 < c.vl) {
+      v_note_write(dg);
+      auto run = [&](auto e) {                                                  // lanes
+        constexpr u32 E = decltype(e)::v;
+        v_each<E>(c, vd, masked, [&](u32 ix) -> u64 {
+          const u64 a = vrd_c<E>(vs2, ix);
+          if (op >= 7) return v_est7(op == 8, a, E, (u32)rm, fl);                  // 7 vfrsqrt7.v, 8 vfrec7.v
+          if (op == 0) return w ? f_sqrt<F32>(a, rm, fl) : f_sqrt<F64>(a, rm, fl);
+          if (op == 3 || op == 4) {
+            if (rm == RM_RNE) return w ? hw_int_to_f32(a, op == 4, fl) : hw_int_to_f64(a, op == 4, true, fl);
+            return w ? int_to_f<F32>(a, op == 4, false, rm, fl) : int_to_f<F64>(a, op == 4, true, rm, fl);
+          }
+          const bool sg = op == 2 || op == 6;
+          return w ? f_to_int<F32>(a, rm, sg, false, fl) : f_to_int<F64>(a, rm, sg, true, fl);
+        });
+      };
+      if (w) run(K<2>()); else run(K<3>());
+      sub_fence();
+    }
+    or_fflags(sub_or(fl));
     vec_success();
   }
   // vfmerge.vfm (vector-float.cpp:4068-4130)
@@ -2632,8 +2786,11 @@ template <class MEM, bool DRY = false> struct Lane {
     if (!v_check_emul(r, cur_pc, c.gx8, vd, vs2, 0)) return;
     if (!v_fp_legal(c.esz)) { vec_fail(r, cur_pc); return; }
     const u64 sc = vf_scalar(fs1, c.esz); const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, vd, ix, c.esz, false, d)) d = v_mask_bit(ix) ? sc : vrd(vs2, ix, c.esz); vwr(vd, ix, c.esz, dg, d); }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v; v_each<E>(c, vd, false, [&](u32 ix) { return v_mask_bit(ix) ? sc : vrd_c<E>(vs2, ix); }); });   // lanes
+      sub_fence();
+    }
     vec_success();
   }
   WSP_HD void v_fp_redsum(const Rec& r, u64 cur_pc, u32 op)                             // vfredusum / vfredosum (:6756-6990): sequential at the defaults
@@ -2673,22 +2830,21 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 vlmax = c.gx8 * vlenb / 32, single = vlenb >> 3, elems = vlmax > single ? vlmax : single, dg = wg < 8 ? 8 : wg;
     const u64 sc = vf ? vf_scalar(vs1, 2) : 0;
     unsigned fl = 0;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < elems; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, 3, masked, d)) {
-          u64 e1 = f32_to_f64(vf ? sc : vrd(vs1, ix, 2), fl);
-          const u64 e2 = wide_src ? vrd(vs2, ix, 3) : f32_to_f64(vrd(vs2, ix, 2), fl);
-          if (op < 8) d = vf_op(op, e2, e1, 3, rm, fl);
-          else {
-            const u32 k = op - 8; u64 dd = vrd(vd, ix, 3);
-            if (k & 1) e1 = fneg<F64>(e1, fl);
-            if (k == 5 || k == 6) dd = fneg<F64>(dd, fl);
-            d = f_fma<F64>(e1, e2, dd, rm, fl);
-          }
-        }
-        vwr(vd, ix, 3, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      const bool apart = (wide_src || v_apart(vd, wg, vs2, c.gx8)) && (vf || v_apart(vd, wg, vs1, c.gx8));
+      v_each_w(c, vd, 3, elems, masked, apart, [&](u32 ix) -> u64 {             // lanes
+        u64 e1 = f32_to_f64(vf ? sc : vrd(vs1, ix, 2), fl);
+        const u64 e2 = wide_src ? vrd(vs2, ix, 3) : f32_to_f64(vrd(vs2, ix, 2), fl);
+        if (op < 8) return vf_op(op, e2, e1, 3, rm, fl);
+        const u32 k = op - 8; u64 dd = vrd(vd, ix, 3), z = 0;
+        if (k & 1) e1 = fneg<F64>(e1, fl);
+        if (k == 5 || k == 6) dd = fneg<F64>(dd, fl);
+        if (rm == RM_RNE && hw_fma64(e1, e2, dd, z, fl)) return z;
+        return f_fma<F64>(e1, e2, dd, rm, fl);
+      });
+      fl = sub_or(fl);
+    }
     or_fflags(fl);
     vec_success();
   }
@@ -2706,12 +2862,12 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dsz = narrow ? 2 : 3, vlmax = c.gx8 * vlenb / 32, single = vlenb >> dsz, elems = vlmax > single ? vlmax : single;
     const u32 dg8 = narrow ? c.gx8 : wg, dg = dg8 < 8 ? 8 : dg8;
     unsigned fl = 0;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < elems; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, dsz, masked, d)) d = narrow ? f64_to_f32(vrd(vs2, ix, 3), rm, fl) : f32_to_f64(vrd(vs2, ix, 2), fl);
-        vwr(vd, ix, dsz, dg, d);
-      }
+    if (0 < c.vl) {
+      v_note_write(dg);
+      v_each_w(c, vd, dsz, elems, masked, v_apart(vd, dg8, vs2, narrow ? wg : c.gx8), [&](u32 ix) -> u64 {   // lanes
+        return narrow ? f64_to_f32(vrd(vs2, ix, 3), rm, fl) : f32_to_f64(vrd(vs2, ix, 2), fl); });
+      fl = sub_or(fl);
+    }
     or_fflags(fl);
     vec_success();
   }
@@ -2770,28 +2926,28 @@ template <class MEM, bool DRY = false> struct Lane {
     const u32 dg8 = narrow ? c.gx8 : wg, dg = dg8 < 8 ? 8 : dg8;
     if (rtz) rm = RM_RTZ;
     unsigned fl = 0;
-    if (0 < c.vl)
-      for (u32 ix = 0; ix < elems; ++ix) {
-        u64 d;
-        if (v_dest_active(c, vd, ix, dsz, masked, d)) {
-          const u64 a = vrd(vs2, ix, ssz);
-          if (to_int) {
-            if (ssz == 2 && dsz == 3) d = f_to_int<F32>(a, rm, sg, true, fl);
-            else if (ssz == 3) d = f_to_int<F64>(a, rm, sg, false, fl) & 0xffffffffull;
-            else {                                                              // f32 -> 16 bits through the 32-bit conversion (float-util.hpp:309-327)
-              unsigned f2 = 0; const u64 v = f_to_int<F32>(a, rm, sg, false, f2);
-              if (sg) { i64 t = (i64)(i32)v; if (t > 32767) { t = 32767; f2 = FL_NV; } else if (t < -32768) { t = -32768; f2 = FL_NV; } d = (u64)t & 0xffff; }
-              else { u64 t = v & 0xffffffffull; if (t > 65535) { t = 65535; f2 = FL_NV; } d = t; }
-              fl |= f2;
-            }
-          } else {
-            if (ssz == 1) d = int_to_f<F32>(sg ? (u64)(i64)(int16_t)a : (a & 0xffff), sg, false, rm, fl);
-            else if (ssz == 2) d = int_to_f<F64>(a, sg, false, rm, fl);
-            else d = int_to_f<F32>(a, sg, true, rm, fl);
+    if (0 < c.vl) {
+      v_note_write(dg);
+      v_each_w(c, vd, dsz, elems, masked, v_apart(vd, dg8, vs2, narrow ? wg : c.gx8), [&](u32 ix) -> u64 {   // lanes
+        const u64 a = vrd(vs2, ix, ssz); u64 d;
+        if (to_int) {
+          if (ssz == 2 && dsz == 3) d = f_to_int<F32>(a, rm, sg, true, fl);
+          else if (ssz == 3) d = f_to_int<F64>(a, rm, sg, false, fl) & 0xffffffffull;
+          else {                                                                // f32 -> 16 bits through the 32-bit conversion (float-util.hpp:309-327)
+            unsigned f2 = 0; const u64 v = f_to_int<F32>(a, rm, sg, false, f2);
+            if (sg) { i64 t = (i64)(i32)v; if (t > 32767) { t = 32767; f2 = FL_NV; } else if (t < -32768) { t = -32768; f2 = FL_NV; } d = (u64)t & 0xffff; }
+            else { u64 t = v & 0xffffffffull; if (t > 65535) { t = 65535; f2 = FL_NV; } d = t; }
+            fl |= f2;
           }
+        } else {
+          if (ssz == 1) d = int_to_f<F32>(sg ? (u64)(i64)(int16_t)a : (a & 0xffff), sg, false, rm, fl);
+          else if (ssz == 2) d = rm == RM_RNE ? hw_int_to_f64(a, sg, false, fl) : int_to_f<F64>(a, sg, false, rm, fl);
+          else d = int_to_f<F32>(a, sg, true, rm, fl);
         }
-        vwr(vd, ix, dsz, dg, d);
-      }
+        return d;
+      });
+      fl = sub_or(fl);
+    }
     or_fflags(fl);
     vec_success();
   }
@@ -2897,7 +3053,11 @@ template <class MEM, bool DRY = false> struct Lane {
         if ((!vm && rd == 0) || rs2 != 0) { vec_fail(r, cur_pc); return; }
         if (!v_check_emul(r, cur_pc, c.gx8, rd, 0, 0)) return;
         const u32 dg = c.gx8 < 8 ? 8 : c.gx8;
-        if (0 < c.vl) for (u32 ix = 0; ix < c.elem_max; ++ix) { u64 d; if (v_dest_active(c, rd, ix, c.esz, !vm, d)) d = ix & ones_of(c.esz); vwr(rd, ix, c.esz, dg, d); }
+        if (0 < c.vl) {
+          v_note_write(dg);
+          esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v; v_each<E>(c, rd, !vm, [&](u32 ix) { return (u64)ix; }); });   // lanes
+          sub_fence();
+        }
         vec_success(); return;
       }
       if (f6 >= 0x18 && f6 <= 0x1f && !vx) { v_mask_logical(r, cur_pc, f6 - 0x18); return; }

@@ -96,6 +96,12 @@ struct DevMem {
   { for (u32 o = 1u << lpw_shift; o < 64; o <<= 1) v |= (u32)__shfl_xor((int)v, (int)o, 64); return v; }
   __device__ __forceinline__ u32 xlane_min(u32 v) const
   { for (u32 o = 1u << lpw_shift; o < 64; o <<= 1) { const u32 t = (u32)__shfl_xor((int)v, (int)o, 64); v = t < v ? t : v; } return v; }
+  // the value of the sub-group lane whose index differs in bit `stage` (a butterfly stage of a reduction over the sub-group)
+  __device__ __forceinline__ u64 xlane_xchg64(u64 v, u32 stage) const
+  {
+    const int o = (int)((1u << lpw_shift) << stage);
+    return (u64)(u32)__shfl_xor((int)(u32)v, o, 64) | ((u64)(u32)__shfl_xor((int)(u32)(v >> 32), o, 64) << 32);
+  }
   __device__ __forceinline__ void xlane_fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
   __device__ __forceinline__ u8* p(u64 off) const { return arena + (((off >> 3) << lpw_shift) << 3) + (off & 7); }
   __device__ __forceinline__ u8 ld8(u64 o) const { return *p(o); }
@@ -211,6 +217,9 @@ __device__ __forceinline__ u64 wsp_stop_at(u64 slice_end, u64 max_exec, u64 max_
 // or has run WSP_COLD_BURST steps (the other lanes of the wave wait meanwhile).
 #ifndef WSP_COLD_BURST
 #define WSP_COLD_BURST 64u
+#endif
+#ifndef WSP_HOT_QUANTUM
+#define WSP_HOT_QUANTUM 128u                             // hot-loop iterations per round while other lanes of the wave wait (step kernel)
 #endif
 // One compiled body serves traced and untraced runs (HF_NOTRACE in the lane's flags makes commit() return at once): what an
 // untraced run executes here is exactly what the traced parity tests execute.  The arguments fit the 16 argument registers (2 for
@@ -420,17 +429,28 @@ __device__ __noinline__ WarmRet wsp_vwarm(const DevState* dp, VWarmArgs va, u32 
       pend &= ~__ballot(mine);
     }
 #else
+    // the record of the sequential successor is requested before this instruction executes: its latency (a dependent trip to
+    // L2 / HBM per instruction of the burst otherwise) hides behind the element loops
+    const u64 nidx = pc + 4 - va.text_lo;
+    const bool nin = alive && nidx < (u64)text_len;
+    uint4 qn; qn.x = 0; qn.y = 0; qn.z = 0; qn.w = 0;
+    if (nin) qn = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(va.recs) + (nidx << 3));
     if (alive) WSP_VW_ONE(w0, imm, raw);
 #endif
 #undef WSP_VW_ONE
     // ---- go on while the next instruction is a vector instruction too
     if (alive && done) {
       ++n_done; pc += 4;
+#if WSP_VW_GROUP
       const u64 idx = pc - va.text_lo;
       alive = n_done < max_n && idx < (u64)text_len;
+      uint4 qn; qn.x = 0; qn.y = 0; qn.z = 0; qn.w = 0;
+      if (alive) qn = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(va.recs) + (idx << 3));
+#else
+      alive = n_done < max_n && nin;
+#endif
       if (alive) {
-        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(va.recs) + (idx << 3));
-        w0 = q.x; imm = (i32)q.y; raw = q.w;
+        w0 = qn.x; imm = (i32)qn.y; raw = qn.w;
         const u32 op = w0 & 0xff;
         alive = op >= OP_VEC && op <= OP_VST;
       }
@@ -666,9 +686,13 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
     bool need_cold = run && !can;
 
     const unsigned long long ph0 = WSP_PROF_T();
-    if (!__any(need_cold)) {
+    // The hot lanes run whenever there are any.  While other lanes of the wave wait for one of the out-of-line paths (a wave of
+    // different programs: some lane is nearly always in S / U-mode code or at a trap) the hot lanes get a quantum of
+    // WSP_HOT_QUANTUM iterations, then the other paths take their turn: every class of lane advances in every round.
+    if (__any(can)) {
       const u64 left = stop_at - L.h.exec;
-      const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu));
+      u32 n = (u32)__builtin_amdgcn_readfirstlane((int)wave_min_u32(can ? (left > 0x40000000ULL ? 0x40000000u : (u32)left) : 0xffffffffu));
+      if (__any(need_cold) && n > WSP_HOT_QUANTUM) n = WSP_HOT_QUANTUM;
       if (WSP_CONVERGED_LOOP && same_prog) {
         // ============================================================================================================
         // Converged loop (all harts of the wave share one program image).  One pc - `upc`, an SGPR - is scheduled per
@@ -849,7 +873,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
         }
 #endif
         if (can) { L.h.exec += vit; L.h.pc = tlo + vpc; }
-        need_cold = ncv != 0;
+        need_cold = need_cold || ncv != 0;
       } else if (can) {
         u32 pco = (u32)off64, it = 0;
         u32 ncv = 0;                                      // "needs the general step", as a VGPR flag (no lane-mask algebra)
@@ -1121,24 +1145,6 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   if (lane == 0 && still) atomicAdd(d.running, (u32)__popcll(still));
 }
 
-// Split build (whisper_amd.build): the four instantiations of the step kernel dominate the device compile, so the file is
-// compiled five times in parallel - WSP_STEP_PART = 0..3 keeps the text up to here and instantiates one step kernel each;
-// WSP_STEP_PART = -1 is everything else and only declares them.  Without WSP_STEP_PART the file is one translation unit
-// (profiling and A/B builds).
-#define WSP_STEP_DECL(T, F) template __global__ void wsp_step_kernel<T, F>(DevState d, const DevState* dp, u64 max_steps, u32 notrace)
-#if defined(WSP_STEP_PART) && WSP_STEP_PART == 0
-WSP_STEP_DECL(false, false);
-#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 1
-WSP_STEP_DECL(false, true);
-#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 2
-WSP_STEP_DECL(true, false);
-#elif defined(WSP_STEP_PART) && WSP_STEP_PART == 3
-WSP_STEP_DECL(true, true);
-#elif defined(WSP_STEP_PART)
-extern WSP_STEP_DECL(false, false); extern WSP_STEP_DECL(false, true); extern WSP_STEP_DECL(true, false); extern WSP_STEP_DECL(true, true);
-#endif
-
-#if !defined(WSP_STEP_PART) || WSP_STEP_PART < 0
 // ------------------------------------------------------------------------------------------ support kernels
 // Pre-decode one program image: thread i decodes the (up to) 4 bytes at byte offset 2*i.
 __global__ void wsp_predecode_kernel(const u8* img, u64 n_bytes, u32 isa, Rec* out)
@@ -1299,6 +1305,20 @@ __global__ void wsp_sf_eval_kernel(u32 op, int rm, const u64* a, const u64* b, c
       case 3: hw = hw_div64(x, y, r, fl); break;
       case 5: hw = hw_fma64(x, y, z, r, fl); break;
       case 10: case 11: case 12: case 13: r = hw_int_to_f64(z, (k - 10) & 1, ((k - 10) & 2) != 0, fl); hw = true; break;
+      default: break;
+    }
+    if (hw) { out[i] = r; flags[i] = fl | 0x80000000u; return; }
+  }
+  if ((op & 0x200) && !dbl && rm == RM_RNE) {                // the same for binary32
+    const u64 x32 = x & 0xffffffffULL, y32 = y & 0xffffffffULL, z32 = z & 0xffffffffULL;
+    bool hw = false;
+    switch (k) {
+      case 0: hw = hw_add32(x32, y32, r, fl); break;
+      case 1: hw = hw_add32(x32, y32 ^ F32::SIGN, r, fl); break;
+      case 2: hw = hw_mul32(x32, y32, r, fl); break;
+      case 3: hw = hw_div32(x32, y32, r, fl); break;
+      case 5: hw = hw_fma32(x32, y32, z32, r, fl); break;
+      case 10: case 11: r = hw_int_to_f32(z, (k - 10) & 1, fl); hw = true; break;
       default: break;
     }
     if (hw) { out[i] = r; flags[i] = fl | 0x80000000u; return; }
@@ -2553,4 +2573,3 @@ extern "C" int wsp_sf_eval(uint32_t op, uint32_t rm, const uint64_t* a, const ui
   HIPOK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(flags, dfl.p, n * 4, hipMemcpyDeviceToHost));
   return WSP_OK;
 }
-#endif  // !WSP_STEP_PART || WSP_STEP_PART < 0

@@ -506,4 +506,82 @@ WSP_HD u64 hw_int_to_f64(u64 v, bool is_signed, bool is64, unsigned& fl)        
   return hw_bits(is_signed ? (double)(i64)v : (double)v);
 }
 
+// ---- binary32 on the FP unit.  Operands and results ordinary binary32 numbers (zero or normal, result away from overflow and
+// underflow).  add / sub / mul / div are computed in binary64 and rounded once more to binary32: with 53 >= 2 * 24 + 2 significand
+// bits the second rounding is innocuous for these four operations, so the result is the correctly rounded binary32 one; inexact is
+// decided exactly (2Sum in binary64 for sums, the exact 48-bit product, the fma residual for quotients).  fma is not covered by that
+// theorem: the result is the unit's own single-rounding binary32 fma, inexact from the exact product plus a 2Sum in binary64.
+WSP_HD float hw_f32(u64 v) { const u32 w = (u32)v; float f; __builtin_memcpy(&f, &w, 4); return f; }
+WSP_HD u32 hw_bits32(float f) { u32 v; __builtin_memcpy(&v, &f, 4); return v; }
+WSP_HD bool hw_zero32(u64 a) { return !((u32)a << 1); }
+WSP_HD int hw_exp32(u64 a) { return (int)((a >> 23) & 0xff); }
+WSP_HD bool hw_ord32(u64 a) { const int e = hw_exp32(a); return hw_zero32(a) || (e >= 1 && e <= 0xfe); }
+// the binary32 result r of an operation whose exact value is v (a binary64 value standing for it): in range when it is an exact
+// zero or a normal number above the smallest binade (a value just under 2^-126 that rounds up to it is still tiny: underflow); a
+// zero or subnormal result of a non-zero value underflowed
+WSP_HD bool hw_res32_ok(u32 r, bool exact_zero) { const int e = (int)((r >> 23) & 0xff); return e == 0xff ? false : e == 0 ? (exact_zero && !(r << 1)) : e >= 2; }
+
+WSP_HD bool hw_add32(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!(hw_ord32(a) && hw_ord32(b))) return false;
+  const double x = (double)hw_f32(a), y = (double)hw_f32(b), s = x + y;
+  const double bv = s - x, av = s - bv, e = (x - av) + (y - bv);        // x + y = s + e exactly
+  const float r = (float)s;
+  const u32 rb = hw_bits32(r);
+  if (!hw_res32_ok(rb, s == 0.0 && e == 0.0)) return false;
+  z = rb; if ((double)r != s || e != 0.0) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD bool hw_mul32(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!(hw_ord32(a) && hw_ord32(b))) return false;
+  const double p = (double)hw_f32(a) * (double)hw_f32(b);               // 48 significant bits: exact
+  const float r = (float)p;
+  const u32 rb = hw_bits32(r);
+  if (!hw_res32_ok(rb, p == 0.0)) return false;
+  z = rb; if ((double)r != p) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD bool hw_div32(u64 a, u64 b, u64& z, unsigned& fl)
+{
+  WSP_FP_STRICT
+  if (!(hw_ord32(a) && hw_ord32(b)) || hw_zero32(b)) return false;
+  const double x = (double)hw_f32(a), y = (double)hw_f32(b), q = x / y;
+  const float r = (float)q;
+  const u32 rb = hw_bits32(r);
+  if (!hw_res32_ok(rb, x == 0.0)) return false;
+  z = rb; if (__builtin_fma(-(double)r, y, x) != 0.0) fl |= FL_NX;      // r * y has 48 significant bits: the residual is exact
+  return true;
+}
+
+WSP_HD bool hw_fma32(u64 a, u64 b, u64 c, u64& z, unsigned& fl)          // a * b + c
+{
+  WSP_FP_STRICT
+  if (!(hw_ord32(a) && hw_ord32(b) && hw_ord32(c))) return false;
+  const float xf = hw_f32(a), yf = hw_f32(b), wf = hw_f32(c);
+  const double p = (double)xf * (double)yf, w = (double)wf, s = p + w;  // p exact
+  const double bv = s - p, av = s - bv, e = (p - av) + (w - bv);        // p + w = s + e exactly
+  // one rounding of the exact value to binary32: through binary64 unless that lands on a binary32 tie (then the error term decides)
+  const u64 sb = hw_bits(s);
+  float r;
+  if (e == 0.0 || (sb & 0x1fffffffULL) != 0x10000000ULL) r = (float)s;  // s is not a tie, or is the exact value
+  else r = __builtin_fmaf(xf, yf, wf);
+  const u32 rb = hw_bits32(r);
+  if (!hw_res32_ok(rb, s == 0.0 && e == 0.0)) return false;
+  z = rb; if ((double)r != s || e != 0.0) fl |= FL_NX;
+  return true;
+}
+
+WSP_HD u64 hw_int_to_f32(u64 v, bool is_signed, unsigned& fl)                     // 32-bit integer -> binary32: always in the domain
+{
+  const u32 w = (u32)v;
+  const u32 mag = (is_signed && (i32)w < 0) ? 0u - w : w;
+  if (mag && (u32)((mag << __builtin_clz(mag)) << 24)) fl |= FL_NX;               // more than 24 significant bits
+  return hw_bits32(is_signed ? (float)(i32)w : (float)w);
+}
+
 }  // namespace wsf
