@@ -245,15 +245,16 @@ def _replicated(progs, reps, lanes=0, trace=True):
         b.close()
 
 
-def test_rvv_16384_harts():
-    """BASELINE config 3 size: 16384 harts (64 vector programs x 256 replicas, 64 lanes per wave).  One replica of every
-    program is checked against the oracle; the size-independent property for the rest is determinism: all replicas of a
-    program end with identical digests wherever they sit in the batch."""
-    progs = [WL.rvv_program(s) for s in range(64)]
+@pytest.mark.parametrize("vlenb", [64, 32])
+def test_rvv_16384_harts(vlenb):
+    """BASELINE config 3 size at both of its vector lengths (VLEN 512 and 256): 16384 harts (64 vector programs x 256 replicas).
+    One replica of every program is checked against the oracle; the size-independent property for the rest is determinism: all
+    replicas of a program end with identical digests wherever they sit in the batch."""
+    progs = [WL.rvv_program(s, vlenb=vlenb) for s in range(64)]
     reps = 256
     res, secs = _replicated(progs, reps)
     total = sum(r["exec"] for r in res)
-    print(f"rvv 16384 harts: {total} instructions in {secs:.3f} s = {total / secs / 1e9:.3f} GIPS")
+    print(f"rvv 16384 harts, VLEN {8 * vlenb}: {total} instructions in {secs:.3f} s = {total / secs / 1e9:.3f} GIPS")
     for i, p in enumerate(progs):
         ro, _, _ = S.run_oracle(p, hart_id=i * reps)
         assert res[i * reps] == ro, p.name

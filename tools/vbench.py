@@ -31,10 +31,13 @@ def make(kind, iters, vlenb):
     a.label("_start")
     a.li(5, 0x6600); a.csrs(CSR["mstatus"], 5)
     a.li(8, S["buf"]); a.li(9, iters); a.li(12, 3); a.li(13, 5)
-    a.fmv_d_x(1, 0); a.fmv_d_x(2, 0)
+    a.fmv_d_x(2, 0); a.li(6, 0x3FC00000); a.fmv_w_x(1, 6)     # f1 = 1.5f, NaN-boxed
     a.vsetvli(15, 0, Asm.vtype(sew, 8, ta=True, ma=True))     # rs1 = x0, rd != x0: vl = VLMAX
     a.vop(0x14, 2, 8, 0, 0x11); a.vop(0x14, 2, 16, 0, 0x11); a.vop(0x14, 2, 24, 0, 0x11)   # vid.v
     a.vop(0x1B, 4, 0, 8, 13)                                   # vmslt.vx v0, v8, x13: a mask with a few bits set
+    if kind.startswith("vf") and kind != "vfcvt":              # ordinary floating-point values (small integers), not the bit patterns of vid
+        for v in (8, 16, 24):
+            a.vop(0x12, 1, v, v, 3)                            # vfcvt.f.x.v
     a.label("loop")
     for k in range(32):
         if kind in ("vadd", "vadd_e8"): a.vop(0x00, 0, 24, 8, 16)

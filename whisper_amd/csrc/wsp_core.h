@@ -1527,12 +1527,17 @@ template <class MEM, bool DRY = false> struct Lane {
   { switch (esz) { case 0: f(K<0>()); break; case 1: f(K<1>()); break; case 2: f(K<2>()); break; default: f(K<3>()); break; } }
   template <u32 E> WSP_HD u64 vrd_c(u32 reg, u32 ix) { return m.vld(reg * vlenb + (ix << E), E); }
   template <u32 E> WSP_HD void vst_c(u32 reg, u32 ix, u64 v) { m.vst(reg * vlenb + (ix << E), E, v); }
-  template <u32 E, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
+  template <u32 E, bool UNROLL = false, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
   {
     const u64 on = ones_of(E);
     const u32 vl = c.vl < c.elem_max ? c.vl : c.elem_max;
-    if (!masked) for (u32 ix = vsub; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
-    else
+    if (!masked && UNROLL) {
+      // small bodies, unrolled: with one wave on the SIMD nothing else hides the LDS round trips of an iteration, so four go out together
+#pragma unroll 4
+      for (u32 ix = vsub; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
+    } else if (!masked) {
+      for (u32 ix = vsub; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
+    } else
       for (u32 ix = vsub; ix < vl; ix += vgrp) {
         if (v_mask_bit(ix)) vst_c<E>(vd, ix, body(ix) & on);
         else if (c.ma) vst_c<E>(vd, ix, on);
@@ -1689,9 +1694,18 @@ template <class MEM, bool DRY = false> struct Lane {
           // every element lies in ordinary memory the hart may read, aligned: no element can fault, none is special
           v_note_write(gx8);
           const u64 off0 = base - mem_base;
+          // the whole 8-byte words of an unmasked load from a word-aligned base are copied as words (the register file is
+          // byte-contiguous, the arena word-interleaved); the elements behind them one by one
+          u32 s0 = start;
+          if (!masked && start == 0 && !(off0 & 7)) {
+            const u32 nw = (u32)(((u64)c.vl << eew) >> 3);
+#pragma unroll 4
+            for (u32 wd = vsub; wd < nw; wd += vgrp) m.vst(vd * vlenb + wd * 8, 3, m.ld64(off0 + (u64)wd * 8));
+            s0 = (nw * 8) >> eew;
+          }
           auto run = [&](auto e) { constexpr u32 E = decltype(e)::v;
             const u64 on = ones_of(E);
-            for (u32 ix = start + vsub; ix < elem_max; ix += vgrp) {
+            for (u32 ix = s0 + vsub; ix < elem_max; ix += vgrp) {
               if (ix >= c.vl) { if (c.ta) vst_c<E>(vd, ix, on); }
               else if (masked && !v_mask_bit(ix)) { if (c.ma) vst_c<E>(vd, ix, on); }
               else vst_c<E>(vd, ix, mem_read(off0 + ((u64)ix << E), 1u << E));
@@ -1762,8 +1776,15 @@ template <class MEM, bool DRY = false> struct Lane {
       // memory (v_store_elem): any such element sends the instruction through the serial loop below, on every lane alike.
       if (!strided && start < c.vl && v_plain_range(base + (u64)start * esz, (u64)(c.vl - start) * esz, esz, 2, true)) {
         const u64 off0 = base - mem_base;
+        u32 s0 = start;
+        if (!masked && start == 0 && !(off0 & 7)) {          // whole words as words, as in v_load_unit
+          const u32 nw = (u32)(((u64)c.vl << eew) >> 3);
+#pragma unroll 4
+          for (u32 wd = vsub; wd < nw; wd += vgrp) m.st64(off0 + (u64)wd * 8, m.vld(vd * vlenb + wd * 8, 3));
+          s0 = (nw * 8) >> eew;
+        }
         auto run = [&](auto e) { constexpr u32 E = decltype(e)::v;
-          for (u32 ix = start + vsub; ix < c.vl; ix += vgrp) {
+          for (u32 ix = s0 + vsub; ix < c.vl; ix += vgrp) {
             if (masked && !v_mask_bit(ix)) continue;
             mem_write(off0 + ((u64)ix << E), 1u << E, vrd_c<E>(vd, ix));
           } };
@@ -2000,7 +2021,7 @@ template <class MEM, bool DRY = false> struct Lane {
       const bool vv = kind == 0;
       esz_switch(c.esz, [&](auto e) {                                           // lanes
         constexpr u32 E = decltype(e)::v;
-#define WSP_VI_CASE(OP) case OP: v_each<E>(c, vd, masked, [&](u32 ix) { return vi_op(OP, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
+#define WSP_VI_CASE(OP) case OP: v_each<E, true>(c, vd, masked, [&](u32 ix) { return vi_op(OP, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
         switch (DRY ? op : ~0u) {                                               // (the general path's copy keeps the one generic loop)
           WSP_VI_CASE(VI_ADD) WSP_VI_CASE(VI_SUB) WSP_VI_CASE(VI_RSUB) WSP_VI_CASE(VI_AND) WSP_VI_CASE(VI_OR) WSP_VI_CASE(VI_XOR)
           WSP_VI_CASE(VI_SLL) WSP_VI_CASE(VI_SRL) WSP_VI_CASE(VI_SRA) WSP_VI_CASE(VI_MINU) WSP_VI_CASE(VI_MIN) WSP_VI_CASE(VI_MAXU)

@@ -42,6 +42,7 @@ struct ProgDev { u64 text_lo, text_hi; const Rec* recs; const HRec* hrecs; };   
 
 struct DevState {
   u32 n_harts, n_waves, lpw, lpw_shift, S, isa, hart_id_base, tlb_n;
+  u32 mtab_off, pad0;  // byte offset in the launch's LDS of the lane table (ln_of): behind everything else, set per launch (launch_step)
   u64 mem_base, mem_size;
   u64* x; u64* f; u64* hot64; u32* hot32; u64* cold;
   u64* tlb;            // [n_harts][tlb_n][2] packed TLB entries (wsp_core.h); null when the ISA has no S
@@ -134,19 +135,21 @@ struct DevMem {
 
 // Mirror lanes.  Measured on gfx950 (tools/lab/valu_rate.hip): a wave that has its SIMD to itself issues a vector ALU instruction
 // every ~1.9 ns with 15 or more lanes enabled in exec, but only every ~8.6 ns with 4 or fewer - and small batches put 1 .. 8 harts
-// in a wave.  So in batches without V (whose idle lanes serve as vector sub-groups) with up to 8 harts per wave, lanes lpw .. 15
-// run COPIES of the harts of lanes 0 .. lpw - 1 (lane l copies hart l mod lpw): same state loaded, same instructions executed in
+// in a wave, while in a wave of many different programs the few harts that run long (a fuzz program caught in a trap loop until its
+// instruction limit) end up alone: tools/exp_replicas.py measured 2.4 us per instruction for such a hart with 15 copies beside it
+// against ~10 us alone.  So in batches without V (whose idle lanes serve as vector sub-groups) the lanes that have no running hart
+// of their own at the start of a launch run COPIES of the wave's running harts: same state loaded, same instructions executed in
 // lock step, the same values stored to the same addresses at the same time (LDS register files, arena, HBM state rows, TLB, commit
 // ring: every store of a copy is the owner's store again; nothing on these paths is an atomic), results of the copies ignored.
+// The assignment is made once per launch (wsp_step_kernel) and kept in LDS: wsp_mtab[lane] = the lane whose hart this lane works
+// on | 0x100 for a copy | 0x200 for a lane with nothing to do.  Waves whose running harts share one program get copies up to 16
+// enabled lanes (they execute together anyway); waves of different programs use every idle lane, dealt out in turn.  Batches in
+// which waves mix programs run in short slices (wsp_batch_run), so that the lanes of harts that have finished are dealt out again.
 #define WSP_MIRROR_LANES 16u
-__device__ __forceinline__ bool wsp_mirrors(const DevState& d) { return !d.vreg && d.lpw <= 8; }
-__device__ __forceinline__ u32 ln_of(const DevState& d)
-{
-  const u32 lane = threadIdx.x;
-  if (lane < d.lpw) return blockIdx.x * d.lpw + lane < d.n_harts ? lane : 0;
-  const u32 own = lane & (d.lpw - 1);
-  return (wsp_mirrors(d) && lane < WSP_MIRROR_LANES && blockIdx.x * d.lpw + own < d.n_harts) ? own : 0;
-}
+// (the table sits behind the register files in the launch's dynamic LDS, not in a static array: the hand-written loop addresses the
+// register files by LDS offsets that take wsp_lds to be at LDS address 0)
+__device__ __forceinline__ u32* wsp_mtab_of(const DevState& d) { return (u32*)((char*)wsp_lds + d.mtab_off); }
+__device__ __forceinline__ u32 ln_of(const DevState& d) { return wsp_mtab_of(d)[threadIdx.x] & 0xffu; }
 
 template <class LaneT> __device__ __forceinline__ void wsp_lane_setup(LaneT& L, const DevState& d, u32 wave, u32 ln, u32 slot, const Rec*& recs)
 {
@@ -614,14 +617,38 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   const unsigned long long pk0 = WSP_PROF_T();
   const u32 lane = threadIdx.x, wave = blockIdx.x;
   const u32 hart = wave * d.lpw + lane;
-  const bool active = lane < d.lpw && hart < d.n_harts;
-  // a lane without a hart looks at hart 0's slot; in a V batch at the slot of the hart whose sub-group it belongs to (wsp_vwarm)
-  const u32 own = lane & (d.lpw - 1);
-  const bool mirror = wsp_mirrors(d) && lane >= d.lpw && lane < WSP_MIRROR_LANES && wave * d.lpw + own < d.n_harts;   // see ln_of
-  const bool live = active || mirror;
-  const u32 ln = live ? own : (d.vreg && wave * d.lpw + own < d.n_harts) ? own : 0;
-  const u32 slot = wave * 64 + ln;
   const u32 S = d.S;
+  const bool has_own = lane < d.lpw && hart < d.n_harts;
+  // which hart this lane works on during this launch (see "Mirror lanes" above)
+  bool mirror = false;
+  {
+    u32 ent = has_own ? lane : 0x200u;
+    if (!d.vreg) {
+      const bool own_run = has_own && d.hot32[H32_STATUS * S + wave * 64 + lane] == (u32)ST_RUNNING;
+      const unsigned long long rm = __ballot(own_run);
+      const u32 nrun = (u32)__popcll(rm);
+      const u32 pgl = own_run ? d.prog[wave * 64 + lane] : 0;
+      const u32 pgf = nrun ? (u32)__builtin_amdgcn_readlane((int)pgl, __ffsll((long long)rm) - 1) : ~0u;
+      const bool same = pgf != ~0u && __all(!own_run || pgl == pgf);     // (all lanes vote: outside the branch below)
+      if (nrun && !own_run) {
+        const u32 target = same ? WSP_MIRROR_LANES : 64u;
+        const u32 rank = (u32)__popcll(~rm & ((1ULL << lane) - 1));       // this lane's place among the lanes without a running hart
+        if (nrun + rank < target) {
+          unsigned long long t = rm;
+          for (u32 k = rank % nrun; k; --k) t &= t - 1;                   // drop the k lowest running lanes
+          ent = (u32)(__ffsll((long long)t) - 1) | 0x100u;
+          mirror = true;
+        }
+      }
+    }
+    wsp_mtab_of(d)[lane] = ent;
+  }
+  const bool active = has_own && !mirror;                // this lane's own hart (running or not): its state is loaded and stored here
+  // a lane with nothing to do looks at hart 0's slot; in a V batch at the slot of the hart whose sub-group it belongs to (wsp_vwarm)
+  const u32 own = lane & (d.lpw - 1);
+  const bool live = active || mirror;
+  const u32 ln = live ? (wsp_mtab_of(d)[lane] & 0xffu) : (d.vreg && wave * d.lpw + own < d.n_harts) ? own : 0;
+  const u32 slot = wave * 64 + ln;
 
   Lane<DevMem> L; const Rec* recs;
   wsp_lane_setup(L, d, wave, ln, slot, recs);
@@ -2268,6 +2295,7 @@ template <bool TRACE, bool FP> static hipError_t launch_step(wsp_batch* b, u64 s
   DevState& d = b->d;
   size_t lds = (size_t)d.lpw * WSP_XSLOTS * 8 * (FP ? 2 : 1);
   if (d.vreg) lds = (size_t)d.lpw * (2 * WSP_XSLOTS * 8 + 32 * d.vlenb + 32);     // x block, f block, vector register files, vector CSRs
+  d.mtab_off = (u32)lds; lds += 64 * 4;                                          // the lane table (ln_of)
   hipError_t e = hipMemcpyAsync(b->d_state, &d, sizeof(DevState), hipMemcpyHostToDevice, b->stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((wsp_step_kernel<TRACE, FP>), dim3(d.n_waves), dim3(64), lds, b->stream, d, (const DevState*)b->d_state, steps, notrace);
@@ -2278,21 +2306,24 @@ extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flag
 {
   if (!b) return fail(WSP_EINVAL, "null batch");
   HIPOK(hipSetDevice(b->device));
-  const u64 SLICE = 1ULL << 24;
   u64 remaining = max_steps; u32 running = 0;
   b->last_kernel_s = 0; b->last_launches = 0;
   bool trace = (flags & WSP_RUN_TRACE_HASH) != 0;
   // The lean TRACE = false kernels only for untraced batches whose every wave runs a single program image (their converged
   // loop); any other untraced batch runs the TRACE = true kernel with `notrace` set.
-  bool lean = !trace;
-  if (lean) {
+  bool uniform = true;
+  {
     const DevState& d = b->d;
-    for (u32 w = 0; w < d.n_waves && lean; ++w) {
+    for (u32 w = 0; w < d.n_waves && uniform; ++w) {
       const u32 h0 = w * d.lpw, h1 = std::min(d.n_harts, h0 + d.lpw), pg = b->hart_prog[h0];
-      if (pg == ~0u) lean = false;
-      for (u32 h = h0 + 1; h < h1 && lean; ++h) lean = b->hart_prog[h] == pg;
+      if (pg == ~0u) uniform = false;
+      for (u32 h = h0 + 1; h < h1 && uniform; ++h) uniform = b->hart_prog[h] == pg;
     }
   }
+  const bool lean = !trace && uniform;
+  // Steps per launch.  Waves that mix programs finish their harts at very different times, and the lanes of finished harts are
+  // dealt out as copies of the ones still running only at the start of a launch (step kernel, "Mirror lanes"): short slices there.
+  const u64 SLICE = (uniform || b->d.vreg) ? (1ULL << 24) : (1ULL << 12);
   const u32 nt = trace ? 0u : 1u;
   do {
     u64 n = std::min(remaining, SLICE);
