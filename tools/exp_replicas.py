@@ -15,7 +15,7 @@ progs = []
 for g in range(nprog):
     progs.append(WL.variant(WL.sv39_program(g // nv), g % nv))
 p0 = progs[0]
-for rep, lanes in ((R, R), (1, R), (1, 1)):
+for rep, lanes in (((R, R), (1, R), (1, 1)) if len(sys.argv) < 4 else [(1, int(x)) for x in sys.argv[3].split(',')]):
     n = nprog * rep
     b = W.Batch(n, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=lanes, tlb_entries=p0.meta.get("tlb_entries", 0))
     try:
@@ -29,7 +29,7 @@ for rep, lanes in ((R, R), (1, R), (1, 1)):
         ks, _ = b.run_stats()
         res = b.results()
         insts = sum(r.exec_count for r in res)
-        print(json.dumps(dict(programs=nprog, replicas=rep, lanes=lanes, harts=n, left=left, kernel_ms=ks * 1e3, instructions=insts, gips=insts / ks / 1e9,
+        print(json.dumps(dict(programs=nprog, replicas=rep, lanes=lanes, harts=n, left=left, launches=b.run_stats()[1], kernel_ms=ks * 1e3, instructions=insts, gips=insts / ks / 1e9,
                               long_harts=sum(1 for r in res if r.exec_count >= p0.max_inst))), flush=True)
     finally:
         b.close()

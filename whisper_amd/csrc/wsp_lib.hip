@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   const bool has_own = lane < d.lpw && hart < d.n_harts;
   // which hart this lane works on during this launch (see "Mirror lanes" above)
   bool mirror = false;
+  u32 run_pg = ~0u; bool run_same = false;               // the running harts' common program image, if they have one
   {
     u32 ent = has_own ? lane : 0x200u;
     if (!d.vreg) {
@@ -630,6 +631,7 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
       const u32 pgl = own_run ? d.prog[wave * 64 + lane] : 0;
       const u32 pgf = nrun ? (u32)__builtin_amdgcn_readlane((int)pgl, __ffsll((long long)rm) - 1) : ~0u;
       const bool same = pgf != ~0u && __all(!own_run || pgl == pgf);     // (all lanes vote: outside the branch below)
+      run_pg = pgf; run_same = same;
       if (nrun && !own_run) {
         const u32 target = same ? WSP_MIRROR_LANES : 64u;
         const u32 rank = (u32)__popcll(~rm & ((1ULL << lane) - 1));       // this lane's place among the lanes without a running hart
@@ -689,8 +691,10 @@ __global__ void __launch_bounds__(64, WSP_WAVES_PER_EU) wsp_step_kernel(DevState
   const bool rv32 = (d.isa & ISA_RV32) != 0;
   const u64 am = rv32 ? 0xffffffffULL : ~0ULL;
   // Every hart of the wave runs the same program image: the converged loop below applies (one pc for the running group).
-  const u32 pg0 = (u32)__builtin_amdgcn_readfirstlane((int)d.prog[wave * 64]);
-  const bool same_prog = pg0 != ~0u && __all(!active || d.prog[slot] == pg0);
+  // (Among the harts that are RUNNING at the start of this launch: a wave of different programs whose other harts have finished
+  // runs its last hart - and the copies of it - through the converged loop too.  V batches: among all the wave's harts.)
+  const u32 pg0 = d.vreg ? (u32)__builtin_amdgcn_readfirstlane((int)d.prog[wave * 64]) : (u32)__builtin_amdgcn_readfirstlane((int)run_pg);
+  const bool same_prog = d.vreg ? (pg0 != ~0u && __all(!active || d.prog[slot] == pg0)) : run_same;
 
   // Outer loop: { hot inner loop (no calls) ; one general step for the lanes that asked for it }.
   //
