@@ -25,7 +25,7 @@ for rep, lanes in (((R, R), (1, R), (1, 1)) if len(sys.argv) < 4 else [(1, int(x
             for i, p in enumerate(progs):
                 b.load_elf_bytes(p.elf, i * rep, (i + 1) * rep)
         b.set_stop(max_inst=p0.max_inst)
-        left = b.run()
+        left = b.run(trace_hash=bool(os.environ.get('EXP_TRACE')))
         ks, _ = b.run_stats()
         res = b.results()
         insts = sum(r.exec_count for r in res)

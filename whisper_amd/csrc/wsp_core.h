@@ -1522,18 +1522,31 @@ template <class MEM, bool DRY = false> struct Lane {
   // elementwise instruction, split over the sub-group (lane vsub takes elements vsub, vsub + vgrp, ...): body(ix) is the value
   // of an active element; tail and masked-off elements become all ones under the agnostic policies and otherwise stay as they
   // are - isDestActive (VecRegs.hpp:738-757) followed by a write of the value it returned.
+#ifndef WSP_V_BATCH_ALL
+#define WSP_V_BATCH_ALL 0                                // 1: the general path's copy batches too (host test builds of the batch loop)
+#endif
   template <u32 V> struct K { static constexpr u32 v = V; };
   template <class F> WSP_HD static void esz_switch(u32 esz, F&& f)
   { switch (esz) { case 0: f(K<0>()); break; case 1: f(K<1>()); break; case 2: f(K<2>()); break; default: f(K<3>()); break; } }
   template <u32 E> WSP_HD u64 vrd_c(u32 reg, u32 ix) { return m.vld(reg * vlenb + (ix << E), E); }
   template <u32 E> WSP_HD void vst_c(u32 reg, u32 ix, u64 v) { m.vst(reg * vlenb + (ix << E), E, v); }
-  template <u32 E, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
+  template <u32 E, bool BATCH = false, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
   {
     const u64 on = ones_of(E);
     const u32 vl = c.vl < c.elem_max ? c.vl : c.elem_max;
-    // (unrolling the loop by four, to put several LDS round trips in flight at once, measured no gain: vadd.vv 6.9 -> 7.5 us)
-    if (!masked) for (u32 ix = vsub; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
-    else
+    if (!masked) {
+      u32 ix = vsub;
+      if (BATCH) {
+        // small bodies, four elements at a time: all four are read and computed before any is written, so their LDS round trips
+        // overlap (with one wave on the SIMD nothing else hides them; a plain unroll does not help - the compiler keeps every
+        // read behind the write before it, which may alias).  Elementwise instructions: an element depends on its own index only.
+        for (; ix + 3 * vgrp < vl; ix += 4 * vgrp) {
+          const u64 r0 = body(ix), r1 = body(ix + vgrp), r2 = body(ix + 2 * vgrp), r3 = body(ix + 3 * vgrp);
+          vst_c<E>(vd, ix, r0 & on); vst_c<E>(vd, ix + vgrp, r1 & on); vst_c<E>(vd, ix + 2 * vgrp, r2 & on); vst_c<E>(vd, ix + 3 * vgrp, r3 & on);
+        }
+      }
+      for (; ix < vl; ix += vgrp) vst_c<E>(vd, ix, body(ix) & on);
+    } else
       for (u32 ix = vsub; ix < vl; ix += vgrp) {
         if (v_mask_bit(ix)) vst_c<E>(vd, ix, body(ix) & on);
         else if (c.ma) vst_c<E>(vd, ix, on);
@@ -2017,7 +2030,7 @@ template <class MEM, bool DRY = false> struct Lane {
       const bool vv = kind == 0;
       esz_switch(c.esz, [&](auto e) {                                           // lanes
         constexpr u32 E = decltype(e)::v;
-#define WSP_VI_CASE(OP) case OP: v_each<E>(c, vd, masked, [&](u32 ix) { return vi_op(OP, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
+#define WSP_VI_CASE(OP) case OP: v_each<E, DRY || WSP_V_BATCH_ALL>(c, vd, masked, [&](u32 ix) { return vi_op(OP, vrd_c<E>(vs2, ix), vv ? vrd_c<E>(vs1, ix) : scalar, E); }); break;
         switch (DRY ? op : ~0u) {                                               // (the general path's copy keeps the one generic loop)
           WSP_VI_CASE(VI_ADD) WSP_VI_CASE(VI_SUB) WSP_VI_CASE(VI_RSUB) WSP_VI_CASE(VI_AND) WSP_VI_CASE(VI_OR) WSP_VI_CASE(VI_XOR)
           WSP_VI_CASE(VI_SLL) WSP_VI_CASE(VI_SRL) WSP_VI_CASE(VI_SRA) WSP_VI_CASE(VI_MINU) WSP_VI_CASE(VI_MIN) WSP_VI_CASE(VI_MAXU)
@@ -2042,7 +2055,7 @@ template <class MEM, bool DRY = false> struct Lane {
       v_note_write(dg);
       esz_switch(c.esz, [&](auto e) {                                           // lanes
         constexpr u32 E = decltype(e)::v;
-        v_each<E>(c, vd, masked, [&](u32 ix) {
+        v_each<E, DRY || WSP_V_BATCH_ALL>(c, vd, masked, [&](u32 ix) {
           const u64 e1 = vx ? xs : vrd_c<E>(vs1, ix), e2 = vrd_c<E>(vs2, ix), dd = vrd_c<E>(vd, ix);
           return k == 0 ? e1 * e2 + dd : k == 1 ? dd - e1 * e2 : k == 2 ? e1 * dd + e2 : e2 - e1 * dd;
         });
@@ -2063,7 +2076,7 @@ template <class MEM, bool DRY = false> struct Lane {
       if (0 < c.vl) {
         v_note_write(dg);
         esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v;       // lanes
-          v_each<E>(c, vd, false, [&](u32 ix) { return kind == 0 ? vrd_c<E>(vs1, ix) : scalar; }); });
+          v_each<E, DRY || WSP_V_BATCH_ALL>(c, vd, false, [&](u32 ix) { return kind == 0 ? vrd_c<E>(vs1, ix) : scalar; }); });
         sub_fence();
       }
       if (s.vgroup == 0) { s.vgroup = dg / 8; s.chg |= CH_VREG; }               // touchReg (vector.cpp:8150)
@@ -2075,7 +2088,7 @@ template <class MEM, bool DRY = false> struct Lane {
     if (0 < c.vl) {
       v_note_write(dg);
       esz_switch(c.esz, [&](auto e) { constexpr u32 E = decltype(e)::v;         // lanes (v0 is neither vd nor a source here)
-        v_each<E>(c, vd, false, [&](u32 ix) { return v_mask_bit(ix) ? (kind == 0 ? vrd_c<E>(vs1, ix) : scalar) : vrd_c<E>(vs2, ix); }); });
+        v_each<E, DRY || WSP_V_BATCH_ALL>(c, vd, false, [&](u32 ix) { return v_mask_bit(ix) ? (kind == 0 ? vrd_c<E>(vs1, ix) : scalar) : vrd_c<E>(vs2, ix); }); });
       sub_fence();
     }
     vec_success();
