@@ -11,7 +11,7 @@ nv = 50
 progs = [WL.variant(WL.sv39_program(g // nv), g % nv) for g in range(nprog)]
 p0 = progs[0]
 for N in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,4096,16384").split(",")]:
-    b = W.Batch(nprog, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=1, tlb_entries=p0.meta.get("tlb_entries", 0))
+    b = W.Batch(nprog, isa=p0.isa, mem_base=p0.mem_base, mem_size=p0.mem_size, lanes_per_wave=int(os.environ.get("EXP_LANES", "1")), tlb_entries=p0.meta.get("tlb_entries", 0))
     try:
         b.load_elfs([p.elf for p in progs], lo=0)
         b.set_stop(max_inst=p0.max_inst)
