@@ -2325,13 +2325,11 @@ extern "C" int64_t wsp_batch_run(wsp_batch* b, uint64_t max_steps, uint32_t flag
     }
   }
   const bool lean = !trace && uniform;
-  // Steps per launch.  The lanes of harts that have finished are dealt out as copies of the ones still running only at the start of
-  // a launch (step kernel, "Mirror lanes"), so short slices would let the last harts of a wave of different programs run with
-  // copies beside them.  Measured on a batch of 1600 different Sv39 fuzz programs (tools/exp_replicas.py, gpu_pmc_exp.sh,
-  // profiles/r03_exp_*): the harts that run on alone do need 2.4x fewer cycles per instruction with copies, but a launch whose
-  // grid leaves the machine nearly idle (47 busy waves) runs at a ~3x lower shader clock than the tail of one long launch does
-  // (SQ_BUSY_CYCLES per ms: 21 M against 64 M), and 15 launches of 4096 steps took 351 ms against 142 ms for the one-hart-per-wave
-  // layout in one launch.  So: one launch per 2^24 steps; WSP_SLICE_STEPS overrides it (tuning aid).
+  // Steps per launch.  The lanes without a running hart are dealt out as copies of the running ones at the start of a launch
+  // (step kernel, "Mirror lanes").  Cutting the run of a batch of different programs into launches of 4096 steps, so that the
+  // lanes of finished harts are dealt out again, measured no gain (1600 different Sv39 fuzz programs, 4 per wave: 351 ms sliced,
+  // 357 ms in one launch, 360 ms with the lanes dealt out again inside the launch; 144 ms one hart per wave - profiles/r03_exp_*),
+  // so a launch runs 2^24 steps; WSP_SLICE_STEPS overrides it (tuning aid).
   u64 SLICE = 1ULL << 24;
   if (const char* e = getenv("WSP_SLICE_STEPS")) { const unsigned long long v = strtoull(e, nullptr, 0); if (v) SLICE = v; }
   (void)uniform;
