@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_INST = 8.0        # SURVEY.md 8(d) model: 4 B fetch + ~0.3 x 8 B data + slice state swap, rounded up
 N_SIMD, CLK_HZ = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 clocks
-PROFILE_TAG = "r03_b"            # profiles/<tag>_pmc_per_launch.json + <tag>_bench.json: rocprofv3 --pmc passes of this same command
+PROFILE_TAG = "r03_d"            # profiles/<tag>_pmc_per_launch.json + <tag>_bench.json: rocprofv3 --pmc passes of this same command
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_per_launch.json")
 CSRC = [os.path.join(ROOT, "whisper_amd", "csrc", f) for f in ("wsp_lib.hip", "wsp_core.h", "wsp_conv_core.h", "wsp_conv_handlers.inc", "wsp_softfloat.h")]
 
