@@ -22,7 +22,9 @@ for separate in (True, False):
         b.set_stop(max_inst=p0.max_inst)
         if os.environ.get('EXP_STOP_OTHERS'):
             for i in range(nprog):
-                b.set_stop(max_inst=10, lo=4 * i + 1, hi=4 * i + 4)
+                keep = int(os.environ['EXP_STOP_OTHERS']) & 3
+                for l in range(4):
+                    if l != keep: b.set_stop(max_inst=10, lo=4 * i + l, hi=4 * i + l + 1)
         b.run(trace_hash=bool(os.environ.get("EXP_TRACE")))
         ks, launches = b.run_stats()
         print(json.dumps(dict(programs=nprog, separate_images=separate, kernel_ms=ks * 1e3)), flush=True)

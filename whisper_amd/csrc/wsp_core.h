@@ -1530,12 +1530,12 @@ template <class MEM, bool DRY = false> struct Lane {
   { switch (esz) { case 0: f(K<0>()); break; case 1: f(K<1>()); break; case 2: f(K<2>()); break; default: f(K<3>()); break; } }
   template <u32 E> WSP_HD u64 vrd_c(u32 reg, u32 ix) { return m.vld(reg * vlenb + (ix << E), E); }
   template <u32 E> WSP_HD void vst_c(u32 reg, u32 ix, u64 v) { m.vst(reg * vlenb + (ix << E), E, v); }
-  template <u32 E, bool BATCH = false, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body, u32 first = ~0u)
+  template <u32 E, bool BATCH = false, class F> WSP_HD void v_each(const VCfg& c, u32 vd, bool masked, F&& body)
   {
     const u64 on = ones_of(E);
     const u32 vl = c.vl < c.elem_max ? c.vl : c.elem_max;
     if (!masked) {
-      u32 ix = first != ~0u ? first : vsub;              // (first: the caller has done this lane's elements below it already)
+      u32 ix = vsub;
       if (BATCH) {
         // small bodies, four elements at a time: all four are read and computed before any is written, so their LDS round trips
         // overlap (with one wave on the SIMD nothing else hides them; a plain unroll does not help - the compiler keeps every
@@ -2686,35 +2686,6 @@ template <class MEM, bool DRY = false> struct Lane {
           if (rm == RM_RNE && (w ? hw_fma32(a, b, c3, z, fl) : hw_fma64(a, b, c3, z, fl))) return z;
           return w ? f_fma<F32>(a, b, c3, rm, fl) : f_fma<F64>(a, b, c3, rm, fl);
         };
-        // Warm path, unmasked, round to nearest even, no negated operand (add / sub / mul / div and their reversed forms, vfmadd,
-        // vfmacc): four elements at a time on the FP unit - the hw_* routines are chains of dependent binary64 operations with long
-        // latencies, and four independent chains overlap.  The first element whose operands or result are not ordinary ends the
-        // batches; the loop below finishes the instruction one element at a time (FP unit or integer softfloat, as before).
-        u32 first = ~0u;
-        if ((DRY || WSP_V_BATCH_ALL) && !masked && rm == RM_RNE && (op < 6 || op == 8 || op == 12)) {
-          auto hw_elem = [&](u32 ix, u64& z, unsigned& f) -> bool {
-            const u64 e1 = vf ? sc : vrd_c<E>(vs1, ix), e2 = vrd_c<E>(vs2, ix);
-            if (op < 6) {
-              u64 a = e2, b = e1; u32 o = op;
-              if (o >= 4) { a = e1; b = e2; o = o == 4 ? 1u : 3u; }
-              if (w) return o == 0 ? hw_add32(a, b, z, f) : o == 1 ? hw_add32(a, b ^ F32::SIGN, z, f) : o == 2 ? hw_mul32(a, b, z, f) : hw_div32(a, b, z, f);
-              return o == 0 ? hw_add64(a, b, z, f) : o == 1 ? hw_add64(a, b ^ F64::SIGN, z, f) : o == 2 ? hw_mul64(a, b, z, f) : hw_div64(a, b, z, f);
-            }
-            const u64 dd = vrd_c<E>(vd, ix);
-            if (op == 8) return w ? hw_fma32(e1, dd, e2, z, f) : hw_fma64(e1, dd, e2, z, f);     // vfmadd: vd * vs1 + vs2
-            return w ? hw_fma32(e1, e2, dd, z, f) : hw_fma64(e1, e2, dd, z, f);                   // vfmacc: vs1 * vs2 + vd
-          };
-          const u32 vl = c.vl < c.elem_max ? c.vl : c.elem_max;
-          u32 ix = vsub;
-          for (; ix + 3 * vgrp < vl; ix += 4 * vgrp) {
-            u64 z0 = 0, z1 = 0, z2 = 0, z3 = 0; unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-            const bool k0 = hw_elem(ix, z0, f0), k1 = hw_elem(ix + vgrp, z1, f1), k2 = hw_elem(ix + 2 * vgrp, z2, f2), k3 = hw_elem(ix + 3 * vgrp, z3, f3);
-            if (!(k0 & k1 & k2 & k3)) break;
-            fl |= f0 | f1 | f2 | f3;
-            vst_c<E>(vd, ix, z0); vst_c<E>(vd, ix + vgrp, z1); vst_c<E>(vd, ix + 2 * vgrp, z2); vst_c<E>(vd, ix + 3 * vgrp, z3);
-          }
-          first = ix;
-        }
         v_each<E>(c, vd, masked, [&](u32 ix) -> u64 {
           u64 e1 = vf ? sc : vrd_c<E>(vs1, ix), e2 = vrd_c<E>(vs2, ix);
           if (op < 8) return vf_op(op, e2, e1, E, rm, fl);
@@ -2731,7 +2702,7 @@ template <class MEM, bool DRY = false> struct Lane {
           }
           if (op < 18) return w ? vf_minmax<F32>(op == 17, e2, e1, fl) : vf_minmax<F64>(op == 17, e2, e1, fl);
           return (e2 & ~sign) | ((op == 18 ? e1 : op == 19 ? ~e1 : e2 ^ e1) & sign);
-        }, first);
+        });
       };
       if (w) run(K<2>()); else run(K<3>());
       sub_fence();
