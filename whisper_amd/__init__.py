@@ -59,8 +59,21 @@ def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     deps = [SRC, os.path.join(HERE, "csrc", "wsp_core.h"), os.path.join(HERE, "csrc", "wsp_conv_core.h"), os.path.join(HERE, "csrc", "wsp_conv_handlers.inc"), os.path.join(HERE, "csrc", "wsp_softfloat.h"), os.path.join(HERE, "csrc", "wsp_config.h"),
             os.path.join(HERE, "csrc", "wsp_disasm.h"), os.path.join(HERE, "csrc", "wsp_disasm_tables.inc"), os.path.join(ROOT, "include", "whisper_amd.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    # fresh = built from exactly these sources: a digest of them is kept beside the library (file times do not survive copies of the
+    # tree, and the device compile takes a quarter of an hour); a library without a digest file falls back to the file times
+    import hashlib
+    h = hashlib.sha256()
+    for d in deps:
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    digest = h.hexdigest()
+    dpath = LIB_PATH + ".digest"
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.exists(dpath):
+            if open(dpath).read().strip() == digest:
+                return LIB_PATH
+        elif all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     # -structurizecfg-skip-uniform-regions: the interpreter's dispatch is a tree of wave-uniform branches; left to the
     # structurizer every level of it costs three extra scalar instructions (measured: 10.6 -> 11.9 GIPS, profiles/README.md)
@@ -68,6 +81,8 @@ def build(force=False):
     # compiling the four kernels side by side repeats it four times (tried: no gain)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            "-mllvm", "-structurizecfg-skip-uniform-regions", "-o", LIB_PATH, SRC])
+    with open(dpath, "w") as fh:
+        fh.write(digest + "\n")
     return LIB_PATH
 
 
